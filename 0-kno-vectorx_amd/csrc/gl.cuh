@@ -1,0 +1,84 @@
+// Goldilocks field (p = 2^64 - 2^32 + 1) and quadratic extension F_p[X]/(X^2-7)
+// device arithmetic for gfx950.  K1 of SURVEY.md section 2.2: what plonky2_field
+// (v0.2.0, Cargo.lock:4871-4873; used by the reference at header.rs:47,
+// subchain_verification.rs:448) provides on the CPU.
+//
+// CDNA4 has no 64x64->128 multiply: the product is built from 32-bit
+// v_mul_lo/v_mul_hi/v_mad_u64_u32 (the compiler's expansion of __umul64hi) and
+// reduced with 2^64 = 2^32 - 1, 2^96 = -1 (mod p).  Every function takes and
+// returns CANONICAL values (< p) unless its name says otherwise.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GL_P 0xFFFFFFFF00000001ULL
+#define GL_EPS 0xFFFFFFFFULL
+
+struct gl2 {
+    uint64_t a, b;  // a + b X
+};
+
+__device__ __forceinline__ uint64_t gl_canon(uint64_t x) { return x >= GL_P ? x - GL_P : x; }
+
+__device__ __forceinline__ uint64_t gl_add(uint64_t a, uint64_t b) {
+    uint64_t s = a + b;
+    uint64_t t = s + GL_EPS;  // s - p (mod 2^64)
+    return (s < a || s >= GL_P) ? t : s;
+}
+__device__ __forceinline__ uint64_t gl_sub(uint64_t a, uint64_t b) {
+    uint64_t d = a - b;
+    return a < b ? d - GL_EPS : d;  // + p (mod 2^64)
+}
+__device__ __forceinline__ uint64_t gl_neg(uint64_t a) { return a ? GL_P - a : 0; }
+__device__ __forceinline__ uint64_t gl_dbl(uint64_t a) { return gl_add(a, a); }
+
+// (hi, lo) 128-bit -> canonical
+__device__ __forceinline__ uint64_t gl_reduce128(uint64_t hi, uint64_t lo) {
+    uint64_t hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
+    uint64_t t0 = lo - hi_hi;
+    if (lo < hi_hi) t0 -= GL_EPS;  // borrow: add p
+    uint64_t t1 = hi_lo * GL_EPS;  // < 2^64
+    uint64_t t2 = t0 + t1;
+    if (t2 < t1) t2 += GL_EPS;  // carry: subtract p (mod 2^64 adds eps)
+    return gl_canon(t2);
+}
+__device__ __forceinline__ uint64_t gl_mul(uint64_t a, uint64_t b) {
+    return gl_reduce128(__umul64hi(a, b), a * b);
+}
+__device__ __forceinline__ uint64_t gl_sqr(uint64_t a) { return gl_mul(a, a); }
+// multiply by a small constant c < 2^32
+__device__ __forceinline__ uint64_t gl_mul_small(uint64_t a, uint32_t c) {
+    uint64_t lo = (a & GL_EPS) * c;  // < 2^64
+    uint64_t hi = (a >> 32) * c;     // < 2^64, weight 2^32
+    // a*c = lo + hi*2^32 ; hi*2^32 = (hi_lo << 32) + hi_hi * 2^64
+    uint64_t hi_lo = hi & GL_EPS, hi_hi = hi >> 32;
+    uint64_t r = gl_canon(lo);
+    r = gl_add(r, gl_canon(hi_lo << 32));
+    r = gl_add(r, hi_hi * GL_EPS);  // hi_hi < 2^32 so product < p
+    return r;
+}
+__device__ __forceinline__ uint64_t gl_pow(uint64_t a, uint64_t e) {
+    uint64_t r = 1;
+    while (e) {
+        if (e & 1) r = gl_mul(r, a);
+        a = gl_sqr(a);
+        e >>= 1;
+    }
+    return r;
+}
+__device__ __forceinline__ uint64_t gl_inv(uint64_t a) { return gl_pow(a, GL_P - 2); }
+
+__device__ __forceinline__ gl2 gl2_add(gl2 x, gl2 y) { return {gl_add(x.a, y.a), gl_add(x.b, y.b)}; }
+__device__ __forceinline__ gl2 gl2_sub(gl2 x, gl2 y) { return {gl_sub(x.a, y.a), gl_sub(x.b, y.b)}; }
+__device__ __forceinline__ gl2 gl2_mul(gl2 x, gl2 y) {
+    uint64_t bb = gl_mul(x.b, y.b);
+    return {gl_add(gl_mul(x.a, y.a), gl_mul_small(bb, 7)), gl_add(gl_mul(x.a, y.b), gl_mul(x.b, y.a))};
+}
+__device__ __forceinline__ gl2 gl2_scale(gl2 x, uint64_t s) { return {gl_mul(x.a, s), gl_mul(x.b, s)}; }
+__device__ __forceinline__ gl2 gl2_inv(gl2 x) {
+    uint64_t n = gl_sub(gl_sqr(x.a), gl_mul_small(gl_sqr(x.b), 7));
+    uint64_t ni = gl_inv(n);
+    return {gl_mul(x.a, ni), gl_mul(gl_neg(x.b), ni)};
+}
+
+__device__ __forceinline__ uint32_t brev32(uint32_t x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }

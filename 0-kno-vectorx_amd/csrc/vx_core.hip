@@ -1,0 +1,259 @@
+// Context lifecycle, HBM buffers, K1 batch field arithmetic.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "gl.cuh"
+#include "vx_internal.h"
+
+int32_t vx_fail(vx_ctx* ctx, int32_t code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+static int32_t make_powtab(vx_ctx* ctx, uint64_t base, PowTab* out) {
+    std::vector<uint64_t> h(3 * 2048);
+    uint64_t b = base;
+    for (int l = 0; l < 3; ++l) {
+        uint64_t acc = 1;
+        for (int j = 0; j < 2048; ++j) {
+            h[l * 2048 + j] = acc;
+            acc = glh::mul(acc, b);
+        }
+        b = glh::pow(b, 2048);
+    }
+    VX_HIP(hipMalloc(&out->d, h.size() * 8));
+    VX_HIP(hipMemcpyAsync(out->d, h.data(), h.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    VX_HIP(hipStreamSynchronize(ctx->stream));
+    return VX_OK;
+}
+
+int32_t vx_get_shift_tab(vx_ctx* ctx, uint64_t base, PowTab* out) {
+    auto it = ctx->shift_tabs.find(base);
+    if (it == ctx->shift_tabs.end()) {
+        PowTab t;
+        VX_TRY(make_powtab(ctx, base, &t));
+        it = ctx->shift_tabs.emplace(base, t).first;
+    }
+    *out = it->second;
+    return VX_OK;
+}
+
+int32_t vx_scratch(vx_ctx* ctx, size_t n, uint64_t** out) {
+    if (ctx->scratch_n < n) {
+        if (ctx->scratch) {
+            VX_HIP(hipStreamSynchronize(ctx->stream));
+            VX_HIP(hipFree(ctx->scratch));
+            ctx->scratch = nullptr;
+            ctx->scratch_n = 0;
+        }
+        VX_HIP(hipMalloc(&ctx->scratch, n * 8));
+        ctx->scratch_n = n;
+    }
+    *out = ctx->scratch;
+    return VX_OK;
+}
+
+extern "C" {
+
+const char* vx_backend_name(void) { return "hip-gfx950"; }
+
+int32_t vx_ctx_create(int device, vx_ctx** out) {
+    if (!out) return VX_ERR_ARG;
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0 || device < 0 || device >= n_dev) return VX_ERR_DEVICE;
+    vx_ctx* ctx = new vx_ctx();
+    ctx->device = device;
+    ctx->scratch = nullptr;
+    ctx->scratch_n = 0;
+    ctx->pinned = nullptr;
+    ctx->pinned_n = 0;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return VX_ERR_DEVICE;
+    }
+    int32_t rc = make_powtab(ctx, glh::ROOT_2_32, &ctx->tw_fwd);
+    if (rc == VX_OK) rc = make_powtab(ctx, glh::inv(glh::ROOT_2_32), &ctx->tw_inv);
+    if (rc == VX_OK) {
+        std::vector<uint64_t> f(2048), b(2048);
+        uint64_t w = glh::root(12), wi = glh::inv(w), a = 1, c = 1;
+        for (int j = 0; j < 2048; ++j) {
+            f[j] = a;
+            b[j] = c;
+            a = glh::mul(a, w);
+            c = glh::mul(c, wi);
+        }
+        if (hipMalloc(&ctx->w12_fwd, 2048 * 8) != hipSuccess || hipMalloc(&ctx->w12_inv, 2048 * 8) != hipSuccess ||
+            hipMemcpy(ctx->w12_fwd, f.data(), 2048 * 8, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(ctx->w12_inv, b.data(), 2048 * 8, hipMemcpyHostToDevice) != hipSuccess)
+            rc = VX_ERR_DEVICE;
+    }
+    if (rc == VX_OK) {
+        ctx->pinned_n = 1 << 20;
+        if (hipHostMalloc(&ctx->pinned, ctx->pinned_n) != hipSuccess) rc = VX_ERR_DEVICE;
+    }
+    if (rc != VX_OK) {
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return VX_OK;
+}
+
+int32_t vx_ctx_destroy(vx_ctx* ctx) {
+    if (!ctx) return VX_ERR_ARG;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->shift_tabs) hipFree(kv.second.d);
+    hipFree(ctx->tw_fwd.d);
+    hipFree(ctx->tw_inv.d);
+    hipFree(ctx->w12_fwd);
+    hipFree(ctx->w12_inv);
+    if (ctx->scratch) hipFree(ctx->scratch);
+    if (ctx->pinned) hipHostFree(ctx->pinned);
+    hipEventDestroy(ctx->ev0);
+    hipEventDestroy(ctx->ev1);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return VX_OK;
+}
+
+int32_t vx_sync(vx_ctx* ctx) {
+    if (!ctx) return VX_ERR_ARG;
+    VX_HIP(hipStreamSynchronize(ctx->stream));
+    return VX_OK;
+}
+const char* vx_last_error(const vx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int32_t vx_timer_start(vx_ctx* ctx) {
+    if (!ctx) return VX_ERR_ARG;
+    VX_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    return VX_OK;
+}
+int32_t vx_timer_stop(vx_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return VX_ERR_ARG;
+    VX_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    VX_HIP(hipEventSynchronize(ctx->ev1));
+    VX_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return VX_OK;
+}
+
+int32_t vx_alloc(vx_ctx* ctx, size_t n, vx_buf** out) {
+    if (!ctx || !out) return VX_ERR_ARG;
+    VX_CHECK(n > 0, "vx_alloc: n == 0");
+    vx_buf* b = new vx_buf{nullptr, n};
+    hipError_t e = hipMalloc(&b->d, n * 8);
+    if (e != hipSuccess) {
+        delete b;
+        return vx_fail(ctx, VX_ERR_OOM, "hipMalloc(%zu bytes): %s", n * 8, hipGetErrorString(e));
+    }
+    *out = b;
+    return VX_OK;
+}
+int32_t vx_free(vx_ctx* ctx, vx_buf* buf) {
+    if (!ctx || !buf) return VX_ERR_ARG;
+    VX_HIP(hipStreamSynchronize(ctx->stream));
+    VX_HIP(hipFree(buf->d));
+    delete buf;
+    return VX_OK;
+}
+int32_t vx_upload(vx_ctx* ctx, vx_buf* dst, size_t off, const uint64_t* src, size_t n) {
+    if (!ctx || !dst || !src) return VX_ERR_ARG;
+    VX_CHECK(off + n <= dst->n, "vx_upload: range [%zu,%zu) exceeds buffer of %zu", off, off + n, dst->n);
+    VX_HIP(hipMemcpyAsync(dst->d + off, src, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    VX_HIP(hipStreamSynchronize(ctx->stream));  // caller may reuse src immediately
+    return VX_OK;
+}
+int32_t vx_download(vx_ctx* ctx, const vx_buf* src, size_t off, uint64_t* dst, size_t n) {
+    if (!ctx || !dst || !src) return VX_ERR_ARG;
+    VX_CHECK(off + n <= src->n, "vx_download: range [%zu,%zu) exceeds buffer of %zu", off, off + n, src->n);
+    VX_HIP(hipMemcpyAsync(dst, src->d + off, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipStreamSynchronize(ctx->stream));
+    return VX_OK;
+}
+int32_t vx_copy(vx_ctx* ctx, vx_buf* dst, size_t doff, const vx_buf* src, size_t soff, size_t n) {
+    if (!ctx || !dst || !src) return VX_ERR_ARG;
+    VX_CHECK(doff + n <= dst->n && soff + n <= src->n, "vx_copy: out of range");
+    VX_HIP(hipMemcpyAsync(dst->d + doff, src->d + soff, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return VX_OK;
+}
+void* vx_buf_devptr(const vx_buf* buf) { return buf ? buf->d : nullptr; }
+size_t vx_buf_len(const vx_buf* buf) { return buf ? buf->n : 0; }
+}  // extern "C"
+
+// ---------------------------------------------------------------- kernels
+__global__ void k_fill_random(uint64_t* d, size_t n, uint64_t seed) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint64_t z = seed + 0x9E3779B97F4A7C15ULL * (i + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z ^= z >> 31;
+        d[i] = gl_canon(z);
+    }
+}
+template <int OP>
+__global__ void k_batch(const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint64_t x = a[i], y = OP == 3 ? 0 : b[i], r;
+        if (OP == 0) r = gl_add(x, y);
+        else if (OP == 1) r = gl_sub(x, y);
+        else if (OP == 2) r = gl_mul(x, y);
+        else r = x ? gl_inv(x) : 0;
+        o[i] = r;
+    }
+}
+__global__ void k_ext_mul(const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        gl2 x{a[2 * i], a[2 * i + 1]}, y{b[2 * i], b[2 * i + 1]};
+        gl2 r = gl2_mul(x, y);
+        o[2 * i] = r.a;
+        o[2 * i + 1] = r.b;
+    }
+}
+static inline unsigned grid_for(size_t n) {
+    size_t g = (n + 255) / 256;
+    return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+template <int OP>
+static int32_t batch_op(vx_ctx* ctx, const vx_buf* a, const vx_buf* b, vx_buf* o, size_t n) {
+    if (!ctx || !a || !o || (OP != 3 && !b)) return VX_ERR_ARG;
+    VX_CHECK(n <= a->n && n <= o->n && (OP == 3 || n <= b->n), "batch op: n exceeds a buffer");
+    if (n == 0) return VX_OK;
+    hipLaunchKernelGGL(k_batch<OP>, dim3(grid_for(n)), dim3(256), 0, ctx->stream, a->d, OP == 3 ? a->d : b->d, o->d, n);
+    VX_HIP(hipGetLastError());
+    return VX_OK;
+}
+extern "C" {
+int32_t vx_fill_random(vx_ctx* ctx, vx_buf* dst, size_t off, size_t n, uint64_t seed) {
+    if (!ctx || !dst) return VX_ERR_ARG;
+    VX_CHECK(off + n <= dst->n, "vx_fill_random: out of range");
+    if (n == 0) return VX_OK;
+    hipLaunchKernelGGL(k_fill_random, dim3(grid_for(n)), dim3(256), 0, ctx->stream, dst->d + off, n, seed);
+    VX_HIP(hipGetLastError());
+    return VX_OK;
+}
+int32_t vx_field_batch_add(vx_ctx* c, const vx_buf* a, const vx_buf* b, vx_buf* o, size_t n) { return batch_op<0>(c, a, b, o, n); }
+int32_t vx_field_batch_sub(vx_ctx* c, const vx_buf* a, const vx_buf* b, vx_buf* o, size_t n) { return batch_op<1>(c, a, b, o, n); }
+int32_t vx_field_batch_mul(vx_ctx* c, const vx_buf* a, const vx_buf* b, vx_buf* o, size_t n) { return batch_op<2>(c, a, b, o, n); }
+int32_t vx_field_batch_inv(vx_ctx* c, const vx_buf* a, vx_buf* o, size_t n) { return batch_op<3>(c, a, nullptr, o, n); }
+int32_t vx_ext_batch_mul(vx_ctx* ctx, const vx_buf* a, const vx_buf* b, vx_buf* o, size_t n) {
+    if (!ctx || !a || !b || !o) return VX_ERR_ARG;
+    VX_CHECK(2 * n <= a->n && 2 * n <= b->n && 2 * n <= o->n, "ext batch mul: n exceeds a buffer");
+    if (n == 0) return VX_OK;
+    hipLaunchKernelGGL(k_ext_mul, dim3(grid_for(n)), dim3(256), 0, ctx->stream, a->d, b->d, o->d, n);
+    VX_HIP(hipGetLastError());
+    return VX_OK;
+}
+}

@@ -1,0 +1,92 @@
+// libvxprove internals: context, device buffers, host-side field helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <vector>
+
+#pragma GCC visibility push(default)
+#include "../../include/vx.h"
+#pragma GCC visibility pop
+
+// ---- host-side Goldilocks (table generation, transcript) ----------------------------
+namespace glh {
+static const uint64_t P = 0xFFFFFFFF00000001ULL;
+static inline uint64_t add(uint64_t a, uint64_t b) {
+    uint64_t s = a + b;
+    return (s < a || s >= P) ? s - P : s;
+}
+static inline uint64_t sub(uint64_t a, uint64_t b) { return a >= b ? a - b : a + (P - b); }
+static inline uint64_t mul(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) % P); }
+static inline uint64_t pow(uint64_t a, uint64_t e) {
+    uint64_t r = 1;
+    while (e) {
+        if (e & 1) r = mul(r, a);
+        a = mul(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+static inline uint64_t inv(uint64_t a) { return pow(a, P - 2); }
+static const uint64_t ROOT_2_32 = 1753635133440165772ULL;  // 7^((p-1)/2^32)
+static inline uint64_t root(int log_n) {
+    uint64_t r = ROOT_2_32;
+    for (int i = 32; i > log_n; --i) r = mul(r, r);
+    return r;
+}
+}  // namespace glh
+
+struct vx_buf {
+    uint64_t* d;
+    size_t n;
+};
+
+// three-level power table of a base b: lvl[0][j] = b^j, lvl[1][j] = b^(j<<11), lvl[2][j] = b^(j<<22), j < 2048
+struct PowTab {
+    uint64_t* d;  // 3*2048 on device
+};
+
+struct vx_ctx {
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    std::string err;
+    PowTab tw_fwd, tw_inv;       // base = omega_{2^32}, omega_{2^32}^-1
+    uint64_t *w12_fwd, *w12_inv;  // omega_4096^e, e < 2048
+    std::map<uint64_t, PowTab> shift_tabs;
+    uint64_t* scratch;
+    size_t scratch_n;
+    void* pinned;  // small pinned staging area
+    size_t pinned_n;
+};
+
+struct vx_tree {
+    uint64_t* levels;  // level 0 (leaf digests, 4*n) followed by each parent level up to the cap
+    size_t n_leaves;
+    int cap_height;
+    size_t total;  // uint64 count
+};
+
+int32_t vx_fail(vx_ctx* ctx, int32_t code, const char* fmt, ...);
+#define VX_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return vx_fail(ctx, e_ == hipErrorOutOfMemory ? VX_ERR_OOM : VX_ERR_DEVICE, "%s: %s", \
+                           #call, hipGetErrorString(e_));                                         \
+    } while (0)
+#define VX_CHECK(cond, ...)                                   \
+    do {                                                      \
+        if (!(cond)) return vx_fail(ctx, VX_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+#define VX_TRY(call)            \
+    do {                        \
+        int32_t r_ = (call);    \
+        if (r_ != VX_OK) return r_; \
+    } while (0)
+
+int32_t vx_get_shift_tab(vx_ctx* ctx, uint64_t base, PowTab* out);
+int32_t vx_scratch(vx_ctx* ctx, size_t n_u64, uint64_t** out);
+int32_t vx_merkle_build_dev(vx_ctx* ctx, const uint64_t* data, size_t n_leaves, size_t leaf_len, int layout,
+                            int cap_height, vx_tree** out);

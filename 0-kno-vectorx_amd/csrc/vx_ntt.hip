@@ -1,0 +1,371 @@
+// K2/K3: batched Goldilocks NTT and low-degree extension for gfx950.
+//
+// Replaces plonky2_field::fft::{fft,ifft} and PolynomialBatch::{from_values,
+// from_coeffs,lde} (plonky2 v0.2.0 fri/oracle.rs), reached from every
+// `circuit.prove` in the reference (circuits/header_range.rs:167).
+//
+// Design (not a translation of the CPU radix-2 loop): a transform of size
+// n = 2^L is decomposed four-step style into <= 3 in-place passes over HBM;
+// each pass stages a [R rows x T columns] tile (R*T = 4096 elements, 32 KiB)
+// in LDS, runs log2(R) butterfly stages there, and applies the inter-pass
+// twiddle w_S^(i*k) from a three-level power table while the tile moves
+// between LDS and HBM.  Rows of a tile are strided in HBM, the T columns are
+// contiguous (>= 128 B segments), so every global access is coalesced.
+//   DIF-like plan: natural in  -> bit-reversed out   (used for the inverse)
+//   DIT-like plan: bit-reversed in -> natural out    (used for the forward/LDE)
+// so values -> coefficients -> coset evaluations needs NO permutation pass:
+// coefficients simply live in bit-reversed positions in between.  The LDE's
+// zero padding and coset scaling (c_k *= shift^k) are fused into the first
+// DIT pass, which reads only the n = N >> rate_bits real coefficients.
+#include "gl.cuh"
+#include "vx_internal.h"
+
+struct PassArgs {
+    const uint64_t* src;
+    uint64_t* dst;
+    size_t src_col_stride, dst_col_stride;
+    int log_sub;   // S = 2^log_sub: size of the independent sub-arrays at this level
+    int log_rows;  // R = 2^log_rows rows per tile (butterfly stages done in LDS)
+    int log_T;     // T = 2^log_T contiguous columns per tile
+    const uint64_t* w12;  // w_4096^e, e < 2048 (forward or inverse)
+    const uint64_t* tw;   // three-level powers of w_{2^32} (forward or inverse)
+    uint64_t scale;       // DIF mode: multiply on store when > 1 (1/n of the inverse)
+    int expand_bits;      // DIT first pass of an LDE: src holds S >> expand_bits coefficients
+    int log_coeff;        // log2 of the coefficient count (bit-reversal width for shift^k)
+    const uint64_t* shift_tab;  // three-level powers of the coset shift, or null
+};
+
+__device__ __forceinline__ uint64_t tab3_pow(const uint64_t* tab, uint64_t e) {
+    uint64_t r = tab[e & 2047];
+    uint32_t e1 = (uint32_t)(e >> 11) & 2047, e2 = (uint32_t)(e >> 22);
+    if (e1) r = gl_mul(r, tab[2048 + e1]);
+    if (e2) r = gl_mul(r, tab[4096 + e2]);
+    return r;
+}
+// w_{2^log_s}^e from the w_{2^32} table
+__device__ __forceinline__ uint64_t root_pow(const uint64_t* tw, uint64_t e, int log_s) {
+    uint64_t E = (e << (32 - log_s)) & 0xFFFFFFFFULL;
+    uint64_t r = tw[4096 + (E >> 22)];
+    if (log_s > 10) r = gl_mul(r, tw[2048 + ((E >> 11) & 2047)]);
+    if (log_s > 21) r = gl_mul(r, tw[E & 2047]);
+    return r;
+}
+
+// MODE 0: DIF-like pass, MODE 1: DIT-like pass (see file header).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_ntt_pass(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+    const int lr = a.log_rows, lT = a.log_T;
+    const int T = 1 << lT;
+    const int pitch = T > 1 ? T + 1 : 1;
+    const int nelem = 1 << (lr + lT);
+    const size_t m = (size_t)1 << (a.log_sub - lr);  // row stride inside a sub-array
+    const size_t tiles_per_sub = m >> lT;
+    const size_t tile = blockIdx.x;
+    const size_t sub = tile / tiles_per_sub;
+    const size_t col0 = (tile - sub * tiles_per_sub) << lT;
+    const size_t base = (sub << a.log_sub) + col0;
+    const uint64_t* src = a.src + blockIdx.y * a.src_col_stride;
+    uint64_t* dst = a.dst + blockIdx.y * a.dst_col_stride;
+    const int tid = threadIdx.x;
+
+    for (int idx = tid; idx < nelem; idx += 256) {
+        int col = idx & (T - 1), row = idx >> lT;
+        size_t g = base + (size_t)row * m + col;
+        uint64_t v;
+        if (MODE == 1 && a.expand_bits) {
+            v = 0;
+            if ((g & (((size_t)1 << a.expand_bits) - 1)) == 0) {
+                size_t q = g >> a.expand_bits;
+                v = src[q];
+                if (a.shift_tab) v = gl_mul(v, tab3_pow(a.shift_tab, brev32((uint32_t)q, a.log_coeff)));
+            }
+        } else {
+            v = src[g];
+            if (MODE == 1 && a.shift_tab && m == 1)  // plain coset transform: first pass, c_k *= shift^k
+                v = gl_mul(v, tab3_pow(a.shift_tab, brev32((uint32_t)g, a.log_coeff)));
+        }
+        if (MODE == 1 && m > 1) {
+            uint64_t e = (uint64_t)(col0 + col) * brev32((uint32_t)row, lr);
+            v = gl_mul(v, root_pow(a.tw, e, a.log_sub));
+        }
+        lds[row * pitch + col] = v;
+    }
+    __syncthreads();
+
+    const int nbf = nelem >> 1;
+    if (MODE == 0) {
+        for (int s = lr - 1; s >= 0; --s) {
+            const int h = 1 << s;
+            for (int bf = tid; bf < nbf; bf += 256) {
+                int col = bf & (T - 1), pr = bf >> lT;
+                int j = pr & (h - 1);
+                int r0 = ((pr >> s) << (s + 1)) + j;
+                uint64_t u = lds[r0 * pitch + col], v = lds[(r0 + h) * pitch + col];
+                lds[r0 * pitch + col] = gl_add(u, v);
+                lds[(r0 + h) * pitch + col] = gl_mul(gl_sub(u, v), a.w12[j << (11 - s)]);
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int s = 0; s < lr; ++s) {
+            const int h = 1 << s;
+            for (int bf = tid; bf < nbf; bf += 256) {
+                int col = bf & (T - 1), pr = bf >> lT;
+                int j = pr & (h - 1);
+                int r0 = ((pr >> s) << (s + 1)) + j;
+                uint64_t u = lds[r0 * pitch + col];
+                uint64_t v = gl_mul(lds[(r0 + h) * pitch + col], a.w12[j << (11 - s)]);
+                lds[r0 * pitch + col] = gl_add(u, v);
+                lds[(r0 + h) * pitch + col] = gl_sub(u, v);
+            }
+            __syncthreads();
+        }
+    }
+
+    for (int idx = tid; idx < nelem; idx += 256) {
+        int col = idx & (T - 1), row = idx >> lT;
+        uint64_t v = lds[row * pitch + col];
+        if (MODE == 0) {
+            if (m > 1) {
+                uint64_t e = (uint64_t)(col0 + col) * brev32((uint32_t)row, lr);
+                v = gl_mul(v, root_pow(a.tw, e, a.log_sub));
+            }
+            if (a.scale > 1) v = gl_mul(v, a.scale);
+        }
+        dst[base + (size_t)row * m + col] = v;
+    }
+}
+
+// out[i] = in[bitrev(i)] (per column); in != out
+__global__ void k_bitrev_copy(const uint64_t* in, uint64_t* out, int log_n, size_t in_stride, size_t out_stride) {
+    size_t n = (size_t)1 << log_n;
+    const uint64_t* s = in + blockIdx.y * in_stride;
+    uint64_t* d = out + blockIdx.y * out_stride;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        d[i] = s[brev32((uint32_t)i, log_n)];
+}
+// c_k = c_k * mulc * base^k (natural order); tab may be null (base = 1)
+__global__ void k_scale_pow(uint64_t* d, int log_n, size_t stride, const uint64_t* tab, uint64_t mulc) {
+    size_t n = (size_t)1 << log_n;
+    uint64_t* c = d + blockIdx.y * stride;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t v = c[i];
+        if (mulc != 1) v = gl_mul(v, mulc);
+        if (tab) v = gl_mul(v, tab3_pow(tab, i));
+        c[i] = v;
+    }
+}
+__global__ void k_gather_rows(const uint64_t* lde, int log_N, size_t n_cols, const uint64_t* idx, size_t n_idx,
+                              uint64_t* out) {
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= n_idx * n_cols) return;
+    size_t k = t / n_cols, c = t - k * n_cols;
+    size_t row = brev32((uint32_t)idx[k], log_N);
+    out[t] = lde[(c << log_N) + row];
+}
+
+// ---------------------------------------------------------------- host planning
+static void plan_chunks(int L, std::vector<int>& outer, int& last) {
+    last = L < 12 ? L : 12;
+    int rem = L - last;
+    outer.clear();
+    if (rem > 0) {
+        int k = (rem + 7) / 8;
+        for (int i = 0; i < k; ++i) outer.push_back(rem / k + (i < rem % k ? 1 : 0));
+    }
+}
+static inline size_t lds_bytes(int lr, int lT) {
+    size_t T = (size_t)1 << lT;
+    return ((size_t)1 << lr) * (T > 1 ? T + 1 : 1) * 8;
+}
+template <int MODE>
+static int32_t launch_pass(vx_ctx* ctx, PassArgs& a, int log_n, size_t n_cols) {
+    size_t tiles = (size_t)1 << (log_n - a.log_rows - a.log_T);
+    hipLaunchKernelGGL(k_ntt_pass<MODE>, dim3((unsigned)tiles, (unsigned)n_cols), dim3(256), lds_bytes(a.log_rows, a.log_T),
+                       ctx->stream, a);
+    VX_HIP(hipGetLastError());
+    return VX_OK;
+}
+
+// natural -> bit-reversed positions.  src may equal dst.
+static int32_t ntt_dif(vx_ctx* ctx, const uint64_t* src, size_t src_stride, uint64_t* dst, size_t dst_stride, int L,
+                       size_t n_cols, int inverse, uint64_t scale) {
+    std::vector<int> outer;
+    int last;
+    plan_chunks(L, outer, last);
+    PassArgs a{};
+    a.src = src;
+    a.src_col_stride = src_stride;
+    a.dst = dst;
+    a.dst_col_stride = dst_stride;
+    a.w12 = inverse ? ctx->w12_inv : ctx->w12_fwd;
+    a.tw = inverse ? ctx->tw_inv.d : ctx->tw_fwd.d;
+    a.scale = 0;
+    int ls = L;
+    for (int c : outer) {
+        a.log_sub = ls;
+        a.log_rows = c;
+        a.log_T = (ls - c) < (12 - c) ? (ls - c) : (12 - c);
+        VX_TRY(launch_pass<0>(ctx, a, L, n_cols));
+        a.src = dst;
+        a.src_col_stride = dst_stride;
+        ls -= c;
+    }
+    a.log_sub = a.log_rows = last;
+    a.log_T = 0;
+    a.scale = scale;
+    return launch_pass<0>(ctx, a, L, n_cols);
+}
+
+// bit-reversed positions -> natural.  With expand_bits = r the source holds 2^(L-r)
+// coefficients (bit-reversed positions) that are zero-padded to 2^L on the fly.
+static int32_t ntt_dit(vx_ctx* ctx, const uint64_t* src, size_t src_stride, uint64_t* dst, size_t dst_stride, int L,
+                       size_t n_cols, int inverse, int expand_bits, const uint64_t* shift_tab) {
+    std::vector<int> outer;
+    int last;
+    plan_chunks(L, outer, last);
+    PassArgs a{};
+    a.src = src;
+    a.src_col_stride = src_stride;
+    a.dst = dst;
+    a.dst_col_stride = dst_stride;
+    a.w12 = inverse ? ctx->w12_inv : ctx->w12_fwd;
+    a.tw = inverse ? ctx->tw_inv.d : ctx->tw_fwd.d;
+    a.log_sub = a.log_rows = last;
+    a.log_T = 0;
+    a.expand_bits = expand_bits;
+    a.log_coeff = L - expand_bits;
+    a.shift_tab = shift_tab;
+    VX_TRY(launch_pass<1>(ctx, a, L, n_cols));
+    a.src = dst;
+    a.src_col_stride = dst_stride;
+    a.expand_bits = 0;
+    a.shift_tab = nullptr;
+    int ls = last;
+    for (int i = (int)outer.size() - 1; i >= 0; --i) {
+        int c = outer[i];
+        ls += c;
+        a.log_sub = ls;
+        a.log_rows = c;
+        a.log_T = (ls - c) < (12 - c) ? (ls - c) : (12 - c);
+        VX_TRY(launch_pass<1>(ctx, a, L, n_cols));
+    }
+    return VX_OK;
+}
+
+static int32_t bitrev_cols(vx_ctx* ctx, const uint64_t* in, size_t in_stride, uint64_t* out, size_t out_stride, int L,
+                           size_t n_cols) {
+    size_t n = (size_t)1 << L;
+    unsigned gx = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+    hipLaunchKernelGGL(k_bitrev_copy, dim3(gx, (unsigned)n_cols), dim3(256), 0, ctx->stream, in, out, L, in_stride,
+                       out_stride);
+    VX_HIP(hipGetLastError());
+    return VX_OK;
+}
+
+extern "C" {
+
+int32_t vx_ntt(vx_ctx* ctx, vx_buf* buf, size_t off, int log_n, size_t n_cols, size_t col_stride, int inverse,
+               uint64_t shift, int order) {
+    if (!ctx || !buf) return VX_ERR_ARG;
+    VX_CHECK(log_n >= 0 && log_n <= 28, "vx_ntt: log_n %d out of range [0,28]", log_n);
+    size_t n = (size_t)1 << log_n;
+    VX_CHECK(n_cols >= 1 && n_cols <= 65535, "vx_ntt: n_cols %zu out of range", n_cols);
+    VX_CHECK(col_stride >= n && off + (n_cols - 1) * col_stride + n <= buf->n, "vx_ntt: columns exceed the buffer");
+    VX_CHECK(shift < GL_P, "vx_ntt: shift not canonical");
+    VX_CHECK(order == VX_ORDER_NATURAL || order == VX_ORDER_BITREV, "vx_ntt: bad order");
+    if (log_n == 0) return VX_OK;
+    uint64_t* d = buf->d + off;
+    const bool coset = shift > 1;
+    const unsigned gx = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+    PowTab st{nullptr};
+    if (!inverse) {
+        if (coset) VX_TRY(vx_get_shift_tab(ctx, shift, &st));
+        if (order == VX_ORDER_BITREV) {
+            if (coset) {
+                hipLaunchKernelGGL(k_scale_pow, dim3(gx, (unsigned)n_cols), dim3(256), 0, ctx->stream, d, log_n, col_stride,
+                                   (const uint64_t*)st.d, (uint64_t)1);
+                VX_HIP(hipGetLastError());
+            }
+            return ntt_dif(ctx, d, col_stride, d, col_stride, log_n, n_cols, 0, 0);
+        }
+        // natural in -> natural out: permute into scratch (bit-reversed), DIT back into place
+        uint64_t* sc;
+        VX_TRY(vx_scratch(ctx, n * n_cols, &sc));
+        VX_TRY(bitrev_cols(ctx, d, col_stride, sc, n, log_n, n_cols));
+        return ntt_dit(ctx, sc, n, d, col_stride, log_n, n_cols, 0, 0, st.d);
+    }
+    if (coset) VX_TRY(vx_get_shift_tab(ctx, glh::inv(shift), &st));
+    const uint64_t ninv = glh::inv((uint64_t)n % glh::P);
+    if (order == VX_ORDER_BITREV) {
+        // values in bit-reversed positions -> natural coefficients
+        VX_TRY(ntt_dit(ctx, d, col_stride, d, col_stride, log_n, n_cols, 1, 0, nullptr));
+        hipLaunchKernelGGL(k_scale_pow, dim3(gx, (unsigned)n_cols), dim3(256), 0, ctx->stream, d, log_n, col_stride,
+                           (const uint64_t*)st.d, ninv);
+        VX_HIP(hipGetLastError());
+        return VX_OK;
+    }
+    uint64_t* sc;
+    VX_TRY(vx_scratch(ctx, n * n_cols, &sc));
+    VX_TRY(ntt_dif(ctx, d, col_stride, sc, n, log_n, n_cols, 1, ninv));
+    VX_TRY(bitrev_cols(ctx, sc, n, d, col_stride, log_n, n_cols));
+    if (coset) {
+        hipLaunchKernelGGL(k_scale_pow, dim3(gx, (unsigned)n_cols), dim3(256), 0, ctx->stream, d, log_n, col_stride,
+                           (const uint64_t*)st.d, (uint64_t)1);
+        VX_HIP(hipGetLastError());
+    }
+    return VX_OK;
+}
+
+int32_t vx_lde(vx_ctx* ctx, const vx_buf* src, int log_n, size_t n_cols, int rate_bits, uint64_t shift, int src_kind,
+               vx_buf* dst, vx_buf* coeffs_out) {
+    if (!ctx || !src || !dst) return VX_ERR_ARG;
+    VX_CHECK(log_n >= 0 && rate_bits >= 0 && log_n + rate_bits <= 28, "vx_lde: log_n %d + rate_bits %d out of range", log_n, rate_bits);
+    VX_CHECK(n_cols >= 1 && n_cols <= 65535, "vx_lde: n_cols out of range");
+    size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    VX_CHECK(src->n >= n * n_cols, "vx_lde: src holds %zu < %zu elements", src->n, n * n_cols);
+    VX_CHECK(dst->n >= N * n_cols, "vx_lde: dst holds %zu < %zu elements", dst->n, N * n_cols);
+    VX_CHECK(!coeffs_out || coeffs_out->n >= n * n_cols, "vx_lde: coeffs_out too small");
+    VX_CHECK(shift >= 1 && shift < GL_P, "vx_lde: bad shift");
+    VX_CHECK(src->d != dst->d, "vx_lde: src and dst alias");
+    PowTab st{nullptr};
+    if (shift > 1) VX_TRY(vx_get_shift_tab(ctx, shift, &st));
+    // coefficients in bit-reversed positions, in scratch
+    uint64_t* co;
+    VX_TRY(vx_scratch(ctx, n * n_cols, &co));
+    if (src_kind == VX_LDE_SRC_VALUES) {
+        uint64_t ninv = glh::inv((uint64_t)n % glh::P);
+        if (log_n == 0) VX_HIP(hipMemcpyAsync(co, src->d, n_cols * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        else VX_TRY(ntt_dif(ctx, src->d, n, co, n, log_n, n_cols, 1, ninv));
+        if (coeffs_out) VX_TRY(bitrev_cols(ctx, co, n, coeffs_out->d, n, log_n, n_cols));
+    } else {
+        VX_TRY(bitrev_cols(ctx, src->d, n, co, n, log_n, n_cols));
+        if (coeffs_out) VX_HIP(hipMemcpyAsync(coeffs_out->d, src->d, n * n_cols * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (log_n + rate_bits == 0) {
+        VX_HIP(hipMemcpyAsync(dst->d, co, n_cols * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return VX_OK;
+    }
+    return ntt_dit(ctx, co, n, dst->d, N, log_n + rate_bits, n_cols, 0, rate_bits, st.d);
+}
+
+int32_t vx_lde_rows(vx_ctx* ctx, const vx_buf* lde, int log_N, size_t n_cols, const uint64_t* leaf_idx, size_t n_idx,
+                    uint64_t* out) {
+    if (!ctx || !lde || !leaf_idx || !out) return VX_ERR_ARG;
+    size_t N = (size_t)1 << log_N;
+    VX_CHECK(lde->n >= N * n_cols, "vx_lde_rows: lde too small");
+    for (size_t i = 0; i < n_idx; ++i) VX_CHECK(leaf_idx[i] < N, "vx_lde_rows: leaf index %llu >= %zu", (unsigned long long)leaf_idx[i], N);
+    if (n_idx == 0) return VX_OK;
+    uint64_t* sc;
+    VX_TRY(vx_scratch(ctx, n_idx + n_idx * n_cols, &sc));
+    VX_HIP(hipMemcpyAsync(sc, leaf_idx, n_idx * 8, hipMemcpyHostToDevice, ctx->stream));
+    size_t tot = n_idx * n_cols;
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, lde->d, log_N, n_cols,
+                       sc, n_idx, sc + n_idx);
+    VX_HIP(hipGetLastError());
+    VX_HIP(hipMemcpyAsync(out, sc + n_idx, tot * 8, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipStreamSynchronize(ctx->stream));
+    return VX_OK;
+}
+}  // extern "C"

@@ -1,0 +1,269 @@
+"""ctypes binding of libvxprove.so (C ABI: include/vx.h)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvxprove.so")
+P = 2**64 - 2**32 + 1
+
+VX_ORDER_NATURAL, VX_ORDER_BITREV = 0, 1
+VX_LDE_SRC_VALUES, VX_LDE_SRC_COEFFS = 0, 1
+VX_LEAVES_ROW_MAJOR, VX_LEAVES_COLS_BITREV, VX_LEAVES_COLS = 0, 1, 2
+ERR_NAMES = {-1: "VX_ERR_ARG", -2: "VX_ERR_DEVICE", -3: "VX_ERR_OOM", -4: "VX_ERR_BUFSZ", -5: "VX_ERR_STATEMENT", -6: "VX_ERR_POW"}
+
+# every symbol include/vx.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "vx_ctx_create", "vx_ctx_destroy", "vx_sync", "vx_last_error", "vx_backend_name", "vx_timer_start", "vx_timer_stop",
+    "vx_alloc", "vx_free", "vx_upload", "vx_download", "vx_copy", "vx_fill_random", "vx_buf_devptr", "vx_buf_len",
+    "vx_field_batch_add", "vx_field_batch_sub", "vx_field_batch_mul", "vx_field_batch_inv", "vx_ext_batch_mul",
+    "vx_ntt", "vx_lde", "vx_lde_rows",
+    "vx_poseidon_permute_batch", "vx_merkle_build", "vx_merkle_free", "vx_merkle_cap", "vx_merkle_open", "vx_merkle_leaf_digests",
+    "vx_fri_fold", "vx_fri_layer_tree", "vx_fri_leaves", "vx_fri_pow",
+    "vx_blake2b_256_batch", "vx_sha256_pairs", "vx_verify_subchain",
+]
+
+
+class VxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+def build(force=False):
+    """Compile libvxprove.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-s", "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VxError(-2, f"{LIB_PATH} is missing: run __graft_entry__.build(); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, i32, u64 = C.c_void_p, C.c_size_t, C.c_int32, C.c_uint64
+    sig = {
+        "vx_ctx_create": [C.c_int, C.POINTER(vp)], "vx_ctx_destroy": [vp], "vx_sync": [vp],
+        "vx_timer_start": [vp], "vx_timer_stop": [vp, C.POINTER(C.c_float)],
+        "vx_alloc": [vp, sz, C.POINTER(vp)], "vx_free": [vp, vp],
+        "vx_upload": [vp, vp, sz, vp, sz], "vx_download": [vp, vp, sz, vp, sz], "vx_copy": [vp, vp, sz, vp, sz, sz],
+        "vx_fill_random": [vp, vp, sz, sz, u64],
+        "vx_field_batch_add": [vp, vp, vp, vp, sz], "vx_field_batch_sub": [vp, vp, vp, vp, sz],
+        "vx_field_batch_mul": [vp, vp, vp, vp, sz], "vx_field_batch_inv": [vp, vp, vp, sz], "vx_ext_batch_mul": [vp, vp, vp, vp, sz],
+        "vx_ntt": [vp, vp, sz, C.c_int, sz, sz, C.c_int, u64, C.c_int],
+        "vx_lde": [vp, vp, C.c_int, sz, C.c_int, u64, C.c_int, vp, vp],
+        "vx_lde_rows": [vp, vp, C.c_int, sz, vp, sz, vp],
+        "vx_poseidon_permute_batch": [vp, vp, sz],
+        "vx_merkle_build": [vp, vp, sz, sz, sz, C.c_int, C.c_int, C.POINTER(vp)], "vx_merkle_free": [vp, vp],
+        "vx_merkle_cap": [vp, vp, vp], "vx_merkle_open": [vp, vp, vp, sz, vp], "vx_merkle_leaf_digests": [vp, vp, vp],
+        "vx_fri_fold": [vp, vp, C.c_int, C.c_int, vp, u64, vp], "vx_fri_layer_tree": [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
+        "vx_fri_leaves": [vp, vp, C.c_int, C.c_int, vp, sz, vp], "vx_fri_pow": [vp, vp, C.c_int, C.c_int, C.POINTER(u64)],
+        "vx_blake2b_256_batch": [vp, vp, sz, vp, sz, vp], "vx_sha256_pairs": [vp, vp, sz, vp],
+        "vx_verify_subchain": [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp],
+    }
+    for name, args in sig.items():
+        f = getattr(L, name)
+        f.argtypes, f.restype = args, i32
+    L.vx_last_error.argtypes, L.vx_last_error.restype = [vp], C.c_char_p
+    L.vx_backend_name.argtypes, L.vx_backend_name.restype = [], C.c_char_p
+    L.vx_buf_devptr.argtypes, L.vx_buf_devptr.restype = [vp], vp
+    L.vx_buf_len.argtypes, L.vx_buf_len.restype = [vp], sz
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Buffer:
+    def __init__(self, ctx, n):
+        self.ctx, self.n = ctx, int(n)
+        h = C.c_void_p()
+        ctx._ck(ctx.L.vx_alloc(ctx.h, self.n, C.byref(h)))
+        self.h = h
+
+    def upload(self, arr, off=0):
+        a = np.ascontiguousarray(arr).view(np.uint64).reshape(-1) if np.asarray(arr).dtype != np.uint64 else np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1)
+        self.ctx._ck(self.ctx.L.vx_upload(self.ctx.h, self.h, off, _ptr(a), a.size))
+        return self
+
+    def download(self, n=None, off=0):
+        n = self.n - off if n is None else n
+        out = np.empty(n, dtype=np.uint64)
+        self.ctx._ck(self.ctx.L.vx_download(self.ctx.h, self.h, off, _ptr(out), n))
+        return out
+
+    def devptr(self):
+        return self.ctx.L.vx_buf_devptr(self.h)
+
+    def free(self):
+        if self.h:
+            self.ctx.L.vx_free(self.ctx.h, self.h)
+            self.h = None
+
+
+class Tree:
+    def __init__(self, ctx, h, n_leaves, cap_height):
+        self.ctx, self.h, self.n_leaves, self.cap_height = ctx, h, n_leaves, cap_height
+        self.depth = n_leaves.bit_length() - 1 - cap_height
+
+    def cap(self):
+        out = np.empty((1 << self.cap_height, 4), dtype=np.uint64)
+        self.ctx._ck(self.ctx.L.vx_merkle_cap(self.ctx.h, self.h, _ptr(out)))
+        return out
+
+    def open(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        out = np.empty((idx.size, self.depth, 4), dtype=np.uint64)
+        self.ctx._ck(self.ctx.L.vx_merkle_open(self.ctx.h, self.h, _ptr(idx), idx.size, _ptr(out)))
+        return out
+
+    def leaf_digests(self):
+        out = np.empty((self.n_leaves, 4), dtype=np.uint64)
+        self.ctx._ck(self.ctx.L.vx_merkle_leaf_digests(self.ctx.h, self.h, _ptr(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            self.ctx.L.vx_merkle_free(self.ctx.h, self.h)
+            self.h = None
+
+
+class Context:
+    """One device + one stream (vx_ctx).  Raises VxError on any failure."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.vx_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise VxError(rc, f"vx_ctx_create(device={device}) failed: no usable gfx950 device (no CPU fallback exists)")
+        self.h = h
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise VxError(rc, self.L.vx_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.L.vx_ctx_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self):
+        self._ck(self.L.vx_sync(self.h))
+
+    def timer_start(self):
+        self._ck(self.L.vx_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._ck(self.L.vx_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def alloc(self, n):
+        return Buffer(self, n)
+
+    def from_host(self, arr):
+        a = np.ascontiguousarray(arr)
+        nwords = (a.nbytes + 7) // 8
+        if a.dtype != np.uint64:
+            raw = np.zeros(nwords * 8, dtype=np.uint8)
+            raw[: a.nbytes] = a.view(np.uint8).reshape(-1)
+            a = raw.view(np.uint64)
+        return Buffer(self, max(nwords, 1)).upload(a.reshape(-1))
+
+    def fill_random(self, buf, n, seed, off=0):
+        self._ck(self.L.vx_fill_random(self.h, buf.h, off, n, seed))
+
+    def copy(self, dst, src, n, dst_off=0, src_off=0):
+        self._ck(self.L.vx_copy(self.h, dst.h, dst_off, src.h, src_off, n))
+
+    # K1
+    def field_op(self, name, a, b, out, n):
+        f = getattr(self.L, "vx_field_batch_" + name)
+        self._ck(f(self.h, a.h, out.h, n) if name == "inv" else f(self.h, a.h, b.h, out.h, n))
+
+    def ext_mul(self, a, b, out, n):
+        self._ck(self.L.vx_ext_batch_mul(self.h, a.h, b.h, out.h, n))
+
+    # K2 / K3
+    def ntt(self, buf, log_n, n_cols, inverse=False, shift=0, order=VX_ORDER_NATURAL, off=0, col_stride=None):
+        cs = (1 << log_n) if col_stride is None else col_stride
+        self._ck(self.L.vx_ntt(self.h, buf.h, off, log_n, n_cols, cs, int(inverse), shift, order))
+
+    def lde(self, src, log_n, n_cols, rate_bits, dst, shift=7, src_kind=VX_LDE_SRC_VALUES, coeffs_out=None):
+        self._ck(self.L.vx_lde(self.h, src.h, log_n, n_cols, rate_bits, shift, src_kind, dst.h, coeffs_out.h if coeffs_out else None))
+
+    def lde_rows(self, lde, log_N, n_cols, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        out = np.empty((idx.size, n_cols), dtype=np.uint64)
+        self._ck(self.L.vx_lde_rows(self.h, lde.h, log_N, n_cols, _ptr(idx), idx.size, _ptr(out)))
+        return out
+
+    # K4
+    def poseidon(self, states_buf, n):
+        self._ck(self.L.vx_poseidon_permute_batch(self.h, states_buf.h, n))
+
+    def merkle(self, data, n_leaves, leaf_len, layout, cap_height, off=0):
+        t = C.c_void_p()
+        self._ck(self.L.vx_merkle_build(self.h, data.h, off, n_leaves, leaf_len, layout, cap_height, C.byref(t)))
+        return Tree(self, t, n_leaves, cap_height)
+
+    # K6
+    def fri_fold(self, evals, log_n, arity_bits, beta, shift, out):
+        b = np.ascontiguousarray(beta, dtype=np.uint64)
+        self._ck(self.L.vx_fri_fold(self.h, evals.h, log_n, arity_bits, _ptr(b), shift, out.h))
+
+    def fri_layer_tree(self, evals, log_n, arity_bits, cap_height):
+        t = C.c_void_p()
+        self._ck(self.L.vx_fri_layer_tree(self.h, evals.h, log_n, arity_bits, cap_height, C.byref(t)))
+        return Tree(self, t, 1 << (log_n - arity_bits), cap_height)
+
+    def fri_leaves(self, evals, log_n, arity_bits, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        out = np.empty((idx.size, 2 << arity_bits), dtype=np.uint64)
+        self._ck(self.L.vx_fri_leaves(self.h, evals.h, log_n, arity_bits, _ptr(idx), idx.size, _ptr(out)))
+        return out
+
+    def fri_pow(self, state12, pos, bits):
+        s = np.ascontiguousarray(state12, dtype=np.uint64)
+        nonce = C.c_uint64()
+        self._ck(self.L.vx_fri_pow(self.h, _ptr(s), pos, bits, C.byref(nonce)))
+        return nonce.value
+
+    # K8 / statement
+    def blake2b_256_batch(self, msgs_buf, stride, sizes):
+        sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+        out = np.empty((sizes.size, 32), dtype=np.uint8)
+        self._ck(self.L.vx_blake2b_256_batch(self.h, msgs_buf.h, stride, _ptr(sizes), sizes.size, _ptr(out)))
+        return out
+
+    def sha256_pairs(self, pairs):
+        p = np.ascontiguousarray(pairs, dtype=np.uint8).reshape(-1, 64)
+        out = np.empty((p.shape[0], 32), dtype=np.uint8)
+        self._ck(self.L.vx_sha256_pairs(self.h, _ptr(p), p.shape[0], _ptr(out)))
+        return out
+
+    def verify_subchain(self, headers_buf, stride, sizes, max_headers, trusted_block, trusted_hash, target_block):
+        sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+        th = np.frombuffer(bytes(trusted_hash), dtype=np.uint8).copy()
+        out = np.zeros(96, dtype=np.uint8)
+        self._ck(self.L.vx_verify_subchain(self.h, headers_buf.h, stride, _ptr(sizes), sizes.size, max_headers, trusted_block, _ptr(th), target_block, _ptr(out)))
+        return out.tobytes()

@@ -1,0 +1,170 @@
+/*
+ * vx.h -- C ABI of libvxprove, the MI355X-native (gfx950) backend for the
+ * header_range proving path of VectorX (reference: AsherBond/0-kno-vectorx).
+ *
+ * The reference has no FFI of its own: its seams are the
+ * `Circuit::prove` library call (circuits/header_range.rs:167-170) and cargo's
+ * dependency-override mechanism (Cargo.toml:101-106).  Each group below names
+ * the upstream routine (plonky2 v0.2.0 / starkyx v1.0.0 / plonky2x v1.1.0,
+ * pinned at Cargo.lock:4848-4910, 7232-7249) that a `[patch]`-ed Rust shim
+ * would forward to this library, and the in-tree call site that reaches it.
+ * INTEGRATION.md shows the Rust `extern "C"` stubs.
+ *
+ * Conventions
+ *   - plain C, no exceptions; every call returns int32_t: 0 = VX_OK, <0 = VX_ERR_*;
+ *     vx_last_error(ctx) returns a message for the last failure on that ctx.
+ *   - field elements: canonical (< p = 2^64-2^32+1) little-endian uint64_t;
+ *     extension elements (D = 2, X^2 = 7): two consecutive uint64_t (c0, c1).
+ *   - matrices are COLUMN-MAJOR: one polynomial / trace column is contiguous.
+ *   - the caller owns host buffers; vx_buf are device (HBM) buffers owned by
+ *     the ctx that allocated them.
+ *   - a vx_ctx is bound to one device and one HIP stream; calls are
+ *     asynchronous on that stream; vx_sync / vx_download block.  Not
+ *     thread-safe: one ctx per host thread.
+ */
+#ifndef VX_H
+#define VX_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vx_ctx vx_ctx;
+typedef struct vx_buf vx_buf;
+typedef struct vx_tree vx_tree;
+
+enum {
+    VX_OK = 0,
+    VX_ERR_ARG = -1,      /* bad argument (shape, range, null) */
+    VX_ERR_DEVICE = -2,   /* HIP runtime failure / no gfx950 device */
+    VX_ERR_OOM = -3,      /* device allocation failed */
+    VX_ERR_BUFSZ = -4,    /* caller buffer too small; needed size reported */
+    VX_ERR_STATEMENT = -5,/* the header_range statement does not hold for the witness
+                             (the reference panics / fails an in-circuit assert) */
+    VX_ERR_POW = -6       /* proof-of-work search exhausted */
+};
+
+/* ---- lifecycle ------------------------------------------------------------ */
+int32_t vx_ctx_create(int device, vx_ctx** out);
+int32_t vx_ctx_destroy(vx_ctx* ctx);
+int32_t vx_sync(vx_ctx* ctx);
+const char* vx_last_error(const vx_ctx* ctx);
+const char* vx_backend_name(void); /* "hip-gfx950" */
+/* elapsed milliseconds between two points of the ctx stream (HIP events):
+ * vx_timer_start records, vx_timer_stop records + synchronises and returns ms. */
+int32_t vx_timer_start(vx_ctx* ctx);
+int32_t vx_timer_stop(vx_ctx* ctx, float* ms);
+
+/* ---- memory --------------------------------------------------------------- */
+int32_t vx_alloc(vx_ctx* ctx, size_t n_u64, vx_buf** out);
+int32_t vx_free(vx_ctx* ctx, vx_buf* buf);
+int32_t vx_upload(vx_ctx* ctx, vx_buf* dst, size_t dst_off, const uint64_t* src, size_t n_u64);
+int32_t vx_download(vx_ctx* ctx, const vx_buf* src, size_t src_off, uint64_t* dst, size_t n_u64);
+int32_t vx_copy(vx_ctx* ctx, vx_buf* dst, size_t dst_off, const vx_buf* src, size_t src_off, size_t n_u64);
+/* fill with canonical pseudo-random field elements (SplitMix64 of seed+index, reduced mod p) */
+int32_t vx_fill_random(vx_ctx* ctx, vx_buf* dst, size_t off, size_t n_u64, uint64_t seed);
+void* vx_buf_devptr(const vx_buf* buf);
+size_t vx_buf_len(const vx_buf* buf);
+
+/* ---- K1: Goldilocks batch arithmetic (plonky2_field::goldilocks_field; test surface) */
+int32_t vx_field_batch_add(vx_ctx* ctx, const vx_buf* a, const vx_buf* b, vx_buf* out, size_t n);
+int32_t vx_field_batch_sub(vx_ctx* ctx, const vx_buf* a, const vx_buf* b, vx_buf* out, size_t n);
+int32_t vx_field_batch_mul(vx_ctx* ctx, const vx_buf* a, const vx_buf* b, vx_buf* out, size_t n);
+/* Field::batch_multiplicative_inverse; 0 maps to 0 */
+int32_t vx_field_batch_inv(vx_ctx* ctx, const vx_buf* a, vx_buf* out, size_t n);
+int32_t vx_ext_batch_mul(vx_ctx* ctx, const vx_buf* a, const vx_buf* b, vx_buf* out, size_t n_ext);
+
+/* ---- K2: batched radix-2 NTT (plonky2_field::fft::{fft,ifft}, polynomial::{coset_fft,coset_ifft})
+ * buf holds n_cols columns of n = 2^log_n elements at column stride `col_stride`
+ * (elements).  Natural order in and out, in place.
+ *   inverse = 0: values[i] = sum_k coeff[k] * (shift * w^i)^k        (coset_fft; shift 0/1 = plain fft)
+ *   inverse = 1: the inverse map, including the 1/n factor           (coset_ifft / ifft)
+ * order: VX_ORDER_NATURAL, or VX_ORDER_BITREV to leave a FORWARD result (or take an
+ * INVERSE input) in bit-reversed positions and skip the permutation pass. */
+enum { VX_ORDER_NATURAL = 0, VX_ORDER_BITREV = 1 };
+int32_t vx_ntt(vx_ctx* ctx, vx_buf* buf, size_t off, int log_n, size_t n_cols, size_t col_stride,
+               int inverse, uint64_t shift, int order);
+
+/* ---- K3: low-degree extension (plonky2::fri::oracle::PolynomialBatch::{from_values,from_coeffs})
+ * src: n_cols columns of n values (natural order) or, with VX_LDE_SRC_COEFFS, coefficients.
+ * dst: n_cols columns of N = n << rate_bits evaluations on the coset shift*<w_N>, column-major,
+ *      NATURAL order within a column: dst[c*N + i] = P_c(shift * w_N^i).  plonky2's leaf j
+ *      (after its transpose + reverse_index_bits) is row i = bitrev_N(j); vx_merkle_build
+ *      and vx_lde_rows take that mapping into account, no transposed copy is ever made.
+ * coeffs_out (optional, may be NULL): n_cols columns of n coefficients (natural order).
+ * src is preserved. */
+enum { VX_LDE_SRC_VALUES = 0, VX_LDE_SRC_COEFFS = 1 };
+int32_t vx_lde(vx_ctx* ctx, const vx_buf* src, int log_n, size_t n_cols, int rate_bits, uint64_t shift,
+               int src_kind, vx_buf* dst, vx_buf* coeffs_out);
+/* gather plonky2 leaves: for each of n_idx leaf indices j, the n_cols values of row bitrev(j)
+ * -> out[k*n_cols + c] on the HOST (PolynomialBatch::get_lde_values) */
+int32_t vx_lde_rows(vx_ctx* ctx, const vx_buf* lde, int log_N, size_t n_cols, const uint64_t* leaf_idx,
+                    size_t n_idx, uint64_t* out);
+
+/* ---- K4: Poseidon-Goldilocks + Merkle caps (plonky2::hash::{poseidon,hashing,merkle_tree}) */
+/* in-place permutation of n states of 12 elements (state-major: 12 consecutive per state) */
+int32_t vx_poseidon_permute_batch(vx_ctx* ctx, vx_buf* states, size_t n);
+/* MerkleTree::new(leaves, cap_height).  Layouts of `data`:
+ *   VX_LEAVES_ROW_MAJOR: leaf j = data[j*leaf_len .. +leaf_len)
+ *   VX_LEAVES_COLS_BITREV: data is column-major [leaf_len][n_leaves]; leaf j = row bitrev(j)
+ *                          of every column (the layout vx_lde produces)
+ *   VX_LEAVES_COLS: column-major, leaf j = row j. */
+enum { VX_LEAVES_ROW_MAJOR = 0, VX_LEAVES_COLS_BITREV = 1, VX_LEAVES_COLS = 2 };
+int32_t vx_merkle_build(vx_ctx* ctx, const vx_buf* data, size_t off, size_t n_leaves, size_t leaf_len,
+                        int layout, int cap_height, vx_tree** out);
+int32_t vx_merkle_free(vx_ctx* ctx, vx_tree* tree);
+/* cap_out: 4 * 2^cap_height elements (host) */
+int32_t vx_merkle_cap(vx_ctx* ctx, const vx_tree* tree, uint64_t* cap_out);
+/* MerkleTree::prove for n_idx leaves: siblings_out[k][log2(n_leaves)-cap_height][4] (host) */
+int32_t vx_merkle_open(vx_ctx* ctx, const vx_tree* tree, const uint64_t* leaf_idx, size_t n_idx,
+                       uint64_t* siblings_out);
+/* leaf digests (4*n_leaves, device->host), test surface */
+int32_t vx_merkle_leaf_digests(vx_ctx* ctx, const vx_tree* tree, uint64_t* out);
+
+/* ---- K6: FRI (plonky2::fri::{prover,verifier,reduction_strategies}) */
+/* One reduction step.  evals: N = 2^log_n extension values of a polynomial on the coset
+ * shift*<w_N>, NATURAL order (evals[i] = P(shift*w_N^i), interleaved c0,c1).  Writes the
+ * N >> arity_bits values of P'(y) = sum_i beta^i P_i(y) (P(x) = sum_i x^i P_i(x^arity)) on
+ * the coset shift^arity * <w_{N/arity}>, natural order -- the values
+ * fri_committed_trees obtains by folding coefficients and re-running coset_fft. */
+int32_t vx_fri_fold(vx_ctx* ctx, const vx_buf* evals, int log_n, int arity_bits, const uint64_t beta[2],
+                    uint64_t shift, vx_buf* out);
+/* Merkle tree over a FRI layer: leaf j = the `arity` extension values whose natural indices
+ * are bitrev(j*arity + t), t < arity (reverse_index_bits + chunk + flatten of prover.rs). */
+int32_t vx_fri_layer_tree(vx_ctx* ctx, const vx_buf* evals, int log_n, int arity_bits, int cap_height,
+                          vx_tree** out);
+/* FriInitialTreeProof / FriQueryStep evals: the flattened `arity` extension values of each of
+ * n_idx leaves of a FRI layer (MerkleTree::get on the layer tree) -> out[k][2*arity] (host) */
+int32_t vx_fri_leaves(vx_ctx* ctx, const vx_buf* evals, int log_n, int arity_bits, const uint64_t* leaf_idx,
+                      size_t n_idx, uint64_t* out);
+/* fri_proof_of_work: smallest nonce w such that Poseidon(state with state[pos] = w)[7] has
+ * `bits` leading zero bits.  (Upstream's parallel find_any returns an arbitrary valid nonce;
+ * see DESIGN.md section 6.) */
+int32_t vx_fri_pow(vx_ctx* ctx, const uint64_t state[12], int pos, int bits, uint64_t* nonce);
+
+/* ---- K8: witness hashing for the header chain
+ * (plonky2x curta_blake2b_variable via circuits/builder/header.rs:14-19; SimpleMerkleTree /
+ *  sha256 via subchain_verification.rs:213-220, 268-274) */
+/* headers: device bytes, n messages at `stride` bytes each (uint8 view of a vx_buf);
+ * sizes: n uint32 on the HOST; digests_out: 32*n bytes on the HOST */
+int32_t vx_blake2b_256_batch(vx_ctx* ctx, const vx_buf* msgs, size_t stride, const uint32_t* sizes, size_t n,
+                             uint8_t* digests_out);
+/* 64-byte -> 32-byte SHA-256 of n pairs (host in/out; device compute) */
+int32_t vx_sha256_pairs(vx_ctx* ctx, const uint8_t* pairs64, size_t n, uint8_t* out32);
+
+/* ---- statement level: verify_subchain (circuits/builder/subchain_verification.rs:56-303)
+ * headers: n_fetched encoded headers (blocks trusted+1 .. target) resident in HBM at `stride`
+ * bytes each (zero padded), sizes on the host.  max_headers = 256 / 512
+ * (bin/header_range_{256,512}.rs:15).  Runs the map stage (Blake2b header hashes, header
+ * decoding, link checks, 8-leaf SHA-256 roots) and the reduce tree on the GPU and returns the
+ * 96-byte public output target_header_hash || state_root_merkle_root || data_root_merkle_root
+ * (circuits/header_range.rs:56-58).  VX_ERR_STATEMENT if a chain rule is violated. */
+int32_t vx_verify_subchain(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes,
+                           size_t n_fetched, uint32_t max_headers, uint32_t trusted_block,
+                           const uint8_t trusted_hash[32], uint32_t target_block, uint8_t out96[96]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VX_H */

@@ -1,0 +1,47 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol include/vx.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree(vx):
+    assert declared_symbols() == sorted(vx.lib.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(vx):
+    if not os.path.exists(vx.lib.LIB_PATH):
+        vx.lib.build()
+    L = ctypes.CDLL(vx.lib.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(L, name), f"libvxprove.so does not export {name}"
+    L.vx_backend_name.restype = ctypes.c_char_p
+    assert L.vx_backend_name() == b"hip-gfx950"
+
+
+def test_no_cpu_fallback(vx):
+    """Without a GPU the product path must fail loudly, never compute on the host."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(vx.VxError):
+        vx.Context(0)
+
+
+def test_product_does_not_touch_the_oracle():
+    pkg = os.path.join(ROOT, "0-kno-vectorx_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cuh", ".cpp")) or f == "Makefile":
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "vxo_" not in src and "libvxoracle" not in src and "from oracle" not in src and "import oracle" not in src, f

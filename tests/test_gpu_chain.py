@@ -1,0 +1,61 @@
+"""GPU parity for the witness-side hashing and verify_subchain (statement level)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_blake2b_batch_edge_lengths(ctx, oracle):
+    lens = [0, 1, 7, 8, 127, 128, 129, 255, 256, 257, 1000, 4095, 4096]
+    stride = 4096
+    msgs = np.zeros((len(lens), stride), dtype=np.uint8)
+    rng = np.random.default_rng(1)
+    for i, n in enumerate(lens):
+        msgs[i, :n] = rng.integers(0, 256, n, dtype=np.uint8)
+    got = ctx.blake2b_256_batch(ctx.from_host(msgs), stride, lens)
+    for i, n in enumerate(lens):
+        want = hashlib.blake2b(msgs[i, :n].tobytes(), digest_size=32).digest()
+        assert got[i].tobytes() == want == oracle.blake2b_256(msgs[i, :n].tobytes())
+
+
+def test_sha256_pairs(ctx):
+    rng = np.random.default_rng(2)
+    pairs = rng.integers(0, 256, (77, 64), dtype=np.uint8)
+    got = ctx.sha256_pairs(pairs)
+    for i in range(77):
+        assert got[i].tobytes() == hashlib.sha256(pairs[i].tobytes()).digest()
+
+
+@pytest.mark.parametrize("n_headers,N,profile", [(16, 16, "Ptiny"), (11, 16, "Ptiny"), (1, 16, "Ptiny"), (64, 64, "Ptiny"),
+                                                  (256, 256, "P15k"), (219, 256, "Pmix"), (512, 512, "Pmix")])
+def test_verify_subchain_matches_oracle(ctx, oracle, vx, n_headers, N, profile):
+    stride = 512 if profile == "Ptiny" else vx.synth.MAX_HEADER_SIZE
+    ch = vx.synth.Chain(n_headers, profile=profile, stride=stride)
+    buf = ctx.from_host(ch.headers)
+    out = ctx.verify_subchain(buf, stride, ch.sizes, N, ch.trusted_block, ch.trusted_hash, ch.target_block)
+    rc, want = oracle.verify_subchain(ch.headers, ch.sizes, N, ch.trusted_block, ch.trusted_hash, ch.target_block)
+    assert rc == 0 and out == want == ch.expected_outputs(N)
+    digests = ctx.blake2b_256_batch(buf, stride, ch.sizes)
+    assert [d.tobytes() for d in digests] == ch.hashes
+
+
+def test_verify_subchain_rejects_bad_chains(ctx, vx):
+    ch = vx.synth.Chain(16, profile="Ptiny", stride=512)
+    args = (512, ch.sizes, 16, ch.trusted_block)
+
+    def run(headers, sizes=ch.sizes, trusted=ch.trusted_hash):
+        return ctx.verify_subchain(ctx.from_host(headers), 512, sizes, 16, ch.trusted_block, trusted, ch.target_block)
+
+    h = ch.headers.copy()
+    h[5, 3] ^= 1
+    with pytest.raises(vx.VxError) as e:
+        run(h)
+    assert e.value.code == -5
+    other = vx.synth.Chain(16, profile="Ptiny", stride=512, seed=12345)
+    with pytest.raises(vx.VxError):
+        run(np.concatenate([ch.headers[:8], other.headers[8:]]), np.concatenate([ch.sizes[:8], other.sizes[8:]]))
+    with pytest.raises(vx.VxError):
+        run(ch.headers, trusted=bytes(32))
+    assert run(ch.headers) == ch.expected_outputs(16)

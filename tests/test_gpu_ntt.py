@@ -1,0 +1,131 @@
+"""GPU parity (through the C ABI) for K1-K3: field batches, NTT, LDE -- bit-exact vs the oracle."""
+import numpy as np
+import pytest
+
+from conftest import P, rand_field
+
+pytestmark = pytest.mark.gpu
+
+
+def bitrev_perm(log_n):
+    n = 1 << log_n
+    idx = np.arange(n, dtype=np.uint64)
+    out = np.zeros(n, dtype=np.uint64)
+    for b in range(log_n):
+        out |= ((idx >> np.uint64(b)) & np.uint64(1)) << np.uint64(log_n - 1 - b)
+    return out.astype(np.int64)
+
+
+def test_field_batches(ctx, oracle, rng):
+    n = 100003  # ragged on purpose
+    a, b = rand_field(rng, n), rand_field(rng, n)
+    da, db, do = ctx.from_host(a), ctx.from_host(b), ctx.alloc(n)
+    for op in ("add", "sub", "mul"):
+        ctx.field_op(op, da, db, do, n)
+        assert (do.download() == oracle.batch_op(op, a, b)).all(), op
+    ctx.field_op("inv", da, None, do, n)
+    assert (do.download() == oracle.batch_inv(a)).all()
+    m = n // 2
+    ctx.ext_mul(da, db, do, m)
+    assert (do.download(2 * m) == oracle.ext_mul(a[: 2 * m], b[: 2 * m])).all()
+
+
+def test_fill_random_is_canonical(ctx):
+    buf = ctx.alloc(1 << 16)
+    ctx.fill_random(buf, 1 << 16, 42)
+    v = buf.download()
+    assert (v < np.uint64(P)).all() and len(np.unique(v)) > 65000
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 3, 5, 8, 11, 12, 13, 14, 16, 17, 20])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_ntt_matches_oracle(ctx, oracle, rng, log_n, inverse):
+    n = 1 << log_n
+    cols = 5 if log_n <= 14 else 2
+    x = rand_field(rng, (cols, n))
+    buf = ctx.from_host(x)
+    ctx.ntt(buf, log_n, cols, inverse=inverse)
+    assert (buf.download().reshape(cols, n) == oracle.ntt(x, inverse=inverse)).all()
+
+
+@pytest.mark.parametrize("log_n", [4, 12, 15])
+def test_coset_ntt_and_orders(ctx, oracle, rng, log_n):
+    n = 1 << log_n
+    x = rand_field(rng, (3, n))
+    perm = bitrev_perm(log_n)
+    for shift in (7, 49):
+        buf = ctx.from_host(x)
+        ctx.ntt(buf, log_n, 3, shift=shift)
+        want = oracle.ntt(x, shift=shift)
+        assert (buf.download().reshape(3, n) == want).all()
+        ctx.ntt(buf, log_n, 3, inverse=True, shift=shift)
+        assert (buf.download().reshape(3, n) == x).all()
+        # bit-reversed output order (no permutation pass)
+        buf = ctx.from_host(x)
+        ctx.ntt(buf, log_n, 3, shift=shift, order=1)
+        assert (buf.download().reshape(3, n)[:, perm] == want).all()
+        # inverse from bit-reversed input
+        ctx.ntt(buf, log_n, 3, inverse=True, shift=shift, order=1)
+        assert (buf.download().reshape(3, n) == x).all()
+
+
+def test_ntt_column_stride_and_offset(ctx, oracle, rng):
+    log_n, n, stride, off = 9, 512, 700, 33
+    x = rand_field(rng, (4, n))
+    host = np.full(off + 4 * stride, 12345, dtype=np.uint64)
+    for c in range(4):
+        host[off + c * stride: off + c * stride + n] = x[c]
+    buf = ctx.from_host(host)
+    ctx.ntt(buf, log_n, 4, off=off, col_stride=stride)
+    got = buf.download()
+    want = oracle.ntt(x)
+    for c in range(4):
+        assert (got[off + c * stride: off + c * stride + n] == want[c]).all()
+        assert (got[off + c * stride + n: off + (c + 1) * stride] == 12345).all()  # gaps untouched
+    assert (got[:off] == 12345).all()
+
+
+@pytest.mark.parametrize("log_n,rate_bits,cols", [(0, 3, 2), (3, 3, 4), (5, 1, 3), (9, 3, 7), (10, 3, 3), (13, 3, 2), (12, 1, 5), (16, 3, 1)])
+def test_lde_matches_oracle_leaves(ctx, oracle, rng, log_n, rate_bits, cols):
+    n, N = 1 << log_n, 1 << (log_n + rate_bits)
+    vals = rand_field(rng, (cols, n))
+    leaves, coeffs = oracle.lde_from_values(vals, rate_bits, 7)
+    src, dst, co = ctx.from_host(vals), ctx.alloc(N * cols), ctx.alloc(n * cols)
+    ctx.lde(src, log_n, cols, rate_bits, dst, shift=7, coeffs_out=co)
+    got = dst.download().reshape(cols, N)
+    perm = bitrev_perm(log_n + rate_bits)
+    assert (got[:, perm].T == leaves).all()  # plonky2 leaf j = natural row bitrev(j)
+    assert (co.download().reshape(cols, n) == coeffs).all()
+    assert (src.download().reshape(cols, n) == vals).all()  # src preserved
+    idx = np.array([0, 1, N - 1, N // 3], dtype=np.uint64)
+    assert (ctx.lde_rows(dst, log_n + rate_bits, cols, idx) == leaves[idx.astype(np.int64)]).all()
+    # from coefficients
+    dst2 = ctx.alloc(N * cols)
+    ctx.lde(ctx.from_host(coeffs), log_n, cols, rate_bits, dst2, shift=7, src_kind=1)
+    assert (dst2.download() == dst.download()).all()
+
+
+def test_large_ntt_properties(ctx, rng):
+    """BASELINE-size columns (2^22 x 4): oracle-free properties -- round trip, linearity,
+    and agreement of the 3-pass plan with the 2-pass plan on a strided sub-transform."""
+    log_n, cols = 22, 4
+    n = 1 << log_n
+    a, b, s = ctx.alloc(n * cols), ctx.alloc(n * cols), ctx.alloc(n * cols)
+    ctx.fill_random(a, n * cols, 1)
+    ctx.fill_random(b, n * cols, 2)
+    ctx.field_op("add", a, b, s, n * cols)
+    a0 = a.download()
+    for buf in (a, b, s):
+        ctx.ntt(buf, log_n, cols, order=1)
+    t = ctx.alloc(n * cols)
+    ctx.field_op("add", a, b, t, n * cols)
+    assert (t.download() == s.download()).all()  # NTT(a) + NTT(b) == NTT(a + b)
+    ctx.ntt(a, log_n, cols, inverse=True, order=1)
+    assert (a.download() == a0).all()  # round trip
+    # DC term: sum of the inputs equals output[0]
+    col0 = a0[:n]
+    tot = 0
+    for chunk in np.array_split(col0, 64):
+        tot = (tot + int(np.sum(chunk.astype(object)))) % P
+    ctx.ntt(a, log_n, cols)
+    assert int(a.download(1)[0]) == tot
