@@ -152,9 +152,16 @@ int32_t vx_fri_fold(vx_ctx* ctx, const vx_buf* evals, int log_n, int arity_bits,
     size_t N = (size_t)1 << log_n, M = N >> arity_bits;
     VX_CHECK(evals->n >= 2 * N && out->n >= 2 * M, "fri fold: buffers too small");
     VX_CHECK(shift >= 1 && shift < GL_P && beta[0] < GL_P && beta[1] < GL_P, "fri fold: non-canonical input");
+    return vx_fri_fold_dev(ctx, evals->d, log_n, arity_bits, beta, shift, out->d);
+}
+}  // extern "C"
+
+int32_t vx_fri_fold_dev(vx_ctx* ctx, const uint64_t* evals, int log_n, int arity_bits, const uint64_t beta[2], uint64_t shift,
+                        uint64_t* out) {
+    size_t N = (size_t)1 << log_n, M = N >> arity_bits;
     FoldArgs a{};
-    a.in = evals->d;
-    a.out = out->d;
+    a.in = evals;
+    a.out = out;
     a.log_n = log_n;
     a.arity_bits = arity_bits;
     a.half = glh::inv(2);
@@ -183,12 +190,9 @@ int32_t vx_fri_fold(vx_ctx* ctx, const vx_buf* evals, int log_n, int arity_bits,
     return VX_OK;
 }
 
-int32_t vx_fri_layer_tree(vx_ctx* ctx, const vx_buf* evals, int log_n, int arity_bits, int cap_height, vx_tree** out) {
-    if (!ctx || !evals || !out) return VX_ERR_ARG;
-    VX_CHECK(arity_bits >= 0 && arity_bits <= 5 && arity_bits <= log_n && log_n <= 30, "fri tree: bad log_n %d / arity_bits %d", log_n, arity_bits);
+int32_t vx_fri_layer_tree_dev(vx_ctx* ctx, const uint64_t* evals_d, int log_n, int arity_bits, int cap_height, vx_tree** out) {
     size_t N = (size_t)1 << log_n, M = N >> arity_bits;
     int log_m = log_n - arity_bits;
-    VX_CHECK(evals->n >= 2 * N, "fri tree: evals too small");
     VX_CHECK(cap_height >= 0 && cap_height <= log_m, "fri tree: cap_height %d > %d", cap_height, log_m);
     size_t total = 0, cur = M, cap = (size_t)1 << cap_height;
     while (cur > cap) {
@@ -204,12 +208,12 @@ int32_t vx_fri_layer_tree(vx_ctx* ctx, const vx_buf* evals, int log_n, int arity
     }
     dim3 g((unsigned)((M + 255) / 256)), b(256);
     switch (arity_bits) {
-    case 0: hipLaunchKernelGGL(k_fri_leaf_hash<0>, g, b, 0, ctx->stream, evals->d, log_n, t->levels); break;
-    case 1: hipLaunchKernelGGL(k_fri_leaf_hash<1>, g, b, 0, ctx->stream, evals->d, log_n, t->levels); break;
-    case 2: hipLaunchKernelGGL(k_fri_leaf_hash<2>, g, b, 0, ctx->stream, evals->d, log_n, t->levels); break;
-    case 3: hipLaunchKernelGGL(k_fri_leaf_hash<3>, g, b, 0, ctx->stream, evals->d, log_n, t->levels); break;
-    case 4: hipLaunchKernelGGL(k_fri_leaf_hash<4>, g, b, 0, ctx->stream, evals->d, log_n, t->levels); break;
-    default: hipLaunchKernelGGL(k_fri_leaf_hash<5>, g, b, 0, ctx->stream, evals->d, log_n, t->levels); break;
+    case 0: hipLaunchKernelGGL(k_fri_leaf_hash<0>, g, b, 0, ctx->stream, evals_d, log_n, t->levels); break;
+    case 1: hipLaunchKernelGGL(k_fri_leaf_hash<1>, g, b, 0, ctx->stream, evals_d, log_n, t->levels); break;
+    case 2: hipLaunchKernelGGL(k_fri_leaf_hash<2>, g, b, 0, ctx->stream, evals_d, log_n, t->levels); break;
+    case 3: hipLaunchKernelGGL(k_fri_leaf_hash<3>, g, b, 0, ctx->stream, evals_d, log_n, t->levels); break;
+    case 4: hipLaunchKernelGGL(k_fri_leaf_hash<4>, g, b, 0, ctx->stream, evals_d, log_n, t->levels); break;
+    default: hipLaunchKernelGGL(k_fri_leaf_hash<5>, g, b, 0, ctx->stream, evals_d, log_n, t->levels); break;
     }
     size_t off = 0;
     cur = M;
@@ -230,6 +234,17 @@ int32_t vx_fri_layer_tree(vx_ctx* ctx, const vx_buf* evals, int log_n, int arity
     return VX_OK;
 }
 
+int32_t vx_fri_leaves_dev(vx_ctx* ctx, const uint64_t* evals, int log_n, int arity_bits, const uint64_t* leaf_idx, size_t n_idx,
+                          uint64_t* out);
+
+extern "C" {
+int32_t vx_fri_layer_tree(vx_ctx* ctx, const vx_buf* evals, int log_n, int arity_bits, int cap_height, vx_tree** out) {
+    if (!ctx || !evals || !out) return VX_ERR_ARG;
+    VX_CHECK(arity_bits >= 0 && arity_bits <= 5 && arity_bits <= log_n && log_n <= 30, "fri tree: bad log_n %d / arity_bits %d", log_n, arity_bits);
+    VX_CHECK(evals->n >= ((size_t)2 << log_n), "fri tree: evals too small");
+    return vx_fri_layer_tree_dev(ctx, evals->d, log_n, arity_bits, cap_height, out);
+}
+
 int32_t vx_fri_leaves(vx_ctx* ctx, const vx_buf* evals, int log_n, int arity_bits, const uint64_t* leaf_idx, size_t n_idx,
                       uint64_t* out) {
     if (!ctx || !evals || !leaf_idx || !out) return VX_ERR_ARG;
@@ -237,19 +252,26 @@ int32_t vx_fri_leaves(vx_ctx* ctx, const vx_buf* evals, int log_n, int arity_bit
     size_t N = (size_t)1 << log_n, M = N >> arity_bits;
     VX_CHECK(evals->n >= 2 * N, "fri leaves: evals too small");
     for (size_t i = 0; i < n_idx; ++i) VX_CHECK(leaf_idx[i] < M, "fri leaves: index out of range");
+    return vx_fri_leaves_dev(ctx, evals->d, log_n, arity_bits, leaf_idx, n_idx, out);
+}
+}  // extern "C"
+
+int32_t vx_fri_leaves_dev(vx_ctx* ctx, const uint64_t* evals_d, int log_n, int arity_bits, const uint64_t* leaf_idx, size_t n_idx,
+                          uint64_t* out) {
     if (!n_idx) return VX_OK;
     size_t tot = n_idx << arity_bits;
     uint64_t* sc;
     VX_TRY(vx_scratch(ctx, n_idx + 2 * tot, &sc));
     VX_HIP(hipMemcpyAsync(sc, leaf_idx, n_idx * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_fri_gather_leaves, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, evals->d, log_n,
-                       arity_bits, sc, n_idx, sc + n_idx);
+    hipLaunchKernelGGL(k_fri_gather_leaves, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, evals_d, log_n,
+                       arity_bits, (const uint64_t*)sc, n_idx, sc + n_idx);
     VX_HIP(hipGetLastError());
     VX_HIP(hipMemcpyAsync(out, sc + n_idx, 2 * tot * 8, hipMemcpyDeviceToHost, ctx->stream));
     VX_HIP(hipStreamSynchronize(ctx->stream));
     return VX_OK;
 }
 
+extern "C" {
 int32_t vx_fri_pow(vx_ctx* ctx, const uint64_t state[12], int pos, int bits, uint64_t* nonce) {
     if (!ctx || !state || !nonce) return VX_ERR_ARG;
     VX_CHECK(pos >= 0 && pos < 8 && bits >= 0 && bits <= 40, "fri pow: bad pos %d / bits %d", pos, bits);

@@ -90,3 +90,14 @@ int32_t vx_get_shift_tab(vx_ctx* ctx, uint64_t base, PowTab* out);
 int32_t vx_scratch(vx_ctx* ctx, size_t n_u64, uint64_t** out);
 int32_t vx_merkle_build_dev(vx_ctx* ctx, const uint64_t* data, size_t n_leaves, size_t leaf_len, int layout,
                             int cap_height, vx_tree** out);
+
+int32_t vx_ntt_dev(vx_ctx* ctx, uint64_t* d, int log_n, size_t n_cols, size_t col_stride, int inverse, uint64_t shift, int order);
+int32_t vx_lde_dev(vx_ctx* ctx, const uint64_t* src, int log_n, size_t n_cols, int rate_bits, uint64_t shift, int src_kind,
+                   uint64_t* dst, uint64_t* coeffs_out);
+int32_t vx_gather_rows_dev(vx_ctx* ctx, const uint64_t* lde, int log_N, size_t n_cols, const uint64_t* leaf_idx, size_t n_idx,
+                           uint64_t* out);
+int32_t vx_fri_fold_dev(vx_ctx* ctx, const uint64_t* evals, int log_n, int arity_bits, const uint64_t beta[2], uint64_t shift,
+                        uint64_t* out);
+int32_t vx_fri_layer_tree_dev(vx_ctx* ctx, const uint64_t* evals, int log_n, int arity_bits, int cap_height, vx_tree** out);
+int32_t vx_fri_leaves_dev(vx_ctx* ctx, const uint64_t* evals, int log_n, int arity_bits, const uint64_t* leaf_idx, size_t n_idx,
+                          uint64_t* out);

@@ -264,19 +264,66 @@ static int32_t bitrev_cols(vx_ctx* ctx, const uint64_t* in, size_t in_stride, ui
     return VX_OK;
 }
 
+int32_t vx_ntt_dev(vx_ctx* ctx, uint64_t* d, int log_n, size_t n_cols, size_t col_stride, int inverse, uint64_t shift, int order);
+
+// values/coeffs (column-major, stride n) -> coset evaluations (column-major, stride N, natural order)
+int32_t vx_lde_dev(vx_ctx* ctx, const uint64_t* src, int log_n, size_t n_cols, int rate_bits, uint64_t shift, int src_kind,
+                   uint64_t* dst, uint64_t* coeffs_out) {
+    size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    PowTab st{nullptr};
+    if (shift > 1) VX_TRY(vx_get_shift_tab(ctx, shift, &st));
+    uint64_t* co;  // coefficients in bit-reversed positions
+    VX_TRY(vx_scratch(ctx, n * n_cols, &co));
+    if (src_kind == VX_LDE_SRC_VALUES) {
+        uint64_t ninv = glh::inv((uint64_t)n % glh::P);
+        if (log_n == 0) VX_HIP(hipMemcpyAsync(co, src, n_cols * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        else VX_TRY(ntt_dif(ctx, src, n, co, n, log_n, n_cols, 1, ninv));
+        if (coeffs_out) VX_TRY(bitrev_cols(ctx, co, n, coeffs_out, n, log_n, n_cols));
+    } else {
+        VX_TRY(bitrev_cols(ctx, src, n, co, n, log_n, n_cols));
+        if (coeffs_out) VX_HIP(hipMemcpyAsync(coeffs_out, src, n * n_cols * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (log_n + rate_bits == 0) {
+        VX_HIP(hipMemcpyAsync(dst, co, n_cols * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return VX_OK;
+    }
+    return ntt_dit(ctx, co, n, dst, N, log_n + rate_bits, n_cols, 0, rate_bits, st.d);
+}
+
+int32_t vx_gather_rows_dev(vx_ctx* ctx, const uint64_t* lde, int log_N, size_t n_cols, const uint64_t* leaf_idx, size_t n_idx,
+                           uint64_t* out) {
+    if (n_idx == 0) return VX_OK;
+    uint64_t* sc;
+    VX_TRY(vx_scratch(ctx, n_idx + n_idx * n_cols, &sc));
+    VX_HIP(hipMemcpyAsync(sc, leaf_idx, n_idx * 8, hipMemcpyHostToDevice, ctx->stream));
+    size_t tot = n_idx * n_cols;
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, lde, log_N, n_cols,
+                       (const uint64_t*)sc, n_idx, sc + n_idx);
+    VX_HIP(hipGetLastError());
+    VX_HIP(hipMemcpyAsync(out, sc + n_idx, tot * 8, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipStreamSynchronize(ctx->stream));
+    return VX_OK;
+}
+
 extern "C" {
 
 int32_t vx_ntt(vx_ctx* ctx, vx_buf* buf, size_t off, int log_n, size_t n_cols, size_t col_stride, int inverse,
                uint64_t shift, int order) {
     if (!ctx || !buf) return VX_ERR_ARG;
     VX_CHECK(log_n >= 0 && log_n <= 28, "vx_ntt: log_n %d out of range [0,28]", log_n);
+    VX_CHECK(col_stride >= ((size_t)1 << log_n) && n_cols >= 1 && off + (n_cols - 1) * col_stride + ((size_t)1 << log_n) <= buf->n, "vx_ntt: columns exceed the buffer");
+    return vx_ntt_dev(ctx, buf->d + off, log_n, n_cols, col_stride, inverse, shift, order);
+}
+}  // extern "C"
+
+int32_t vx_ntt_dev(vx_ctx* ctx, uint64_t* d, int log_n, size_t n_cols, size_t col_stride, int inverse, uint64_t shift, int order) {
+    if (!ctx || !d) return VX_ERR_ARG;
+    VX_CHECK(log_n >= 0 && log_n <= 28, "vx_ntt: log_n %d out of range [0,28]", log_n);
     size_t n = (size_t)1 << log_n;
     VX_CHECK(n_cols >= 1 && n_cols <= 65535, "vx_ntt: n_cols %zu out of range", n_cols);
-    VX_CHECK(col_stride >= n && off + (n_cols - 1) * col_stride + n <= buf->n, "vx_ntt: columns exceed the buffer");
     VX_CHECK(shift < GL_P, "vx_ntt: shift not canonical");
     VX_CHECK(order == VX_ORDER_NATURAL || order == VX_ORDER_BITREV, "vx_ntt: bad order");
     if (log_n == 0) return VX_OK;
-    uint64_t* d = buf->d + off;
     const bool coset = shift > 1;
     const unsigned gx = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
     PowTab st{nullptr};
@@ -318,6 +365,8 @@ int32_t vx_ntt(vx_ctx* ctx, vx_buf* buf, size_t off, int log_n, size_t n_cols, s
     return VX_OK;
 }
 
+extern "C" {
+
 int32_t vx_lde(vx_ctx* ctx, const vx_buf* src, int log_n, size_t n_cols, int rate_bits, uint64_t shift, int src_kind,
                vx_buf* dst, vx_buf* coeffs_out) {
     if (!ctx || !src || !dst) return VX_ERR_ARG;
@@ -329,25 +378,7 @@ int32_t vx_lde(vx_ctx* ctx, const vx_buf* src, int log_n, size_t n_cols, int rat
     VX_CHECK(!coeffs_out || coeffs_out->n >= n * n_cols, "vx_lde: coeffs_out too small");
     VX_CHECK(shift >= 1 && shift < GL_P, "vx_lde: bad shift");
     VX_CHECK(src->d != dst->d, "vx_lde: src and dst alias");
-    PowTab st{nullptr};
-    if (shift > 1) VX_TRY(vx_get_shift_tab(ctx, shift, &st));
-    // coefficients in bit-reversed positions, in scratch
-    uint64_t* co;
-    VX_TRY(vx_scratch(ctx, n * n_cols, &co));
-    if (src_kind == VX_LDE_SRC_VALUES) {
-        uint64_t ninv = glh::inv((uint64_t)n % glh::P);
-        if (log_n == 0) VX_HIP(hipMemcpyAsync(co, src->d, n_cols * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        else VX_TRY(ntt_dif(ctx, src->d, n, co, n, log_n, n_cols, 1, ninv));
-        if (coeffs_out) VX_TRY(bitrev_cols(ctx, co, n, coeffs_out->d, n, log_n, n_cols));
-    } else {
-        VX_TRY(bitrev_cols(ctx, src->d, n, co, n, log_n, n_cols));
-        if (coeffs_out) VX_HIP(hipMemcpyAsync(coeffs_out->d, src->d, n * n_cols * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    }
-    if (log_n + rate_bits == 0) {
-        VX_HIP(hipMemcpyAsync(dst->d, co, n_cols * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        return VX_OK;
-    }
-    return ntt_dit(ctx, co, n, dst->d, N, log_n + rate_bits, n_cols, 0, rate_bits, st.d);
+    return vx_lde_dev(ctx, src->d, log_n, n_cols, rate_bits, shift, src_kind, dst->d, coeffs_out ? coeffs_out->d : nullptr);
 }
 
 int32_t vx_lde_rows(vx_ctx* ctx, const vx_buf* lde, int log_N, size_t n_cols, const uint64_t* leaf_idx, size_t n_idx,
@@ -356,16 +387,6 @@ int32_t vx_lde_rows(vx_ctx* ctx, const vx_buf* lde, int log_N, size_t n_cols, co
     size_t N = (size_t)1 << log_N;
     VX_CHECK(lde->n >= N * n_cols, "vx_lde_rows: lde too small");
     for (size_t i = 0; i < n_idx; ++i) VX_CHECK(leaf_idx[i] < N, "vx_lde_rows: leaf index %llu >= %zu", (unsigned long long)leaf_idx[i], N);
-    if (n_idx == 0) return VX_OK;
-    uint64_t* sc;
-    VX_TRY(vx_scratch(ctx, n_idx + n_idx * n_cols, &sc));
-    VX_HIP(hipMemcpyAsync(sc, leaf_idx, n_idx * 8, hipMemcpyHostToDevice, ctx->stream));
-    size_t tot = n_idx * n_cols;
-    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, lde->d, log_N, n_cols,
-                       sc, n_idx, sc + n_idx);
-    VX_HIP(hipGetLastError());
-    VX_HIP(hipMemcpyAsync(out, sc + n_idx, tot * 8, hipMemcpyDeviceToHost, ctx->stream));
-    VX_HIP(hipStreamSynchronize(ctx->stream));
-    return VX_OK;
+    return vx_gather_rows_dev(ctx, lde->d, log_N, n_cols, leaf_idx, n_idx, out);
 }
 }  // extern "C"

@@ -1,0 +1,606 @@
+// Generic STARK prover on the GPU primitives (K5 quotient evaluation, K7 transcript, K6 FRI
+// commit + query phases, proof serialisation).
+//
+// Protocol: starky v0.2.0 `prove_with_commitment` over plonky2 v0.2.0's PolynomialBatch /
+// FRI (crates pinned at /root/reference Cargo.lock:4848-4905; the reference reaches them
+// through every `circuit.prove`, circuits/header_range.rs:167, and through curta's STARKs,
+// circuits/builder/header.rs:18).  Same transcript order, same FRI (ConstantArityBits(4,5),
+// cap height 4, 84 queries, 16 PoW bits at rate_bits 1), but organised for the GPU:
+//   - nothing is transposed: LDEs stay column-major, leaves are rows read in place;
+//   - openings at zeta come from barycentric dot products over the trace values, not from
+//     coefficient Horner loops;
+//   - the FRI batch polynomial is assembled and folded in EVALUATION space from the committed
+//     LDE values (the CPU prover works on coefficients and re-runs an FFT per layer).
+// The oracle (oracle/stark_ref.py) restates the CPU prover's coefficient-space algorithm; proofs
+// must match byte for byte (tests/test_gpu_stark.py).
+#include <string.h>
+
+#include "air.cuh"
+#include "poseidon_constants.h"
+#include "vx_internal.h"
+
+// ------------------------------------------------------------------ host Poseidon + challenger
+namespace {
+const uint64_t H_RC[360] = VX_POSEIDON_RC_INIT;
+const uint64_t H_MDS[12] = VX_POSEIDON_MDS_CIRC_INIT;
+void h_poseidon(uint64_t* s) {
+    for (int r = 0; r < 30; ++r) {
+        for (int i = 0; i < 12; ++i) s[i] = glh::add(s[i], H_RC[12 * r + i]);
+        int full = (r < 4 || r >= 26);
+        for (int i = 0; i < (full ? 12 : 1); ++i) {
+            uint64_t x = s[i], x2 = glh::mul(x, x), x4 = glh::mul(x2, x2);
+            s[i] = glh::mul(glh::mul(x4, x2), x);
+        }
+        uint64_t o[12];
+        for (int row = 0; row < 12; ++row) {
+            unsigned __int128 acc = 0;
+            for (int i = 0; i < 12; ++i) acc += (unsigned __int128)s[(i + row) % 12] * H_MDS[i];
+            if (row == 0) acc += (unsigned __int128)s[0] * VX_POSEIDON_MDS_DIAG0;
+            o[row] = (uint64_t)(acc % glh::P);
+        }
+        memcpy(s, o, sizeof o);
+    }
+}
+struct Ext {
+    uint64_t a, b;
+};
+inline Ext e_add(Ext x, Ext y) { return {glh::add(x.a, y.a), glh::add(x.b, y.b)}; }
+inline Ext e_sub(Ext x, Ext y) { return {glh::sub(x.a, y.a), glh::sub(x.b, y.b)}; }
+inline Ext e_mul(Ext x, Ext y) {
+    return {glh::add(glh::mul(x.a, y.a), glh::mul(7, glh::mul(x.b, y.b))), glh::add(glh::mul(x.a, y.b), glh::mul(x.b, y.a))};
+}
+inline Ext e_scale(Ext x, uint64_t s) { return {glh::mul(x.a, s), glh::mul(x.b, s)}; }
+inline Ext e_inv(Ext x) {
+    uint64_t n = glh::sub(glh::mul(x.a, x.a), glh::mul(7, glh::mul(x.b, x.b)));
+    uint64_t ni = glh::inv(n);
+    return {glh::mul(x.a, ni), glh::mul(glh::sub(0, x.b), ni)};
+}
+inline Ext e_pow(Ext x, uint64_t e) {
+    Ext r{1, 0};
+    while (e) {
+        if (e & 1) r = e_mul(r, x);
+        x = e_mul(x, x);
+        e >>= 1;
+    }
+    return r;
+}
+struct Challenger {  // plonky2 iop/challenger.rs
+    uint64_t st[12] = {0}, in[8], out[8];
+    int n_in = 0, n_out = 0;
+    void duplex() {
+        for (int i = 0; i < n_in; ++i) st[i] = in[i];
+        n_in = 0;
+        h_poseidon(st);
+        memcpy(out, st, sizeof out);
+        n_out = 8;
+    }
+    void observe(uint64_t x) {
+        n_out = 0;
+        in[n_in++] = x;
+        if (n_in == 8) duplex();
+    }
+    void observe(const uint64_t* x, size_t n) {
+        for (size_t i = 0; i < n; ++i) observe(x[i]);
+    }
+    uint64_t challenge() {
+        if (n_in > 0 || n_out == 0) duplex();
+        return out[--n_out];
+    }
+    Ext ext_challenge() {
+        uint64_t a = challenge(), b = challenge();
+        return {a, b};
+    }
+};
+}  // namespace
+
+// ------------------------------------------------------------------ kernels
+__device__ __forceinline__ uint64_t root_pow_f(const uint64_t* tw, uint64_t e, int log_s) {
+    uint64_t E = (e << (32 - log_s)) & 0xFFFFFFFFULL;
+    uint64_t r = tw[4096 + (E >> 22)];
+    if (log_s > 10) r = gl_mul(r, tw[2048 + ((E >> 11) & 2047)]);
+    if (log_s > 21) r = gl_mul(r, tw[E & 2047]);
+    return r;
+}
+
+struct QuotArgs {
+    const uint64_t* lde;   // [COLS][N]
+    uint64_t* q_out;       // [2][N]
+    int log_N, rate_bits;
+    uint64_t shift, last, n_inv;  // coset shift g, w_n^-1, 1/n
+    uint64_t alpha[2];
+    uint64_t zh_inv[8];    // 1 / (g^n * w_{2^r}^k - 1), k < 2^r
+    uint64_t zh[8];        // g^n * w_{2^r}^k - 1
+    const uint64_t* periodic;  // [PERIODIC][(1<<PERIOD_LOG) << rate_bits] on the LDE coset
+    const uint64_t* pub;       // [PUB] (device)
+    const uint64_t* tw;        // forward w_{2^32} power table
+};
+
+template <class Air>
+__global__ __launch_bounds__(256) void k_quotient(QuotArgs a) {
+    const size_t N = (size_t)1 << a.log_N;
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint64_t x = gl_mul(a.shift, root_pow_f(a.tw, i, a.log_N));
+    const int k = (int)(i & (((size_t)1 << a.rate_bits) - 1));
+    Consumer<Fp> c;
+    c.acc[0] = c.acc[1] = {0};
+    c.alpha[0] = {a.alpha[0]};
+    c.alpha[1] = {a.alpha[1]};
+    c.z_last = {gl_sub(x, a.last)};
+    // L_first = Z_H(x) / (n (x - 1)),  L_last = last * Z_H(x) / (n (x - last))
+    const uint64_t zh_n = gl_mul(a.zh[k], a.n_inv);
+    c.l_first = {gl_mul(zh_n, gl_inv(gl_sub(x, 1)))};
+    c.l_last = {gl_mul(gl_mul(zh_n, a.last), gl_inv(gl_sub(x, a.last)))};
+    RowView loc{a.lde, N, i}, nxt{a.lde, N, (i + ((size_t)1 << a.rate_bits)) & (N - 1)};
+    Fp per[Air::PERIODIC > 0 ? Air::PERIODIC : 1], pub[Air::PUB > 0 ? Air::PUB : 1];
+    const size_t plen = (size_t)1 << (Air::PERIOD_LOG + a.rate_bits);
+#pragma unroll
+    for (int j = 0; j < Air::PERIODIC; ++j) per[j] = {a.periodic[j * plen + (i & (plen - 1))]};
+#pragma unroll
+    for (int j = 0; j < Air::PUB; ++j) pub[j] = {a.pub[j]};
+    Air::template eval<Fp>(loc, nxt, per, pub, c);
+    a.q_out[i] = gl_mul(c.acc[0].v, a.zh_inv[k]);
+    a.q_out[N + i] = gl_mul(c.acc[1].v, a.zh_inv[k]);
+}
+
+// barycentric weights over the trace domain H: w0[i] = w^i / (zeta - w^i), w1[i] = w^i / (w*zeta - w^i)
+__global__ __launch_bounds__(256) void k_bary_weights(int log_n, gl2 zeta, gl2 zeta_next, const uint64_t* tw, uint64_t* w0,
+                                                      uint64_t* w1) {
+    size_t n = (size_t)1 << log_n;
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t wi = root_pow_f(tw, i, log_n);
+    gl2 d0 = gl2_inv({gl_sub(zeta.a, wi), zeta.b});
+    gl2 d1 = gl2_inv({gl_sub(zeta_next.a, wi), zeta_next.b});
+    d0 = gl2_scale(d0, wi);
+    d1 = gl2_scale(d1, wi);
+    w0[2 * i] = d0.a;
+    w0[2 * i + 1] = d0.b;
+    w1[2 * i] = d1.a;
+    w1[2 * i + 1] = d1.b;
+}
+// out[col] = (sum_i T[col][i] * w0[i], sum_i T[col][i] * w1[i]); one block per column
+__global__ __launch_bounds__(256) void k_bary_dot(const uint64_t* vals, size_t n, const uint64_t* w0, const uint64_t* w1,
+                                                  uint64_t* out) {
+    __shared__ uint64_t red[256 * 4];
+    const uint64_t* col = vals + blockIdx.x * n;
+    gl2 s0{0, 0}, s1{0, 0};
+    for (size_t i = threadIdx.x; i < n; i += 256) {
+        uint64_t v = col[i];
+        s0 = gl2_add(s0, gl2_scale({w0[2 * i], w0[2 * i + 1]}, v));
+        s1 = gl2_add(s1, gl2_scale({w1[2 * i], w1[2 * i + 1]}, v));
+    }
+    red[4 * threadIdx.x] = s0.a;
+    red[4 * threadIdx.x + 1] = s0.b;
+    red[4 * threadIdx.x + 2] = s1.a;
+    red[4 * threadIdx.x + 3] = s1.b;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h)
+            for (int e = 0; e < 4; ++e) red[4 * threadIdx.x + e] = gl_add(red[4 * threadIdx.x + e], red[4 * (threadIdx.x + h) + e]);
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) out[4 * blockIdx.x + threadIdx.x] = red[threadIdx.x];
+}
+
+struct CombineArgs {
+    const uint64_t* trace_lde;  // [c][N]
+    const uint64_t* quot_lde;   // [nq][N]
+    int n_cols, n_q, log_N;
+    const uint64_t* alpha_pow;  // (c + nq) ext powers of the FRI alpha (device)
+    gl2 alpha_c;                // alpha^c
+    gl2 y0, y1;                 // reduced openings at zeta / w*zeta
+    gl2 zeta, zeta_next;
+    uint64_t shift;
+    const uint64_t* tw;
+    uint64_t* out;  // [N] ext
+};
+// final_poly(x) = alpha^c * (S0(x) - y0) / (x - zeta) + (S1(x) - y1) / (x - w zeta)
+// (PolynomialBatch::prove_openings: batch 0 = trace ++ quotient at zeta, batch 1 = trace at w*zeta)
+__global__ __launch_bounds__(256) void k_fri_combine(CombineArgs a) {
+    const size_t N = (size_t)1 << a.log_N;
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    gl2 s1{0, 0};
+    for (int j = 0; j < a.n_cols; ++j)
+        s1 = gl2_add(s1, gl2_scale({a.alpha_pow[2 * j], a.alpha_pow[2 * j + 1]}, a.trace_lde[(size_t)j * N + i]));
+    gl2 s0 = s1;
+    for (int j = 0; j < a.n_q; ++j) {
+        int k = a.n_cols + j;
+        s0 = gl2_add(s0, gl2_scale({a.alpha_pow[2 * k], a.alpha_pow[2 * k + 1]}, a.quot_lde[(size_t)j * N + i]));
+    }
+    const uint64_t x = gl_mul(a.shift, root_pow_f(a.tw, i, a.log_N));
+    gl2 t0 = gl2_mul(gl2_sub(s0, a.y0), gl2_inv({gl_sub(x, a.zeta.a), gl_neg(a.zeta.b)}));
+    gl2 t1 = gl2_mul(gl2_sub(s1, a.y1), gl2_inv({gl_sub(x, a.zeta_next.a), gl_neg(a.zeta_next.b)}));
+    gl2 f = gl2_add(gl2_mul(a.alpha_c, t0), t1);
+    a.out[2 * i] = f.a;
+    a.out[2 * i + 1] = f.b;
+}
+
+// ------------------------------------------------------------------ AIR registry
+struct AirDesc {
+    int id, cols, pub, periodic, period_log;
+    void (*periodic_values)(std::vector<uint64_t>&);  // [periodic][1 << period_log] values on the trace rows
+    void (*launch)(QuotArgs&, hipStream_t);
+};
+template <class Air>
+static void launch_q(QuotArgs& a, hipStream_t s) {
+    size_t N = (size_t)1 << a.log_N;
+    hipLaunchKernelGGL(k_quotient<Air>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, a);
+}
+static void no_periodic(std::vector<uint64_t>& v) { v.clear(); }
+static void mix_periodic(std::vector<uint64_t>& v) { v = {0, 0, 0, 1, 3, 5, 7, 11}; }
+static const AirDesc AIRS[] = {
+    {FibAir::ID, FibAir::COLS, FibAir::PUB, FibAir::PERIODIC, FibAir::PERIOD_LOG, no_periodic, launch_q<FibAir>},
+    {MixAir::ID, MixAir::COLS, MixAir::PUB, MixAir::PERIODIC, MixAir::PERIOD_LOG, mix_periodic, launch_q<MixAir>},
+};
+static const AirDesc* find_air(int id) {
+    for (const AirDesc& d : AIRS)
+        if (d.id == id) return &d;
+    return nullptr;
+}
+
+// values v[0..p) of a periodic column on the rows -> its values on the LDE coset:
+// P(Y) with P(w_p^k) = v[k]; coset point Y_i = shift^(n/p) * w_{p 2^r}^i, i < p 2^r.
+static void periodic_on_coset(const uint64_t* v, int period_log, int rate_bits, uint64_t shift_pow, uint64_t* out) {
+    size_t p = (size_t)1 << period_log, m = p << rate_bits;
+    std::vector<uint64_t> coef(p);
+    uint64_t wp_inv = glh::inv(glh::root(period_log)), pinv = glh::inv(p % glh::P);
+    for (size_t k = 0; k < p; ++k) {  // inverse DFT, O(p^2)
+        uint64_t acc = 0, w = glh::pow(wp_inv, k), cur = 1;
+        for (size_t j = 0; j < p; ++j) {
+            acc = glh::add(acc, glh::mul(v[j], cur));
+            cur = glh::mul(cur, w);
+        }
+        coef[k] = glh::mul(acc, pinv);
+    }
+    uint64_t wm = glh::root(period_log + rate_bits);
+    for (size_t i = 0; i < m; ++i) {
+        uint64_t y = glh::mul(shift_pow, glh::pow(wm, i)), acc = 0;
+        for (size_t k = p; k-- > 0;) acc = glh::add(glh::mul(acc, y), coef[k]);
+        out[i] = acc;
+    }
+}
+
+struct DevMem {  // RAII for the prover's temporaries
+    std::vector<void*> ptrs;
+    std::vector<vx_tree*> trees;
+    ~DevMem() {
+        for (void* p : ptrs) (void)hipFree(p);
+        for (vx_tree* t : trees) {
+            (void)hipFree(t->levels);
+            delete t;
+        }
+    }
+    uint64_t* alloc(size_t n_u64) {
+        void* p = nullptr;
+        if (hipMalloc(&p, n_u64 * 8) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return (uint64_t*)p;
+    }
+};
+
+static const uint64_t VX_PROOF_MAGIC = 0x314b524154535856ULL;  // "VXSTARK1"
+
+static void push_cap(vx_ctx* ctx, const vx_tree* t, std::vector<uint64_t>& out) {
+    size_t cap = (size_t)4 << t->cap_height;
+    size_t o = out.size();
+    out.resize(o + cap);
+    (void)hipMemcpyAsync(out.data() + o, t->levels + t->total - cap, cap * 8, hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+}
+
+static std::vector<int> fri_arity_plan(int degree_bits, const vx_stark_config& cfg) {
+    // FriReductionStrategy::ConstantArityBits(arity_bits, final_poly_bits)
+    std::vector<int> r;
+    int d = degree_bits;
+    while (d > cfg.final_poly_bits && d + cfg.rate_bits - cfg.arity_bits >= cfg.cap_height) {
+        r.push_back(cfg.arity_bits);
+        d -= cfg.arity_bits;
+    }
+    return r;
+}
+
+extern "C" {
+
+int32_t vx_stark_default_config(vx_stark_config* cfg) {
+    if (!cfg) return VX_ERR_ARG;
+    // starky StarkConfig::standard_fast_config: 100-bit conjectured security
+    cfg->rate_bits = 1;
+    cfg->cap_height = 4;
+    cfg->num_queries = 84;
+    cfg->pow_bits = 16;
+    cfg->arity_bits = 4;
+    cfg->final_poly_bits = 5;
+    return VX_OK;
+}
+
+int32_t vx_stark_prove(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_in, const vx_buf* trace, int log_n,
+                       const uint64_t* public_inputs, size_t n_public, uint64_t* proof_out, size_t proof_cap,
+                       size_t* proof_len) {
+    if (!ctx || !cfg_in || !trace || !proof_len) return VX_ERR_ARG;
+    const AirDesc* air = find_air(air_id);
+    VX_CHECK(air, "stark prove: unknown AIR id %d", air_id);
+    const vx_stark_config cfg = *cfg_in;
+    VX_CHECK(cfg.rate_bits >= 1 && cfg.rate_bits <= 3, "stark prove: rate_bits %d not in [1,3]", cfg.rate_bits);
+    VX_CHECK(cfg.arity_bits >= 1 && cfg.arity_bits <= 5 && cfg.final_poly_bits >= 0 && cfg.num_queries >= 1 && cfg.num_queries <= 1024 &&
+                 cfg.pow_bits >= 0 && cfg.pow_bits <= 32, "stark prove: bad FRI config");
+    const int L = log_n, r = cfg.rate_bits, LN = L + r;
+    VX_CHECK(L >= air->period_log && L >= 2 && LN <= 27, "stark prove: log_n %d out of range", L);
+    VX_CHECK(cfg.cap_height >= 0 && cfg.cap_height <= LN, "stark prove: cap_height %d > log2(lde size) %d", cfg.cap_height, LN);
+    VX_CHECK((int)n_public == air->pub && (n_public == 0 || public_inputs), "stark prove: AIR %d takes %d public inputs", air_id, air->pub);
+    const size_t n = (size_t)1 << L, N = (size_t)1 << LN, c = air->cols;
+    VX_CHECK(trace->n >= n * c, "stark prove: trace holds %zu < %zu elements", trace->n, n * c);
+    for (size_t i = 0; i < n_public; ++i) VX_CHECK(public_inputs[i] < glh::P, "stark prove: public input %zu not canonical", i);
+    const int Q = 2, nq = 2 * Q;  // quotient_degree_factor 2 (constraint degree 3), 2 challenges
+    const uint64_t g = 7;         // F::coset_shift()
+    DevMem mem;
+    std::vector<uint64_t> proof;
+
+    // ---- 1. trace commitment: PolynomialBatch::from_values
+    uint64_t* trace_lde = mem.alloc(N * c);
+    VX_CHECK(trace_lde, "stark prove: out of device memory (trace LDE)");
+    VX_TRY(vx_lde_dev(ctx, trace->d, L, c, r, g, VX_LDE_SRC_VALUES, trace_lde, nullptr));
+    vx_tree* t_trace = nullptr;
+    VX_TRY(vx_merkle_build_dev(ctx, trace_lde, N, c, VX_LEAVES_COLS_BITREV, cfg.cap_height, &t_trace));
+    mem.trees.push_back(t_trace);
+
+    const std::vector<int> arities = fri_arity_plan(L, cfg);
+    int final_log = LN;
+    for (int a : arities) final_log -= a;
+    const size_t final_len = ((size_t)1 << final_log) >> r;
+
+    proof.push_back(VX_PROOF_MAGIC);
+    for (uint64_t w : {(uint64_t)air_id, (uint64_t)L, (uint64_t)c, (uint64_t)nq, (uint64_t)r, (uint64_t)cfg.cap_height,
+                       (uint64_t)cfg.num_queries, (uint64_t)cfg.pow_bits, (uint64_t)arities.size()})
+        proof.push_back(w);
+    for (int a : arities) proof.push_back((uint64_t)a);
+    proof.push_back((uint64_t)final_len);
+    proof.push_back((uint64_t)n_public);
+    for (size_t i = 0; i < n_public; ++i) proof.push_back(public_inputs[i]);
+    const size_t cap_words = (size_t)4 << cfg.cap_height;
+    push_cap(ctx, t_trace, proof);
+
+    Challenger ch;
+    ch.observe(public_inputs, n_public);
+    ch.observe(proof.data() + proof.size() - cap_words, cap_words);
+    uint64_t alphas[2] = {ch.challenge(), 0};
+    alphas[1] = ch.challenge();
+
+    // ---- 2. quotient polynomials (compute_quotient_polys) on the size-N coset
+    uint64_t* qv = mem.alloc(2 * N);
+    uint64_t* d_pub = mem.alloc(n_public ? n_public : 1);
+    VX_CHECK(qv && d_pub, "stark prove: out of device memory (quotient)");
+    if (n_public) VX_HIP(hipMemcpyAsync(d_pub, public_inputs, n_public * 8, hipMemcpyHostToDevice, ctx->stream));
+    uint64_t* d_per = nullptr;
+    if (air->periodic) {
+        std::vector<uint64_t> pv, tab;
+        air->periodic_values(pv);
+        const size_t p = (size_t)1 << air->period_log, m = p << r;
+        tab.resize(air->periodic * m);
+        const uint64_t shift_pow = glh::pow(g, n >> air->period_log);
+        for (int j = 0; j < air->periodic; ++j) periodic_on_coset(pv.data() + j * p, air->period_log, r, shift_pow, tab.data() + j * m);
+        d_per = mem.alloc(tab.size());
+        VX_CHECK(d_per, "stark prove: out of device memory (periodic)");
+        VX_HIP(hipMemcpyAsync(d_per, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        VX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    {
+        QuotArgs qa{};
+        qa.lde = trace_lde;
+        qa.q_out = qv;
+        qa.log_N = LN;
+        qa.rate_bits = r;
+        qa.shift = g;
+        qa.last = glh::inv(glh::root(L));
+        qa.n_inv = glh::inv(n % glh::P);
+        qa.alpha[0] = alphas[0];
+        qa.alpha[1] = alphas[1];
+        const uint64_t gn = glh::pow(g, n), wr = glh::root(r);
+        for (int k = 0; k < (1 << r); ++k) {
+            qa.zh[k] = glh::sub(glh::mul(gn, glh::pow(wr, k)), 1);
+            qa.zh_inv[k] = glh::inv(qa.zh[k]);
+        }
+        qa.periodic = d_per;
+        qa.pub = d_pub;
+        qa.tw = ctx->tw_fwd.d;
+        air->launch(qa, ctx->stream);
+        VX_HIP(hipGetLastError());
+    }
+    // values on the coset -> coefficients (coset_ifft), split into Q chunks of n, commit (from_coeffs)
+    VX_TRY(vx_ntt_dev(ctx, qv, LN, 2, N, 1, g, VX_ORDER_NATURAL));
+    // chunk j of challenge k = qv[k*N + j*n .. +n): already contiguous as 2*Q columns of n coefficients
+    uint64_t* quot_lde = mem.alloc(N * nq);
+    VX_CHECK(quot_lde, "stark prove: out of device memory (quotient LDE)");
+    VX_TRY(vx_lde_dev(ctx, qv, L, nq, r, g, VX_LDE_SRC_COEFFS, quot_lde, nullptr));
+    vx_tree* t_quot = nullptr;
+    VX_TRY(vx_merkle_build_dev(ctx, quot_lde, N, nq, VX_LEAVES_COLS_BITREV, cfg.cap_height, &t_quot));
+    mem.trees.push_back(t_quot);
+    push_cap(ctx, t_quot, proof);
+    ch.observe(proof.data() + proof.size() - cap_words, cap_words);
+    const Ext zeta = ch.ext_challenge();
+    const uint64_t wn = glh::root(L);
+    const Ext zeta_next = e_scale(zeta, wn);
+    {
+        Ext zn = e_pow(zeta, n);
+        VX_CHECK(!(zn.a == 1 && zn.b == 0), "stark prove: zeta landed in the trace subgroup");
+    }
+
+    // ---- 3. openings (StarkOpeningSet::new): barycentric dot products over the trace domain
+    VX_TRY(vx_ntt_dev(ctx, qv, L, nq, n, 0, 0, VX_ORDER_NATURAL));  // quotient chunk values on H
+    uint64_t* w0 = mem.alloc(2 * n);
+    uint64_t* w1 = mem.alloc(2 * n);
+    uint64_t* d_open = mem.alloc(4 * (c + nq));
+    VX_CHECK(w0 && w1 && d_open, "stark prove: out of device memory (openings)");
+    hipLaunchKernelGGL(k_bary_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, L, gl2{zeta.a, zeta.b},
+                       gl2{zeta_next.a, zeta_next.b}, (const uint64_t*)ctx->tw_fwd.d, w0, w1);
+    hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)c), dim3(256), 0, ctx->stream, (const uint64_t*)trace->d, n, (const uint64_t*)w0,
+                       (const uint64_t*)w1, d_open);
+    hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)nq), dim3(256), 0, ctx->stream, (const uint64_t*)qv, n, (const uint64_t*)w0,
+                       (const uint64_t*)w1, d_open + 4 * c);
+    VX_HIP(hipGetLastError());
+    std::vector<uint64_t> h_open(4 * (c + nq));
+    VX_HIP(hipMemcpyAsync(h_open.data(), d_open, h_open.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t ninv = glh::inv(n % glh::P);
+    const Ext f0 = e_scale(e_sub(e_pow(zeta, n), Ext{1, 0}), ninv);       // (zeta^n - 1)/n
+    const Ext f1 = e_scale(e_sub(e_pow(zeta_next, n), Ext{1, 0}), ninv);  // ((w zeta)^n - 1)/n
+    std::vector<Ext> o_local(c), o_next(c), o_quot(nq);
+    for (size_t j = 0; j < c; ++j) {
+        o_local[j] = e_mul(f0, Ext{h_open[4 * j], h_open[4 * j + 1]});
+        o_next[j] = e_mul(f1, Ext{h_open[4 * j + 2], h_open[4 * j + 3]});
+    }
+    for (int j = 0; j < nq; ++j) o_quot[j] = e_mul(f0, Ext{h_open[4 * (c + j)], h_open[4 * (c + j) + 1]});
+    for (const Ext& e : o_local) proof.push_back(e.a), proof.push_back(e.b);
+    for (const Ext& e : o_next) proof.push_back(e.a), proof.push_back(e.b);
+    for (const Ext& e : o_quot) proof.push_back(e.a), proof.push_back(e.b);
+    // challenger.observe_openings: batch 0 = local ++ quotient, batch 1 = next
+    for (const Ext& e : o_local) ch.observe(e.a), ch.observe(e.b);
+    for (const Ext& e : o_quot) ch.observe(e.a), ch.observe(e.b);
+    for (const Ext& e : o_next) ch.observe(e.a), ch.observe(e.b);
+
+    // ---- 4. FRI batch polynomial (prove_openings), in evaluation space
+    const Ext alpha = ch.ext_challenge();
+    std::vector<uint64_t> apow(2 * (c + nq));
+    Ext cur{1, 0}, y0{0, 0}, y1{0, 0}, alpha_c{1, 0};
+    for (size_t j = 0; j < c + nq; ++j) {
+        apow[2 * j] = cur.a;
+        apow[2 * j + 1] = cur.b;
+        if (j < c) {
+            y0 = e_add(y0, e_mul(cur, o_local[j]));
+            y1 = e_add(y1, e_mul(cur, o_next[j]));
+        } else y0 = e_add(y0, e_mul(cur, o_quot[j - c]));
+        cur = e_mul(cur, alpha);
+        if (j + 1 == c) alpha_c = cur;
+    }
+    uint64_t* d_apow = mem.alloc(apow.size());
+    std::vector<uint64_t*> layers;
+    layers.push_back(mem.alloc(2 * N));
+    VX_CHECK(d_apow && layers[0], "stark prove: out of device memory (FRI)");
+    VX_HIP(hipMemcpyAsync(d_apow, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    {
+        CombineArgs ca{};
+        ca.trace_lde = trace_lde;
+        ca.quot_lde = quot_lde;
+        ca.n_cols = (int)c;
+        ca.n_q = nq;
+        ca.log_N = LN;
+        ca.alpha_pow = d_apow;
+        ca.alpha_c = {alpha_c.a, alpha_c.b};
+        ca.y0 = {y0.a, y0.b};
+        ca.y1 = {y1.a, y1.b};
+        ca.zeta = {zeta.a, zeta.b};
+        ca.zeta_next = {zeta_next.a, zeta_next.b};
+        ca.shift = g;
+        ca.tw = ctx->tw_fwd.d;
+        ca.out = layers[0];
+        hipLaunchKernelGGL(k_fri_combine, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, ca);
+        VX_HIP(hipGetLastError());
+    }
+
+    // ---- 5. FRI commit phase (fri_committed_trees)
+    std::vector<vx_tree*> ltrees;
+    std::vector<int> llog;
+    int cur_log = LN;
+    uint64_t shift = g;
+    for (int a : arities) {
+        vx_tree* t = nullptr;
+        VX_TRY(vx_fri_layer_tree_dev(ctx, layers.back(), cur_log, a, cfg.cap_height, &t));
+        mem.trees.push_back(t);
+        ltrees.push_back(t);
+        llog.push_back(cur_log);
+        push_cap(ctx, t, proof);
+        ch.observe(proof.data() + proof.size() - cap_words, cap_words);
+        const Ext beta = ch.ext_challenge();
+        const uint64_t b2[2] = {beta.a, beta.b};
+        uint64_t* nxt = mem.alloc((size_t)2 << (cur_log - a));
+        VX_CHECK(nxt, "stark prove: out of device memory (FRI layer)");
+        VX_TRY(vx_fri_fold_dev(ctx, layers.back(), cur_log, a, b2, shift, nxt));
+        layers.push_back(nxt);
+        shift = glh::pow(shift, (uint64_t)1 << a);
+        cur_log -= a;
+    }
+    // final polynomial: coset_ifft of the last layer on the host (<= 2^(final_poly_bits + arity + r) points)
+    const size_t fm = (size_t)1 << cur_log;
+    std::vector<uint64_t> fv(2 * fm), fc(2 * fm);
+    VX_HIP(hipMemcpyAsync(fv.data(), layers.back(), 2 * fm * 8, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipStreamSynchronize(ctx->stream));
+    {
+        const uint64_t wi = glh::inv(glh::root(cur_log)), minv = glh::inv(fm % glh::P), sinv = glh::inv(shift);
+        uint64_t sk = 1;
+        for (size_t k = 0; k < fm; ++k) {
+            Ext acc{0, 0};
+            const uint64_t wk = glh::pow(wi, k);
+            uint64_t wcur = 1;
+            for (size_t i = 0; i < fm; ++i) {
+                acc = e_add(acc, e_scale(Ext{fv[2 * i], fv[2 * i + 1]}, wcur));
+                wcur = glh::mul(wcur, wk);
+            }
+            acc = e_scale(acc, glh::mul(minv, sk));
+            fc[2 * k] = acc.a;
+            fc[2 * k + 1] = acc.b;
+            sk = glh::mul(sk, sinv);
+        }
+    }
+    for (size_t k = final_len; k < fm; ++k)
+        VX_CHECK(fc[2 * k] == 0 && fc[2 * k + 1] == 0, "stark prove: final polynomial has degree >= %zu: the trace violates the AIR constraints", final_len);
+    for (size_t k = 0; k < 2 * final_len; ++k) proof.push_back(fc[k]);
+    ch.observe(fc.data(), 2 * final_len);
+
+    // ---- 6. proof of work (fri_proof_of_work), smallest nonce
+    {
+        uint64_t st[12];
+        memcpy(st, ch.st, sizeof st);
+        for (int i = 0; i < ch.n_in; ++i) st[i] = ch.in[i];
+        uint64_t nonce = 0;
+        VX_TRY(vx_fri_pow(ctx, st, ch.n_in, cfg.pow_bits, &nonce));
+        proof.push_back(nonce);
+        ch.observe(nonce);
+        const uint64_t resp = ch.challenge();
+        VX_CHECK(cfg.pow_bits == 0 || (resp >> (64 - cfg.pow_bits)) == 0, "stark prove: PoW response check failed");
+    }
+
+    // ---- 7. query phase (fri_prover_query_rounds)
+    const size_t nqr = cfg.num_queries;
+    std::vector<uint64_t> qidx(nqr);
+    for (size_t k = 0; k < nqr; ++k) qidx[k] = ch.challenge() % N;
+    const int depth0 = LN - cfg.cap_height;
+    std::vector<uint64_t> rows_t(nqr * c), rows_q(nqr * nq), sib_t(nqr * depth0 * 4), sib_q(nqr * depth0 * 4);
+    VX_TRY(vx_gather_rows_dev(ctx, trace_lde, LN, c, qidx.data(), nqr, rows_t.data()));
+    VX_TRY(vx_gather_rows_dev(ctx, quot_lde, LN, nq, qidx.data(), nqr, rows_q.data()));
+    if (depth0 > 0) {
+        VX_TRY(vx_merkle_open(ctx, t_trace, qidx.data(), nqr, sib_t.data()));
+        VX_TRY(vx_merkle_open(ctx, t_quot, qidx.data(), nqr, sib_q.data()));
+    }
+    std::vector<std::vector<uint64_t>> l_leaves(arities.size()), l_sibs(arities.size());
+    std::vector<uint64_t> lidx = qidx;
+    for (size_t l = 0; l < arities.size(); ++l) {
+        const int a = arities[l], depth = llog[l] - a - cfg.cap_height;
+        for (size_t k = 0; k < nqr; ++k) lidx[k] >>= a;  // leaf index in this layer's tree
+        l_leaves[l].resize(nqr * ((size_t)2 << a));
+        VX_TRY(vx_fri_leaves_dev(ctx, layers[l], llog[l], a, lidx.data(), nqr, l_leaves[l].data()));
+        l_sibs[l].resize(nqr * (depth > 0 ? depth : 0) * 4);
+        if (depth > 0) VX_TRY(vx_merkle_open(ctx, ltrees[l], lidx.data(), nqr, l_sibs[l].data()));
+    }
+    for (size_t k = 0; k < nqr; ++k) {
+        proof.insert(proof.end(), rows_t.begin() + k * c, rows_t.begin() + (k + 1) * c);
+        proof.insert(proof.end(), sib_t.begin() + k * depth0 * 4, sib_t.begin() + (k + 1) * depth0 * 4);
+        proof.insert(proof.end(), rows_q.begin() + k * nq, rows_q.begin() + (k + 1) * nq);
+        proof.insert(proof.end(), sib_q.begin() + k * depth0 * 4, sib_q.begin() + (k + 1) * depth0 * 4);
+        uint64_t x_index = qidx[k];
+        for (size_t l = 0; l < arities.size(); ++l) {
+            const int a = arities[l], depth = llog[l] - a - cfg.cap_height;
+            const size_t arity = (size_t)1 << a, within = x_index & (arity - 1);
+            const uint64_t* leaf = l_leaves[l].data() + k * 2 * arity;
+            for (size_t t = 0; t < arity; ++t)  // evals.remove(x_index & (arity - 1))
+                if (t != within) proof.push_back(leaf[2 * t]), proof.push_back(leaf[2 * t + 1]);
+            if (depth > 0) proof.insert(proof.end(), l_sibs[l].begin() + k * depth * 4, l_sibs[l].begin() + (k + 1) * depth * 4);
+            x_index >>= a;
+        }
+    }
+    *proof_len = proof.size();
+    if (!proof_out || proof_cap < proof.size()) return vx_fail(ctx, VX_ERR_BUFSZ, "stark prove: proof needs %zu words, buffer has %zu", proof.size(), proof_cap);
+    memcpy(proof_out, proof.data(), proof.size() * 8);
+    return VX_OK;
+}
+}  // extern "C"

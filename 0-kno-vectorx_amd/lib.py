@@ -22,8 +22,16 @@ SYMBOLS = [
     "vx_ntt", "vx_lde", "vx_lde_rows",
     "vx_poseidon_permute_batch", "vx_merkle_build", "vx_merkle_free", "vx_merkle_cap", "vx_merkle_open", "vx_merkle_leaf_digests",
     "vx_fri_fold", "vx_fri_layer_tree", "vx_fri_leaves", "vx_fri_pow",
+    "vx_stark_default_config", "vx_stark_prove",
     "vx_blake2b_256_batch", "vx_sha256_pairs", "vx_verify_subchain",
 ]
+
+VX_AIR_FIBONACCI, VX_AIR_MIX = 1, 2
+
+
+class StarkConfig(C.Structure):
+    _fields_ = [("rate_bits", C.c_int32), ("cap_height", C.c_int32), ("num_queries", C.c_int32), ("pow_bits", C.c_int32),
+                ("arity_bits", C.c_int32), ("final_poly_bits", C.c_int32)]
 
 
 class VxError(RuntimeError):
@@ -68,6 +76,8 @@ def load_library():
         "vx_merkle_cap": [vp, vp, vp], "vx_merkle_open": [vp, vp, vp, sz, vp], "vx_merkle_leaf_digests": [vp, vp, vp],
         "vx_fri_fold": [vp, vp, C.c_int, C.c_int, vp, u64, vp], "vx_fri_layer_tree": [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
         "vx_fri_leaves": [vp, vp, C.c_int, C.c_int, vp, sz, vp], "vx_fri_pow": [vp, vp, C.c_int, C.c_int, C.POINTER(u64)],
+        "vx_stark_default_config": [C.POINTER(StarkConfig)],
+        "vx_stark_prove": [vp, C.c_int, C.POINTER(StarkConfig), vp, C.c_int, vp, sz, vp, sz, C.POINTER(sz)],
         "vx_blake2b_256_batch": [vp, vp, sz, vp, sz, vp], "vx_sha256_pairs": [vp, vp, sz, vp],
         "vx_verify_subchain": [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp],
     }
@@ -247,6 +257,26 @@ class Context:
         nonce = C.c_uint64()
         self._ck(self.L.vx_fri_pow(self.h, _ptr(s), pos, bits, C.byref(nonce)))
         return nonce.value
+
+    # K5/K7: generic STARK prover
+    def stark_config(self, **over):
+        cfg = StarkConfig()
+        self._ck(self.L.vx_stark_default_config(C.byref(cfg)))
+        for k, v in over.items():
+            setattr(cfg, k, v)
+        return cfg
+
+    def stark_prove(self, air_id, trace_buf, log_n, public_inputs, cfg=None):
+        cfg = cfg or self.stark_config()
+        pub = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        need = C.c_size_t(0)
+        rc = self.L.vx_stark_prove(self.h, air_id, C.byref(cfg), trace_buf.h, log_n, _ptr(pub), pub.size, None, 0, C.byref(need))
+        if rc != -4:
+            self._ck(rc)
+        # the sizing call ran the prover once; the proof is deterministic, so run again into the buffer
+        out = np.empty(need.value, dtype=np.uint64)
+        self._ck(self.L.vx_stark_prove(self.h, air_id, C.byref(cfg), trace_buf.h, log_n, _ptr(pub), pub.size, _ptr(out), out.size, C.byref(need)))
+        return out[: need.value]
 
     # K8 / statement
     def blake2b_256_batch(self, msgs_buf, stride, sizes):

@@ -143,6 +143,27 @@ int32_t vx_fri_leaves(vx_ctx* ctx, const vx_buf* evals, int log_n, int arity_bit
  * see DESIGN.md section 6.) */
 int32_t vx_fri_pow(vx_ctx* ctx, const uint64_t state[12], int pos, int bits, uint64_t* nonce);
 
+/* ---- K5/K7 + K6 query phase: generic STARK prover (starky v0.2.0 `prove_with_commitment` over
+ * plonky2 v0.2.0 PolynomialBatch / FRI; reached in the reference through curta's hash/EdDSA
+ * STARKs -- circuits/builder/header.rs:18, justification.rs:140,156,237 -- and, for the
+ * Plonk side, through every `circuit.prove`, circuits/header_range.rs:167).
+ * trace: n_cols(air) columns of 2^log_n rows, column-major, resident in HBM.
+ * proof_out: caller buffer of proof_cap uint64 words; *proof_len receives the length; returns
+ * VX_ERR_BUFSZ (with *proof_len set) when the buffer is too small.  Proof layout: DESIGN.md. */
+typedef struct vx_stark_config {
+    int32_t rate_bits;       /* 1: blowup 2, constraint degree <= 3 */
+    int32_t cap_height;      /* 4 */
+    int32_t num_queries;     /* 84 */
+    int32_t pow_bits;        /* 16 */
+    int32_t arity_bits;      /* ConstantArityBits(4, 5) */
+    int32_t final_poly_bits;
+} vx_stark_config;
+enum { VX_AIR_FIBONACCI = 1, VX_AIR_MIX = 2 };
+int32_t vx_stark_default_config(vx_stark_config* cfg);
+int32_t vx_stark_prove(vx_ctx* ctx, int air_id, const vx_stark_config* cfg, const vx_buf* trace, int log_n,
+                       const uint64_t* public_inputs, size_t n_public, uint64_t* proof_out, size_t proof_cap,
+                       size_t* proof_len);
+
 /* ---- K8: witness hashing for the header chain
  * (plonky2x curta_blake2b_variable via circuits/builder/header.rs:14-19; SimpleMerkleTree /
  *  sha256 via subchain_verification.rs:213-220, 268-274) */
