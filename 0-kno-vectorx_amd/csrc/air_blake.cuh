@@ -1,0 +1,223 @@
+// BlakeChainAir (AIR id 3): BLAKE2b-256 parent-hash chain over a sequence of encoded headers --
+// the hash-chain core of verify_subchain (/root/reference
+// circuits/builder/subchain_verification.rs:150-177: hash_encoded_header + parent-hash link;
+// circuits/builder/header.rs:14-19 curta_blake2b_variable).  The reference proves Blake2b with
+// curta's byte-lookup STARK (starkyx v1.0.0, not vendored); this AIR is a from-scratch
+// bit-decomposed ARX arithmetisation of RFC 7693, degree <= 3, 16 rows per compression:
+//   r = 0 INIT (out-state = initial work vector), r = 1..12 ROUND (row r holds round r-1's eight
+//   G evaluations), r = 13 FIN1 (T = H ^ v_lo, V' = v_hi), r = 14 FIN2 (H = T ^ V' = h_out),
+//   r = 15 PAD (H = next h_in, digest register D updated).
+// Columns: 8 G x 8 words x 64 bits, 64 carries, 32 message-schedule limbs, 64 range-check bits,
+// H register (512 bits), digest register D (8 limbs), flags and byte counter.
+// Constraint ORDER is protocol: oracle/blake_air.py restates it independently.
+#pragma once
+#include "air.cuh"
+#include "blake_tables.h"
+
+namespace blk {
+constexpr int W_A1 = 0, W_D1 = 1, W_C1 = 2, W_B1 = 3, W_A2 = 4, W_D2 = 5, W_C2 = 6, W_B2 = 7;
+constexpr int CAR0 = 4096, MS0 = 4160, MB0 = 4192, H0 = 4256, D0 = 4768;
+constexpr int ACT = 4776, FIN = 4777, FIRST = 4778, CAP = 4779, T = 4780, INC = 4781, TB0 = 4782, IB0 = 4814, COLS = 4822;
+VX_HD constexpr int GB(int k, int w, int i) { return (k * 8 + w) * 64 + i; }
+VX_HD constexpr int CAR(int k, int j) { return CAR0 + k * 8 + j; }
+VX_HD constexpr int MS(int s, int h) { return MS0 + 2 * s + h; }
+VX_HD constexpr int H(int w, int i) { return H0 + 64 * w + i; }
+// first bit column of out-state word v[w] (the diagonal-step outputs of a row)
+VX_HD constexpr int OUT(int w) {
+    return w < 4 ? GB(4 + w, W_A2, 0)
+         : w < 8 ? GB(4 + ((w & 3) + 3) % 4, W_B2, 0)
+         : w < 12 ? GB(4 + ((w & 3) + 2) % 4, W_C2, 0)
+                  : GB(4 + ((w & 3) + 1) % 4, W_D2, 0);
+}
+static __device__ const uint64_t IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                                         0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+static __device__ const uint8_t ORDER[16][16] = BLK_ORDER_INIT;
+static __device__ const uint8_t MS_SRC[15][16] = BLK_MS_SRC_INIT;
+static __device__ const uint8_t RC_SLOT[16] = BLK_RC_SLOT_INIT;
+}  // namespace blk
+
+struct BlakeAir {
+    static constexpr int ID = 3, COLS = blk::COLS, PUB = 16, PERIODIC = 16, PERIOD_LOG = 4;
+
+    template <class F, class Row, class C>
+    __device__ static void eval(const Row& loc, const Row& nxt, const F* sel, const F* pub, C& c) {
+        using namespace blk;
+        const F one = F::from(1), two = F::from(2), two32 = F::from(1ULL << 32);
+        F g_on = sel[0];
+        for (int r = 1; r < 12; ++r) g_on = g_on + sel[r];
+        auto at = [&](int which, int col) -> F { return which ? nxt[col] : loc[col]; };
+        auto xorf = [&](F x, F y) -> F { return x + y - two * (x * y); };
+        auto limb = [&](int which, int col0, int h) -> F {
+            F acc = at(which, col0 + 32 * h + 31);
+#pragma unroll 1
+            for (int i = 30; i >= 0; --i) acc = acc + acc + at(which, col0 + 32 * h + i);
+            return acc;
+        };
+        auto boolean = [&](int col) {
+            F x = loc[col];
+            c.constraint(x * (x - one));
+        };
+        // ---- 1. booleans
+#pragma unroll 1
+        for (int col = 0; col < 4096; ++col) boolean(col);
+#pragma unroll 1
+        for (int col = MB0; col < MB0 + 64; ++col) boolean(col);
+#pragma unroll 1
+        for (int col = H0; col < H0 + 512; ++col) boolean(col);
+#pragma unroll 1
+        for (int col = TB0; col < TB0 + 32; ++col) boolean(col);
+#pragma unroll 1
+        for (int col = IB0; col < IB0 + 8; ++col) boolean(col);
+        boolean(ACT);
+        boolean(FIN);
+        boolean(FIRST);
+        boolean(CAP);
+        // ---- 2. carries
+#pragma unroll 1
+        for (int k = 0; k < 8; ++k)
+#pragma unroll 1
+            for (int j = 0; j < 8; ++j) {
+                F x = loc[CAR(k, j)];
+                if ((j & 2) == 0) c.constraint(x * (x - one) * (x - two));
+                else c.constraint(x * (x - one));
+            }
+        // ---- 3. the eight G functions of the round held in the next row
+#pragma unroll 1
+        for (int k = 0; k < 8; ++k) {
+            int wa, ca, wb, cb, wc, cc, wd, cd, xs, ys;  // (row selector, first bit column) of the inputs
+            if (k < 4) {
+                wa = wb = wc = wd = 0;
+                ca = OUT(k), cb = OUT(4 + k), cc = OUT(8 + k), cd = OUT(12 + k);
+                xs = 2 * k, ys = 2 * k + 1;
+            } else {
+                const int j = k - 4;
+                wa = wb = wc = wd = 1;
+                ca = GB(j, W_A2, 0), cb = GB((j + 1) % 4, W_B2, 0), cc = GB((j + 2) % 4, W_C2, 0), cd = GB((j + 3) % 4, W_D2, 0);
+                xs = 8 + 2 * j, ys = 8 + 2 * j + 1;
+            }
+            auto add3 = [&](int w1, int c1, int w2, int c2, int msg_slot, int res_slot, int car_j) {
+                F cin = F::from(0);
+#pragma unroll 1
+                for (int h = 0; h < 2; ++h) {
+                    F lhs = limb(w1, c1, h) + limb(w2, c2, h);
+                    if (msg_slot >= 0) lhs = lhs + nxt[MS(msg_slot, h)];
+                    if (h) lhs = lhs + cin;
+                    F car = nxt[CAR(k, car_j + h)];
+                    c.constraint(g_on * (lhs - limb(1, GB(k, res_slot, 0), h) - two32 * car));
+                    cin = car;
+                }
+            };
+            auto xorrot = [&](int w1, int c1, int w2, int c2, int res_slot, int rot) {
+#pragma unroll 1
+                for (int i = 0; i < 64; ++i) {
+                    const int s = (i + rot) & 63;
+                    c.constraint(g_on * (nxt[GB(k, res_slot, i)] - xorf(at(w1, c1 + s), at(w2, c2 + s))));
+                }
+            };
+            add3(wa, ca, wb, cb, xs, W_A1, 0);
+            xorrot(wd, cd, 1, GB(k, W_A1, 0), W_D1, 32);
+            add3(wc, cc, 1, GB(k, W_D1, 0), -1, W_C1, 2);
+            xorrot(wb, cb, 1, GB(k, W_C1, 0), W_B1, 24);
+            add3(1, GB(k, W_A1, 0), 1, GB(k, W_B1, 0), ys, W_A2, 4);
+            xorrot(1, GB(k, W_D1, 0), 1, GB(k, W_A2, 0), W_D2, 16);
+            add3(1, GB(k, W_C1, 0), 1, GB(k, W_D2, 0), -1, W_C2, 6);
+            xorrot(1, GB(k, W_B1, 0), 1, GB(k, W_C2, 0), W_B2, 63);
+        }
+        // ---- 4. INIT row
+        const F fin = loc[FIN];
+#pragma unroll 1
+        for (int wd = 0; wd < 16; ++wd) {
+            const int col0 = OUT(wd);
+#pragma unroll 1
+            for (int i = 0; i < 64; ++i) {
+                F cell = loc[col0 + i], want;
+                if (wd < 8) want = loc[H(wd, i)];
+                else {
+                    const int bit = (int)((IV[wd - 8] >> i) & 1);
+                    if (wd == 12 && i < 32) want = bit ? one - loc[TB0 + i] : loc[TB0 + i];
+                    else if (wd == 14) want = bit ? one - fin : fin;
+                    else want = F::from((uint64_t)bit);
+                }
+                c.constraint(sel[0] * (cell - want));
+            }
+        }
+        // ---- 5. finalisation
+        F keep_h = sel[15];
+        for (int r = 0; r < 13; ++r) keep_h = keep_h + sel[r];
+#pragma unroll 1
+        for (int wd = 0; wd < 8; ++wd) {
+            const int lo0 = OUT(wd), hi0 = OUT(8 + wd), t0 = GB(wd % 4, wd / 4, 0), v0 = GB(wd % 4, 2 + wd / 4, 0);
+            const uint64_t ivp = wd == 0 ? (IV[0] ^ 0x01010020ULL) : IV[wd];
+#pragma unroll 1
+            for (int i = 0; i < 64; ++i) {
+                const F h = loc[H(wd, i)], hn = nxt[H(wd, i)];
+                c.constraint(sel[12] * (nxt[t0 + i] - xorf(h, loc[lo0 + i])));
+                c.constraint(sel[12] * (nxt[v0 + i] - loc[hi0 + i]));
+                c.constraint(sel[13] * (hn - xorf(loc[t0 + i], loc[v0 + i])));
+                const F ib = F::from((ivp >> i) & 1);
+                c.constraint(sel[14] * (hn - (fin * ib + (one - fin) * h)));
+                c.constraint(keep_h * (hn - h));
+            }
+        }
+        // ---- 6. message schedule, range check, link
+#pragma unroll 1
+        for (int s = 0; s < 16; ++s)
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                const F n_ = nxt[MS(s, h)];
+                F acc = sel[0] * (n_ - loc[MS(MS_SRC[0][s], h)]);
+#pragma unroll 1
+                for (int r = 1; r < 15; ++r) acc = acc + sel[r] * (n_ - loc[MS(MS_SRC[r][s], h)]);
+                c.constraint(acc);
+            }
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            F acc = sel[0] * loc[MS(RC_SLOT[0], h)];
+#pragma unroll 1
+            for (int r = 1; r < 16; ++r) acc = acc + sel[r] * loc[MS(RC_SLOT[r], h)];
+            c.constraint(acc - limb(0, MB0, h));
+        }
+        const F first = loc[FIRST];
+#pragma unroll 1
+        for (int s = 0; s < 4; ++s)
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) c.constraint(sel[0] * first * (loc[MS(s, h)] - loc[D0 + 2 * s + h]));
+        // ---- 7. per-block registers
+        const F in_block = one - sel[15];
+        {
+            const int regs[6] = {ACT, FIN, FIRST, CAP, T, INC};
+#pragma unroll 1
+            for (int q = 0; q < 6; ++q) c.constraint(in_block * (nxt[regs[q]] - loc[regs[q]]));
+        }
+        c.constraint(loc[CAP] - loc[ACT] * fin);
+        c.constraint(sel[15] * (nxt[FIRST] - fin));
+        c.constraint(sel[15] * (nxt[T] - (one - fin) * loc[T] - nxt[INC]));
+        {
+            F tb = loc[TB0 + 31];
+#pragma unroll 1
+            for (int i = 30; i >= 0; --i) tb = tb + tb + loc[TB0 + i];
+            c.constraint(loc[T] - tb);
+            F ib = loc[IB0 + 7];
+#pragma unroll 1
+            for (int i = 6; i >= 0; --i) ib = ib + ib + loc[IB0 + i];
+            c.constraint(loc[INC] - ib);
+            const F c128 = F::from(128);
+            c.constraint(loc[IB0 + 7] * (loc[INC] - c128));
+            c.constraint((one - fin) * (loc[INC] - c128));
+        }
+        // ---- 8. digest register
+        const F cap = loc[CAP];
+#pragma unroll 1
+        for (int j = 0; j < 8; ++j) {
+            const F d = loc[D0 + j], dn = nxt[D0 + j];
+            c.transition((one - sel[14]) * (dn - d));
+            c.constraint(sel[14] * (dn - (cap * limb(0, H(j / 2, 0), j % 2) + (one - cap) * d)));
+        }
+        // ---- 9. boundary
+#pragma unroll 1
+        for (int j = 0; j < 8; ++j) c.first_row(loc[D0 + j] - pub[j]);
+#pragma unroll 1
+        for (int j = 0; j < 8; ++j) c.last_row(loc[D0 + j] - pub[8 + j]);
+        c.last_row(fin - one);
+    }
+};

@@ -1,0 +1,267 @@
+// K8: witness/trace generation for BlakeChainAir on the GPU, and the header_range prove entry.
+//   kernel A  k_blake_chain: one lane per header -- digest + the chaining value before every
+//             128-byte chunk (the only sequential part of BLAKE2b);
+//   kernel B  k_blake_trace: one lane per TRACE ROW (block b, r = row mod 16): recomputes
+//             the <= 12 rounds it needs from the chunk's chaining value and writes its 4822
+//             cells; lanes of a wave write 64 consecutive rows of a column, so every store
+//             instruction is a coalesced 512-byte segment of the column-major trace.
+// Replaces the curta Blake2b witness generation behind hash_encoded_header
+// (/root/reference circuits/builder/header.rs:14-19) for the synthetic header chain.
+#include <string.h>
+
+#include "air_blake.cuh"
+#include "vx_internal.h"
+
+struct BlockDesc {
+    uint64_t msg_off;  // byte offset of the 128-byte chunk in the headers buffer; ~0 = padding block
+    uint32_t t, inc;
+    uint32_t D[8];     // digest register before this block
+    uint8_t fin, first, act, pad;
+    uint32_t pad2;
+};
+
+__device__ __forceinline__ uint64_t b_rotr(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+
+struct GRec {
+    uint64_t w[8];  // a1 d1 c1 b1 a2 d2 c2 b2
+    uint8_t car[8];
+};
+__device__ __forceinline__ void carries(uint64_t o1, uint64_t o2, uint64_t o3, uint8_t* out) {
+    uint64_t lo = (o1 & 0xFFFFFFFFULL) + (o2 & 0xFFFFFFFFULL) + (o3 & 0xFFFFFFFFULL);
+    uint64_t klo = lo >> 32;
+    uint64_t hi = (o1 >> 32) + (o2 >> 32) + (o3 >> 32) + klo;
+    out[0] = (uint8_t)klo;
+    out[1] = (uint8_t)(hi >> 32);
+}
+__device__ __forceinline__ void g_mix(uint64_t* v, int ia, int ib, int ic, int id, uint64_t x, uint64_t y, GRec* rec) {
+    uint64_t a = v[ia], b = v[ib], c = v[ic], d = v[id];
+    uint64_t a1 = a + b + x, d1 = b_rotr(d ^ a1, 32), c1 = c + d1, b1 = b_rotr(b ^ c1, 24);
+    uint64_t a2 = a1 + b1 + y, d2 = b_rotr(d1 ^ a2, 16), c2 = c1 + d2, b2 = b_rotr(b1 ^ c2, 63);
+    if (rec) {
+        rec->w[0] = a1, rec->w[1] = d1, rec->w[2] = c1, rec->w[3] = b1, rec->w[4] = a2, rec->w[5] = d2, rec->w[6] = c2, rec->w[7] = b2;
+        carries(a, b, x, rec->car);
+        carries(c, d1, 0, rec->car + 2);
+        carries(a1, b1, y, rec->car + 4);
+        carries(c1, d2, 0, rec->car + 6);
+    }
+    v[ia] = a2, v[ib] = b2, v[ic] = c2, v[id] = d2;
+}
+__device__ void blake_round(uint64_t* v, const uint64_t* m, int round, GRec* rec) {
+    const uint8_t* s = blk::ORDER[round + 1];  // ORDER[r] for r = 1..12 is sigma[r-1]
+    for (int k = 0; k < 4; ++k) g_mix(v, k, 4 + k, 8 + k, 12 + k, m[s[2 * k]], m[s[2 * k + 1]], rec ? rec + k : nullptr);
+    for (int j = 0; j < 4; ++j)
+        g_mix(v, j, 4 + (j + 1) % 4, 8 + (j + 2) % 4, 12 + (j + 3) % 4, m[s[8 + 2 * j]], m[s[8 + 2 * j + 1]], rec ? rec + 4 + j : nullptr);
+}
+__device__ void blake_init_v(uint64_t* v, const uint64_t* h, uint64_t t, bool fin) {
+    for (int i = 0; i < 8; ++i) v[i] = h[i], v[8 + i] = blk::IV[i];
+    v[12] ^= t;
+    if (fin) v[14] = ~v[14];
+}
+
+// one lane per header: digest and the chaining value in front of each chunk
+__global__ __launch_bounds__(64) void k_blake_chain(const uint8_t* msgs, size_t stride, const uint32_t* sizes, size_t n,
+                                                    const uint32_t* block_base, uint64_t* hchain, uint8_t* digests) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t* p = (const uint64_t*)(msgs + i * stride);
+    const uint32_t len = sizes[i];
+    const uint32_t nchunks = len == 0 ? 1 : (len + 127) / 128;
+    uint64_t h[8], m[16], v[16];
+    for (int k = 0; k < 8; ++k) h[k] = blk::IV[k];
+    h[0] ^= 0x01010020ULL;
+    for (uint32_t cidx = 0; cidx < nchunks; ++cidx) {
+        uint64_t* hc = hchain + 8 * ((size_t)block_base[i] + cidx);
+        for (int k = 0; k < 8; ++k) hc[k] = h[k];
+        const bool fin = cidx + 1 == nchunks;
+        const uint32_t off = 128 * cidx, rem = fin ? len - off : 128;
+        for (int k = 0; k < 16; ++k) {
+            uint32_t b = 8 * k;
+            uint64_t w = 0;
+            if (b < rem) {
+                w = p[(off >> 3) + k];
+                if (rem - b < 8) w &= (1ULL << (8 * (rem - b))) - 1;
+            }
+            m[k] = w;
+        }
+        blake_init_v(v, h, fin ? len : off + 128, fin);
+        for (int r = 0; r < 12; ++r) blake_round(v, m, r, nullptr);
+        for (int k = 0; k < 8; ++k) h[k] ^= v[k] ^ v[k + 8];
+    }
+    uint64_t* d = (uint64_t*)(digests + 32 * i);
+    d[0] = h[0], d[1] = h[1], d[2] = h[2], d[3] = h[3];
+}
+
+__device__ __forceinline__ void put_bits(uint64_t* tr, size_t n, size_t row, int col0, uint64_t val, int nbits = 64) {
+    for (int i = 0; i < nbits; ++i) tr[(size_t)(col0 + i) * n + row] = (val >> i) & 1;
+}
+
+// one lane per trace row
+__global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const BlockDesc* descs, const uint64_t* hchain, size_t n_real,
+                                                     uint64_t* tr, size_t n) {
+    using namespace blk;
+    const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const size_t b = row >> 4;
+    const int r = (int)(row & 15);
+    const BlockDesc d = descs[b];
+    uint64_t h[8], m[16], v[16];
+    if (b < n_real) {
+        for (int k = 0; k < 8; ++k) h[k] = hchain[8 * b + k];
+        const uint64_t* p = (const uint64_t*)(msgs + d.msg_off);
+        for (int k = 0; k < 16; ++k) {
+            uint32_t bb = 8 * k;
+            uint64_t w = 0;
+            if (bb < d.inc) {
+                w = p[k];
+                if (d.inc - bb < 8) w &= (1ULL << (8 * (d.inc - bb))) - 1;
+            }
+            m[k] = w;
+        }
+    } else {  // padding block: the 32-byte message D
+        for (int k = 0; k < 8; ++k) h[k] = IV[k];
+        h[0] ^= 0x01010020ULL;
+        for (int k = 0; k < 16; ++k) m[k] = k < 4 ? ((uint64_t)d.D[2 * k] | ((uint64_t)d.D[2 * k + 1] << 32)) : 0;
+    }
+    // ---- G area (columns 0 .. 4159): zero unless this row uses it
+    GRec rec[8];
+    bool have_rec = false;
+    uint64_t vfin[16];
+    blake_init_v(v, h, d.t, d.fin);
+    uint64_t v0[16];
+    for (int k = 0; k < 16; ++k) v0[k] = v[k];
+    if (r >= 1) {
+        const int last = r <= 12 ? r - 1 : 11;  // rounds 0 .. last
+        for (int q = 0; q <= last; ++q) blake_round(v, m, q, q == last && r <= 12 ? rec : nullptr);
+        have_rec = r <= 12;
+        for (int k = 0; k < 16; ++k) vfin[k] = v[k];
+    }
+    uint64_t h_out[8];
+    if (r >= 13)
+        for (int k = 0; k < 8; ++k) h_out[k] = h[k] ^ vfin[k] ^ vfin[k + 8];
+    if (have_rec) {
+        for (int k = 0; k < 8; ++k) {
+            for (int w = 0; w < 8; ++w) put_bits(tr, n, row, GB(k, w, 0), rec[k].w[w]);
+            for (int j = 0; j < 8; ++j) tr[(size_t)CAR(k, j) * n + row] = rec[k].car[j];
+        }
+    } else {
+        for (int col = 0; col < 4160; ++col) tr[(size_t)col * n + row] = 0;
+        if (r == 0) {
+            for (int w = 0; w < 16; ++w) put_bits(tr, n, row, OUT(w), v0[w]);
+        } else if (r == 13) {
+            for (int w = 0; w < 8; ++w) {
+                put_bits(tr, n, row, GB(w % 4, w / 4, 0), h[w] ^ vfin[w]);
+                put_bits(tr, n, row, GB(w % 4, 2 + w / 4, 0), vfin[8 + w]);
+            }
+        }
+    }
+    // ---- message schedule + range check of natural word r
+    for (int s = 0; s < 16; ++s) {
+        const uint64_t w = m[ORDER[r][s]];
+        tr[(size_t)MS(s, 0) * n + row] = w & 0xFFFFFFFFULL;
+        tr[(size_t)MS(s, 1) * n + row] = w >> 32;
+    }
+    put_bits(tr, n, row, MB0, m[r]);
+    // ---- H register
+    for (int w = 0; w < 8; ++w) {
+        uint64_t hv = r <= 13 ? h[w] : (r == 14 ? h_out[w] : (d.fin ? (w == 0 ? IV[0] ^ 0x01010020ULL : IV[w]) : h_out[w]));
+        put_bits(tr, n, row, H(w, 0), hv);
+    }
+    // ---- digest register, flags, counters
+    const bool cap = d.act && d.fin;
+    for (int j = 0; j < 8; ++j) {
+        uint32_t dv = d.D[j];
+        if (r == 15 && cap) dv = (uint32_t)(h_out[j / 2] >> (32 * (j & 1)));
+        tr[(size_t)(D0 + j) * n + row] = dv;
+    }
+    tr[(size_t)ACT * n + row] = d.act;
+    tr[(size_t)FIN * n + row] = d.fin;
+    tr[(size_t)FIRST * n + row] = d.first;
+    tr[(size_t)CAP * n + row] = cap ? 1 : 0;
+    tr[(size_t)T * n + row] = d.t;
+    tr[(size_t)INC * n + row] = d.inc;
+    put_bits(tr, n, row, TB0, d.t, 32);
+    put_bits(tr, n, row, IB0, d.inc, 8);
+}
+
+extern "C" {
+
+int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_headers,
+                             const uint8_t trusted_hash[32], int log_n, vx_buf* trace_out, uint64_t public_inputs_out[16],
+                             uint8_t* digests_out) {
+    if (!ctx || !headers || !sizes || !trusted_hash || !trace_out || !public_inputs_out) return VX_ERR_ARG;
+    VX_CHECK(stride % 128 == 0 && stride > 0, "blake trace: stride %zu must be a positive multiple of 128", stride);
+    VX_CHECK(n_headers >= 1 && n_headers * stride <= headers->n * 8, "blake trace: headers exceed the buffer");
+    VX_CHECK(log_n >= 4 && log_n <= 24, "blake trace: log_n %d out of range", log_n);
+    const size_t n = (size_t)1 << log_n, n_blocks = n >> 4;
+    VX_CHECK(trace_out->n >= n * blk::COLS, "blake trace: trace buffer holds %zu < %zu elements", trace_out->n, n * (size_t)blk::COLS);
+    std::vector<uint32_t> base(n_headers);
+    size_t n_real = 0;
+    for (size_t i = 0; i < n_headers; ++i) {
+        VX_CHECK(sizes[i] <= stride && sizes[i] >= 32, "blake trace: header %zu has size %u", i, sizes[i]);
+        base[i] = (uint32_t)n_real;
+        n_real += (sizes[i] + 127) / 128;
+    }
+    VX_CHECK(n_real <= n_blocks, "blake trace: %zu compressions do not fit 2^%d rows (%zu blocks)", n_real, log_n, n_blocks);
+    // device scratch: sizes | block_base | digests | hchain | descs
+    const size_t w_sizes = (n_headers * 4 + 7) / 8, w_dig = n_headers * 4, w_hc = n_real * 8;
+    const size_t w_desc = (n_blocks * sizeof(BlockDesc) + 7) / 8;
+    uint64_t* sc;
+    VX_TRY(vx_scratch(ctx, 2 * w_sizes + w_dig + w_hc + w_desc, &sc));
+    uint32_t* d_sizes = (uint32_t*)sc;
+    uint32_t* d_base = (uint32_t*)(sc + w_sizes);
+    uint8_t* d_dig = (uint8_t*)(sc + 2 * w_sizes);
+    uint64_t* d_hc = sc + 2 * w_sizes + w_dig;
+    BlockDesc* d_desc = (BlockDesc*)(d_hc + w_hc);
+    VX_HIP(hipMemcpyAsync(d_sizes, sizes, n_headers * 4, hipMemcpyHostToDevice, ctx->stream));
+    VX_HIP(hipMemcpyAsync(d_base, base.data(), n_headers * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_blake_chain, dim3((unsigned)((n_headers + 63) / 64)), dim3(64), 0, ctx->stream, (const uint8_t*)headers->d,
+                       stride, (const uint32_t*)d_sizes, n_headers, (const uint32_t*)d_base, d_hc, d_dig);
+    VX_HIP(hipGetLastError());
+    std::vector<uint8_t> dig(32 * n_headers);
+    VX_HIP(hipMemcpyAsync(dig.data(), d_dig, dig.size(), hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipStreamSynchronize(ctx->stream));
+    // block descriptors (host): the link rule is checked here too, so a broken chain fails loudly
+    std::vector<BlockDesc> descs(n_blocks);
+    uint8_t D[32];
+    memcpy(D, trusted_hash, 32);
+    size_t bi = 0;
+    for (size_t i = 0; i < n_headers; ++i) {
+        const uint32_t nch = (sizes[i] + 127) / 128;
+        for (uint32_t cidx = 0; cidx < nch; ++cidx, ++bi) {
+            BlockDesc& d = descs[bi];
+            memset(&d, 0, sizeof d);
+            d.fin = cidx + 1 == nch;
+            d.first = cidx == 0;
+            d.act = 1;
+            d.inc = d.fin ? sizes[i] - 128 * cidx : 128;
+            d.t = d.fin ? sizes[i] : 128 * (cidx + 1);
+            d.msg_off = i * stride + 128 * (size_t)cidx;
+            memcpy(d.D, D, 32);
+        }
+        memcpy(D, dig.data() + 32 * i, 32);
+    }
+    for (; bi < n_blocks; ++bi) {
+        BlockDesc& d = descs[bi];
+        memset(&d, 0, sizeof d);
+        d.fin = d.first = 1;
+        d.act = 0;
+        d.inc = d.t = 32;
+        d.msg_off = ~0ULL;
+        memcpy(d.D, D, 32);
+    }
+    VX_HIP(hipMemcpyAsync(d_desc, descs.data(), n_blocks * sizeof(BlockDesc), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_blake_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t*)headers->d,
+                       (const BlockDesc*)d_desc, (const uint64_t*)d_hc, n_real, trace_out->d, n);
+    VX_HIP(hipGetLastError());
+    VX_HIP(hipStreamSynchronize(ctx->stream));  // descs must outlive the kernel
+    for (int j = 0; j < 8; ++j) {
+        uint32_t a, b;
+        memcpy(&a, trusted_hash + 4 * j, 4);
+        memcpy(&b, D + 4 * j, 4);
+        public_inputs_out[j] = a;
+        public_inputs_out[8 + j] = b;
+    }
+    if (digests_out) memcpy(digests_out, dig.data(), dig.size());
+    return VX_OK;
+}
+}

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include "air.cuh"
+#include "air_blake.cuh"
 #include "poseidon_constants.h"
 #include "vx_internal.h"
 
@@ -230,7 +231,12 @@ static void launch_q(QuotArgs& a, hipStream_t s) {
 }
 static void no_periodic(std::vector<uint64_t>& v) { v.clear(); }
 static void mix_periodic(std::vector<uint64_t>& v) { v = {0, 0, 0, 1, 3, 5, 7, 11}; }
+static void blake_periodic(std::vector<uint64_t>& v) {
+    v.assign(16 * 16, 0);
+    for (int k = 0; k < 16; ++k) v[k * 16 + k] = 1;  // sel_k: one-hot on row k of every 16-row block
+}
 static const AirDesc AIRS[] = {
+    {BlakeAir::ID, BlakeAir::COLS, BlakeAir::PUB, BlakeAir::PERIODIC, BlakeAir::PERIOD_LOG, blake_periodic, launch_q<BlakeAir>},
     {FibAir::ID, FibAir::COLS, FibAir::PUB, FibAir::PERIODIC, FibAir::PERIOD_LOG, no_periodic, launch_q<FibAir>},
     {MixAir::ID, MixAir::COLS, MixAir::PUB, MixAir::PERIODIC, MixAir::PERIOD_LOG, mix_periodic, launch_q<MixAir>},
 };

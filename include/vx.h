@@ -174,6 +174,18 @@ int32_t vx_blake2b_256_batch(vx_ctx* ctx, const vx_buf* msgs, size_t stride, con
 /* 64-byte -> 32-byte SHA-256 of n pairs (host in/out; device compute) */
 int32_t vx_sha256_pairs(vx_ctx* ctx, const uint8_t* pairs64, size_t n, uint8_t* out32);
 
+/* ---- K8: BlakeChainAir trace generation (the Blake2b witness behind hash_encoded_header,
+ * circuits/builder/header.rs:14-19, and the parent-hash links of
+ * circuits/builder/subchain_verification.rs:163-177).  headers as for vx_verify_subchain (stride a
+ * multiple of 128).  Writes the column-major trace (4822 columns x 2^log_n rows, 16 rows per
+ * compression, padded with inactive blocks) into trace_out, the 16 public inputs
+ * (trusted hash, target hash as 32-bit little-endian limbs) and optionally the digests (host).
+ * Prove it with vx_stark_prove(ctx, VX_AIR_BLAKE_CHAIN, ...). */
+enum { VX_AIR_BLAKE_CHAIN = 3, VX_BLAKE_AIR_COLS = 4822 };
+int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_headers,
+                             const uint8_t trusted_hash[32], int log_n, vx_buf* trace_out, uint64_t public_inputs_out[16],
+                             uint8_t* digests_out);
+
 /* ---- statement level: verify_subchain (circuits/builder/subchain_verification.rs:56-303)
  * headers: n_fetched encoded headers (blocks trusted+1 .. target) resident in HBM at `stride`
  * bytes each (zero padded), sizes on the host.  max_headers = 256 / 512

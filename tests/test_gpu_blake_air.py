@@ -1,0 +1,80 @@
+"""BlakeChainAir on the GPU: trace == the oracle's restatement cell by cell, proof bytes == the
+coefficient-space reference prover, and the reference verifier accepts / rejects."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import blake_air as B
+from oracle import stark_ref as S
+
+pytestmark = pytest.mark.gpu
+S.register_air(B.BlakeChainAir)
+
+
+def chain_msgs(ch):
+    return [ch.headers[i, : ch.sizes[i]].tobytes() for i in range(ch.n)]
+
+
+@pytest.mark.parametrize("n_headers,log_n", [(1, 6), (2, 7), (5, 9)])
+def test_trace_matches_oracle(ctx, vx, n_headers, log_n):
+    ch = vx.synth.Chain(n_headers, profile="Ptiny", stride=512)
+    buf, pub, dig = ctx.blake_chain_trace(ctx.from_host(ch.headers), 512, ch.sizes, ch.trusted_hash, log_n)
+    want, wpub, target = B.gen_trace(chain_msgs(ch), log_n, ch.trusted_hash)
+    got = buf.download().reshape(B.COLS, 1 << log_n)
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, f"first differing cells (col,row): {bad[:5].tolist()}"
+    assert [int(x) for x in pub] == wpub and target == ch.target_hash
+    assert [d.tobytes() for d in dig] == ch.hashes == [hashlib.blake2b(m, digest_size=32).digest() for m in chain_msgs(ch)]
+
+
+def test_edge_sizes_trace(ctx, vx):
+    """Chunk-boundary lengths: 128 (one full final chunk), 129, 255, 256, 257 and the 32-byte minimum."""
+    trusted = hashlib.sha256(b"edge").digest()
+    msgs, d = [], trusted
+    for n in (128, 129, 255, 256, 257, 32, 33):
+        m = d + bytes((7 * i + n) & 0xFF for i in range(n - 32))
+        msgs.append(m)
+        d = hashlib.blake2b(m, digest_size=32).digest()
+    hdr = np.zeros((len(msgs), 384), dtype=np.uint8)
+    for i, m in enumerate(msgs):
+        hdr[i, : len(m)] = np.frombuffer(m, dtype=np.uint8)
+    sizes = [len(m) for m in msgs]
+    buf, pub, dig = ctx.blake_chain_trace(ctx.from_host(hdr), 384, sizes, trusted, 8)
+    want, wpub, target = B.gen_trace(msgs, 8, trusted)
+    assert (buf.download().reshape(B.COLS, 256) == want).all() and dig[-1].tobytes() == d == target
+
+
+def test_proof_bytes_and_verification(ctx, vx, oracle):
+    ch = vx.synth.Chain(2, profile="Ptiny", stride=512)
+    log_n = 7
+    buf, pub, _ = ctx.blake_chain_trace(ctx.from_host(ch.headers), 512, ch.sizes, ch.trusted_hash, log_n)
+    got = ctx.stark_prove(B.ID, buf, log_n, pub)
+    trace, wpub, _ = B.gen_trace(chain_msgs(ch), log_n, ch.trusted_hash)
+    want = S.prove(B.BlakeChainAir, trace, wpub)
+    assert got.size == want.size and (got == want).all()
+    S.verify(got, expect_air=B.ID, expect_public=wpub)
+
+
+def test_larger_chain_verifies_and_forgeries_fail(ctx, vx, oracle):
+    ch = vx.synth.Chain(16, profile="Ptiny", stride=512)
+    log_n = 10
+    hb = ctx.from_host(ch.headers)
+    buf, pub, _ = ctx.blake_chain_trace(hb, 512, ch.sizes, ch.trusted_hash, log_n)
+    proof = ctx.stark_prove(B.ID, buf, log_n, pub, ctx.stark_config(num_queries=20))
+    cfg = dict(S.DEFAULT_CFG, num_queries=20)
+    info = S.verify(proof, cfg, expect_air=B.ID)
+    limbs = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "little") for j in range(8)]  # noqa: E731
+    assert info["public_inputs"] == limbs(ch.trusted_hash) + limbs(ch.target_hash)
+    # a trace with one flipped witness bit must not verify
+    tr = buf.download().reshape(B.COLS, 1 << log_n)
+    tr[B.GB(3, 2, 5), 100] ^= np.uint64(1)
+    bad = ctx.stark_prove(B.ID, ctx.from_host(tr), log_n, pub, ctx.stark_config(num_queries=20))
+    with pytest.raises(S.VerifyError):
+        S.verify(bad, cfg)
+    # claiming a different target hash must not verify
+    pub2 = pub.copy()
+    pub2[9] ^= np.uint64(1)
+    bad = ctx.stark_prove(B.ID, buf, log_n, pub2, ctx.stark_config(num_queries=20))
+    with pytest.raises(S.VerifyError):
+        S.verify(bad, cfg)
