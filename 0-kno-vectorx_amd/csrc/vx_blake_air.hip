@@ -264,4 +264,55 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
     if (digests_out) memcpy(digests_out, dig.data(), dig.size());
     return VX_OK;
 }
+
+static const uint64_t VX_HR_MAGIC = 0x3145474e41525248ULL;  // "HRRANGE1"
+
+int32_t vx_header_range_proof_bound(const vx_stark_config* cfg, size_t n_chunks, size_t* n_words) {
+    if (!cfg || !n_words || n_chunks == 0) return VX_ERR_ARG;
+    int log_n = 4;
+    while (((size_t)16 << (log_n - 4)) < 16 * n_chunks) ++log_n;
+    size_t w = 0;
+    int32_t rc = vx_stark_proof_bound(VX_AIR_BLAKE_CHAIN, cfg, log_n, &w);
+    *n_words = w + 16;
+    return rc;
+}
+
+int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_fetched,
+                              uint32_t max_headers, uint32_t trusted_block, const uint8_t trusted_hash[32], uint32_t target_block,
+                              const vx_stark_config* cfg, uint8_t out96[96], uint64_t* proof_out, size_t proof_cap,
+                              size_t* proof_len) {
+    if (!ctx || !cfg || !proof_len || !out96) return VX_ERR_ARG;
+    // 1. statement + public outputs (map/reduce chain rules, Merkle roots)
+    VX_TRY(vx_verify_subchain(ctx, headers, stride, sizes, n_fetched, max_headers, trusted_block, trusted_hash, target_block, out96));
+    // 2. Blake2b parent-hash-chain STARK over every compression of every header
+    size_t chunks = 0;
+    for (size_t i = 0; i < n_fetched; ++i) chunks += (sizes[i] + 127) / 128;
+    int log_n = 4;
+    while (((size_t)1 << log_n) < 16 * chunks) ++log_n;
+    vx_buf* trace = nullptr;
+    VX_TRY(vx_alloc(ctx, ((size_t)blk::COLS) << log_n, &trace));
+    uint64_t pub[16];
+    int32_t rc = vx_blake_chain_trace(ctx, headers, stride, sizes, n_fetched, trusted_hash, log_n, trace, pub, nullptr);
+    size_t plen = 0;
+    if (rc == VX_OK) {
+        uint8_t tgt[32];
+        for (int j = 0; j < 8; ++j) {
+            uint32_t l = (uint32_t)pub[8 + j];
+            memcpy(tgt + 4 * j, &l, 4);
+        }
+        if (memcmp(tgt, out96, 32) != 0) rc = vx_fail(ctx, VX_ERR_STATEMENT, "header_range: chain digest differs from the subchain target hash");
+    }
+    if (rc == VX_OK)
+        rc = vx_stark_prove(ctx, VX_AIR_BLAKE_CHAIN, cfg, trace, log_n, pub, 16, proof_out && proof_cap > 16 ? proof_out + 16 : nullptr,
+                            proof_cap > 16 ? proof_cap - 16 : 0, &plen);
+    (void)vx_free(ctx, trace);
+    *proof_len = plen + 16;
+    if (rc != VX_OK) return rc;
+    proof_out[0] = VX_HR_MAGIC;
+    proof_out[1] = max_headers;
+    proof_out[2] = trusted_block;
+    proof_out[3] = target_block;
+    memcpy(proof_out + 4, out96, 96);
+    return VX_OK;
+}
 }

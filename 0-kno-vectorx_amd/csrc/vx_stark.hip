@@ -321,6 +321,22 @@ int32_t vx_stark_default_config(vx_stark_config* cfg) {
     return VX_OK;
 }
 
+int32_t vx_stark_proof_bound(int air_id, const vx_stark_config* cfg, int log_n, size_t* n_words) {
+    const AirDesc* air = find_air(air_id);
+    if (!air || !cfg || !n_words || log_n < 2 || cfg->rate_bits < 1) return VX_ERR_ARG;
+    const size_t c = air->cols, nq = 4, LN = log_n + cfg->rate_bits, cap = (size_t)4 << cfg->cap_height;
+    const std::vector<int> ar = fri_arity_plan(log_n, *cfg);
+    size_t per_query = c + nq + 2 * 4 * LN, words = 16 + ar.size() + air->pub + 2 * cap + 2 * (2 * c + nq) + ar.size() * cap + 1;
+    size_t cur = LN;
+    for (int a : ar) {
+        per_query += 2 * (((size_t)1 << a) - 1) + 4 * cur;
+        cur -= a;
+    }
+    words += 2 * (((size_t)1 << cur) >> cfg->rate_bits) + cfg->num_queries * per_query;
+    *n_words = words;
+    return VX_OK;
+}
+
 int32_t vx_stark_prove(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_in, const vx_buf* trace, int log_n,
                        const uint64_t* public_inputs, size_t n_public, uint64_t* proof_out, size_t proof_cap,
                        size_t* proof_len) {

@@ -22,7 +22,7 @@ SYMBOLS = [
     "vx_ntt", "vx_lde", "vx_lde_rows",
     "vx_poseidon_permute_batch", "vx_merkle_build", "vx_merkle_free", "vx_merkle_cap", "vx_merkle_open", "vx_merkle_leaf_digests",
     "vx_fri_fold", "vx_fri_layer_tree", "vx_fri_leaves", "vx_fri_pow",
-    "vx_stark_default_config", "vx_stark_prove",
+    "vx_stark_default_config", "vx_stark_proof_bound", "vx_stark_prove", "vx_header_range_proof_bound", "vx_header_range_prove",
     "vx_blake2b_256_batch", "vx_sha256_pairs", "vx_verify_subchain", "vx_blake_chain_trace",
 ]
 
@@ -78,6 +78,9 @@ def load_library():
         "vx_fri_fold": [vp, vp, C.c_int, C.c_int, vp, u64, vp], "vx_fri_layer_tree": [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
         "vx_fri_leaves": [vp, vp, C.c_int, C.c_int, vp, sz, vp], "vx_fri_pow": [vp, vp, C.c_int, C.c_int, C.POINTER(u64)],
         "vx_stark_default_config": [C.POINTER(StarkConfig)],
+        "vx_stark_proof_bound": [C.c_int, C.POINTER(StarkConfig), C.c_int, C.POINTER(sz)],
+        "vx_header_range_proof_bound": [C.POINTER(StarkConfig), sz, C.POINTER(sz)],
+        "vx_header_range_prove": [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.POINTER(StarkConfig), vp, vp, sz, C.POINTER(sz)],
         "vx_stark_prove": [vp, C.c_int, C.POINTER(StarkConfig), vp, C.c_int, vp, sz, vp, sz, C.POINTER(sz)],
         "vx_blake2b_256_batch": [vp, vp, sz, vp, sz, vp], "vx_sha256_pairs": [vp, vp, sz, vp],
         "vx_verify_subchain": [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp],
@@ -272,13 +275,25 @@ class Context:
         cfg = cfg or self.stark_config()
         pub = np.ascontiguousarray(public_inputs, dtype=np.uint64)
         need = C.c_size_t(0)
-        rc = self.L.vx_stark_prove(self.h, air_id, C.byref(cfg), trace_buf.h, log_n, _ptr(pub), pub.size, None, 0, C.byref(need))
-        if rc != -4:
-            self._ck(rc)
-        # the sizing call ran the prover once; the proof is deterministic, so run again into the buffer
+        self._ck(self.L.vx_stark_proof_bound(air_id, C.byref(cfg), log_n, C.byref(need)))
         out = np.empty(need.value, dtype=np.uint64)
         self._ck(self.L.vx_stark_prove(self.h, air_id, C.byref(cfg), trace_buf.h, log_n, _ptr(pub), pub.size, _ptr(out), out.size, C.byref(need)))
         return out[: need.value]
+
+    def header_range_prove(self, headers_buf, stride, sizes, max_headers, trusted_block, trusted_hash, target_block, cfg=None, out=None):
+        """HeaderRangeCircuit::prove for a chain resident in HBM -> (96-byte output, proof blob words)."""
+        cfg = cfg or self.stark_config()
+        sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+        th = np.frombuffer(bytes(trusted_hash), dtype=np.uint8).copy()
+        chunks = int(((sizes.astype(np.int64) + 127) // 128).sum())
+        need = C.c_size_t(0)
+        self._ck(self.L.vx_header_range_proof_bound(C.byref(cfg), chunks, C.byref(need)))
+        if out is None or out.size < need.value:
+            out = np.empty(need.value, dtype=np.uint64)
+        out96 = np.zeros(96, dtype=np.uint8)
+        self._ck(self.L.vx_header_range_prove(self.h, headers_buf.h, stride, _ptr(sizes), sizes.size, max_headers, trusted_block, _ptr(th),
+                                              target_block, C.byref(cfg), _ptr(out96), _ptr(out), out.size, C.byref(need)))
+        return out96.tobytes(), out[: need.value]
 
     # K8 / statement
     def blake2b_256_batch(self, msgs_buf, stride, sizes):

@@ -160,6 +160,8 @@ typedef struct vx_stark_config {
 } vx_stark_config;
 enum { VX_AIR_FIBONACCI = 1, VX_AIR_MIX = 2 };
 int32_t vx_stark_default_config(vx_stark_config* cfg);
+/* upper bound on the proof length (uint64 words) for buffer sizing */
+int32_t vx_stark_proof_bound(int air_id, const vx_stark_config* cfg, int log_n, size_t* n_words);
 int32_t vx_stark_prove(vx_ctx* ctx, int air_id, const vx_stark_config* cfg, const vx_buf* trace, int log_n,
                        const uint64_t* public_inputs, size_t n_public, uint64_t* proof_out, size_t proof_cap,
                        size_t* proof_len);
@@ -196,6 +198,17 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
 int32_t vx_verify_subchain(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes,
                            size_t n_fetched, uint32_t max_headers, uint32_t trusted_block,
                            const uint8_t trusted_hash[32], uint32_t target_block, uint8_t out96[96]);
+
+/* ---- top level: HeaderRangeCircuit::prove (circuits/header_range.rs:26-59 via Circuit::prove, :167).
+ * Inputs as vx_verify_subchain.  Output blob (uint64 words): "HRRANGE1", max_headers, trusted_block,
+ * target_block, the 96 public output bytes (12 words), then the BlakeChainAir STARK proof.
+ * What the blob proves today is listed in DESIGN.md section 2 (the justification / Merkle-root /
+ * numbering gadgets are checked natively by vx_verify_subchain but not yet inside a STARK). */
+int32_t vx_header_range_proof_bound(const vx_stark_config* cfg, size_t n_chunks, size_t* n_words);
+int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_fetched,
+                              uint32_t max_headers, uint32_t trusted_block, const uint8_t trusted_hash[32],
+                              uint32_t target_block, const vx_stark_config* cfg, uint8_t out96[96], uint64_t* proof_out,
+                              size_t proof_cap, size_t* proof_len);
 
 #ifdef __cplusplus
 }

@@ -78,3 +78,22 @@ def test_larger_chain_verifies_and_forgeries_fail(ctx, vx, oracle):
     bad = ctx.stark_prove(B.ID, buf, log_n, pub2, ctx.stark_config(num_queries=20))
     with pytest.raises(S.VerifyError):
         S.verify(bad, cfg)
+
+
+def test_header_range_prove_end_to_end(ctx, vx, oracle):
+    """Top-level entry: public outputs + BlakeChainAir proof in one blob; the reference verifier accepts it."""
+    ch = vx.synth.Chain(16, profile="Ptiny", stride=512)
+    cfg = ctx.stark_config(num_queries=12)
+    out96, blob = ctx.header_range_prove(ctx.from_host(ch.headers), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
+    assert out96 == ch.expected_outputs(16)
+    assert int(blob[0]) == 0x3145474E41525248 and [int(x) for x in blob[1:4]] == [16, ch.trusted_block, ch.target_block]
+    assert blob[4:16].tobytes() == out96
+    info = S.verify(blob[16:], dict(S.DEFAULT_CFG, num_queries=12), expect_air=B.ID)
+    limbs = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "little") for j in range(8)]  # noqa: E731
+    assert info["public_inputs"] == limbs(ch.trusted_hash) + limbs(out96[:32])
+    # a chain that violates the statement never reaches the prover
+    h = ch.headers.copy()
+    h[5, 3] ^= 1
+    with pytest.raises(vx.VxError) as e:
+        ctx.header_range_prove(ctx.from_host(h), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
+    assert e.value.code == -5
