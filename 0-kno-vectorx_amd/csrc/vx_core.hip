@@ -43,15 +43,51 @@ int32_t vx_get_shift_tab(vx_ctx* ctx, uint64_t base, PowTab* out) {
     return VX_OK;
 }
 
+void vx_pool_trim(vx_ctx* ctx) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->pool_free)
+        for (void* p : kv.second) (void)hipFree(p);
+    ctx->pool_free.clear();
+}
+void* vx_pool_alloc(vx_ctx* ctx, size_t bytes) {
+    const size_t gran = (size_t)2 << 20;
+    const size_t sz = ((bytes ? bytes : 1) + gran - 1) / gran * gran;
+    auto it = ctx->pool_free.find(sz);
+    void* p = nullptr;
+    if (it != ctx->pool_free.end() && !it->second.empty()) {
+        p = it->second.back();
+        it->second.pop_back();
+    } else if (hipMalloc(&p, sz) != hipSuccess) {
+        (void)hipGetLastError();
+        vx_pool_trim(ctx);  // give cached blocks back and retry once
+        if (hipMalloc(&p, sz) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
+    ctx->pool_live[p] = sz;
+    return p;
+}
+void vx_pool_free(vx_ctx* ctx, void* p) {
+    if (!p) return;
+    auto it = ctx->pool_live.find(p);
+    if (it == ctx->pool_live.end()) {  // not ours: plain free
+        (void)hipFree(p);
+        return;
+    }
+    ctx->pool_free[it->second].push_back(p);
+    ctx->pool_live.erase(it);
+}
+
 int32_t vx_scratch(vx_ctx* ctx, size_t n, uint64_t** out) {
     if (ctx->scratch_n < n) {
         if (ctx->scratch) {
-            VX_HIP(hipStreamSynchronize(ctx->stream));
-            VX_HIP(hipFree(ctx->scratch));
+            vx_pool_free(ctx, ctx->scratch);
             ctx->scratch = nullptr;
             ctx->scratch_n = 0;
         }
-        VX_HIP(hipMalloc(&ctx->scratch, n * 8));
+        ctx->scratch = (uint64_t*)vx_pool_alloc(ctx, n * 8);
+        if (!ctx->scratch) return vx_fail(ctx, VX_ERR_OOM, "scratch: cannot allocate %zu bytes", n * 8);
         ctx->scratch_n = n;
     }
     *out = ctx->scratch;
@@ -115,7 +151,9 @@ int32_t vx_ctx_destroy(vx_ctx* ctx) {
     hipFree(ctx->tw_inv.d);
     hipFree(ctx->w12_fwd);
     hipFree(ctx->w12_inv);
-    if (ctx->scratch) hipFree(ctx->scratch);
+    if (ctx->scratch) vx_pool_free(ctx, ctx->scratch);
+    vx_pool_trim(ctx);
+    for (auto& kv : ctx->pool_live) hipFree(kv.first);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);
@@ -148,18 +186,17 @@ int32_t vx_alloc(vx_ctx* ctx, size_t n, vx_buf** out) {
     if (!ctx || !out) return VX_ERR_ARG;
     VX_CHECK(n > 0, "vx_alloc: n == 0");
     vx_buf* b = new vx_buf{nullptr, n};
-    hipError_t e = hipMalloc(&b->d, n * 8);
-    if (e != hipSuccess) {
+    b->d = (uint64_t*)vx_pool_alloc(ctx, n * 8);
+    if (!b->d) {
         delete b;
-        return vx_fail(ctx, VX_ERR_OOM, "hipMalloc(%zu bytes): %s", n * 8, hipGetErrorString(e));
+        return vx_fail(ctx, VX_ERR_OOM, "device allocation of %zu bytes failed", n * 8);
     }
     *out = b;
     return VX_OK;
 }
 int32_t vx_free(vx_ctx* ctx, vx_buf* buf) {
     if (!ctx || !buf) return VX_ERR_ARG;
-    VX_HIP(hipStreamSynchronize(ctx->stream));
-    VX_HIP(hipFree(buf->d));
+    vx_pool_free(ctx, buf->d);
     delete buf;
     return VX_OK;
 }

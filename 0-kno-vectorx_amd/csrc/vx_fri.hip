@@ -201,10 +201,10 @@ int32_t vx_fri_layer_tree_dev(vx_ctx* ctx, const uint64_t* evals_d, int log_n, i
     }
     total += 4 * cur;
     vx_tree* t = new vx_tree{nullptr, M, cap_height, total};
-    hipError_t e = hipMalloc(&t->levels, total * 8);
-    if (e != hipSuccess) {
+    t->levels = (uint64_t*)vx_pool_alloc(ctx, total * 8);
+    if (!t->levels) {
         delete t;
-        return vx_fail(ctx, VX_ERR_OOM, "fri tree: hipMalloc: %s", hipGetErrorString(e));
+        return vx_fail(ctx, VX_ERR_OOM, "fri tree: cannot allocate %zu bytes", total * 8);
     }
     dim3 g((unsigned)((M + 255) / 256)), b(256);
     switch (arity_bits) {
@@ -226,7 +226,7 @@ int32_t vx_fri_layer_tree_dev(vx_ctx* ctx, const uint64_t* evals_d, int log_n, i
     }
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
-        hipFree(t->levels);
+        vx_pool_free(ctx, t->levels);
         delete t;
         return vx_fail(ctx, VX_ERR_DEVICE, "fri tree launch: %s", hipGetErrorString(le));
     }

@@ -59,7 +59,15 @@ struct vx_ctx {
     size_t scratch_n;
     void* pinned;  // small pinned staging area
     size_t pinned_n;
+    // device memory pool: blocks are recycled by exact (rounded) size instead of hipFree'd -- a
+    // proof allocates tens of GB and hipMalloc/hipFree of such blocks costs far more than the kernels.
+    // All work is on ctx->stream, so a recycled block is safe to hand out again immediately.
+    std::map<size_t, std::vector<void*>> pool_free;
+    std::map<void*, size_t> pool_live;
 };
+void* vx_pool_alloc(vx_ctx* ctx, size_t bytes);
+void vx_pool_free(vx_ctx* ctx, void* p);
+void vx_pool_trim(vx_ctx* ctx);
 
 struct vx_tree {
     uint64_t* levels;  // level 0 (leaf digests, 4*n) followed by each parent level up to the cap

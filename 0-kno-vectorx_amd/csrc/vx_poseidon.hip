@@ -97,10 +97,10 @@ int32_t vx_merkle_build_dev(vx_ctx* ctx, const uint64_t* data, size_t n_leaves, 
     }
     total += 4 * cur;
     vx_tree* t = new vx_tree{nullptr, n_leaves, cap_height, total};
-    hipError_t e = hipMalloc(&t->levels, total * 8);
-    if (e != hipSuccess) {
+    t->levels = (uint64_t*)vx_pool_alloc(ctx, total * 8);
+    if (!t->levels) {
         delete t;
-        return vx_fail(ctx, VX_ERR_OOM, "merkle: hipMalloc(%zu): %s", total * 8, hipGetErrorString(e));
+        return vx_fail(ctx, VX_ERR_OOM, "merkle: cannot allocate %zu bytes", total * 8);
     }
     unsigned g = (unsigned)((n_leaves + 255) / 256);
     if (layout == VX_LEAVES_ROW_MAJOR)
@@ -120,7 +120,7 @@ int32_t vx_merkle_build_dev(vx_ctx* ctx, const uint64_t* data, size_t n_leaves, 
     }
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
-        hipFree(t->levels);
+        vx_pool_free(ctx, t->levels);
         delete t;
         return vx_fail(ctx, VX_ERR_DEVICE, "merkle launch: %s", hipGetErrorString(le));
     }
@@ -146,8 +146,7 @@ int32_t vx_merkle_build(vx_ctx* ctx, const vx_buf* data, size_t off, size_t n_le
 }
 int32_t vx_merkle_free(vx_ctx* ctx, vx_tree* tree) {
     if (!ctx || !tree) return VX_ERR_ARG;
-    VX_HIP(hipStreamSynchronize(ctx->stream));
-    VX_HIP(hipFree(tree->levels));
+    vx_pool_free(ctx, tree->levels);
     delete tree;
     return VX_OK;
 }

@@ -268,20 +268,21 @@ static void periodic_on_coset(const uint64_t* v, int period_log, int rate_bits, 
     }
 }
 
-struct DevMem {  // RAII for the prover's temporaries
+struct DevMem {  // RAII for the prover's temporaries (recycled through the ctx pool)
+    vx_ctx* ctx;
     std::vector<void*> ptrs;
     std::vector<vx_tree*> trees;
+    explicit DevMem(vx_ctx* c) : ctx(c) {}
     ~DevMem() {
-        for (void* p : ptrs) (void)hipFree(p);
+        for (void* p : ptrs) vx_pool_free(ctx, p);
         for (vx_tree* t : trees) {
-            (void)hipFree(t->levels);
+            vx_pool_free(ctx, t->levels);
             delete t;
         }
     }
     uint64_t* alloc(size_t n_u64) {
-        void* p = nullptr;
-        if (hipMalloc(&p, n_u64 * 8) != hipSuccess) return nullptr;
-        ptrs.push_back(p);
+        void* p = vx_pool_alloc(ctx, n_u64 * 8);
+        if (p) ptrs.push_back(p);
         return (uint64_t*)p;
     }
 };
@@ -356,7 +357,7 @@ int32_t vx_stark_prove(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_in, c
     for (size_t i = 0; i < n_public; ++i) VX_CHECK(public_inputs[i] < glh::P, "stark prove: public input %zu not canonical", i);
     const int Q = 2, nq = 2 * Q;  // quotient_degree_factor 2 (constraint degree 3), 2 challenges
     const uint64_t g = 7;         // F::coset_shift()
-    DevMem mem;
+    DevMem mem(ctx);
     std::vector<uint64_t> proof;
 
     // ---- 1. trace commitment: PolynomialBatch::from_values
