@@ -20,31 +20,50 @@ struct gl2 {
 
 __device__ __forceinline__ uint64_t gl_canon(uint64_t x) { return x >= GL_P ? x - GL_P : x; }
 
+// a + b: the sum exceeds p exactly when a + b overflows 64 bits or (a + b) + eps does, so the two
+// carry flags decide (no 64-bit compares).
 __device__ __forceinline__ uint64_t gl_add(uint64_t a, uint64_t b) {
-    uint64_t s = a + b;
-    uint64_t t = s + GL_EPS;  // s - p (mod 2^64)
-    return (s < a || s >= GL_P) ? t : s;
+    uint64_t s, t;
+    const bool c1 = __builtin_add_overflow(a, b, &s);
+    const bool c2 = __builtin_add_overflow(s, (uint64_t)GL_EPS, &t);  // s - p (mod 2^64)
+    return (c1 | c2) ? t : s;
 }
 __device__ __forceinline__ uint64_t gl_sub(uint64_t a, uint64_t b) {
-    uint64_t d = a - b;
-    return a < b ? d - GL_EPS : d;  // + p (mod 2^64)
+    uint64_t d;
+    const bool bw = __builtin_sub_overflow(a, b, &d);
+    return d - (bw ? (uint64_t)GL_EPS : 0);  // + p (mod 2^64)
 }
 __device__ __forceinline__ uint64_t gl_neg(uint64_t a) { return a ? GL_P - a : 0; }
 __device__ __forceinline__ uint64_t gl_dbl(uint64_t a) { return gl_add(a, a); }
 
-// (hi, lo) 128-bit -> canonical
-__device__ __forceinline__ uint64_t gl_reduce128(uint64_t hi, uint64_t lo) {
-    uint64_t hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
-    uint64_t t0 = lo - hi_hi;
-    if (lo < hi_hi) t0 -= GL_EPS;  // borrow: add p
-    uint64_t t1 = hi_lo * GL_EPS;  // < 2^64
+// (hi, lo) 128-bit -> [0, 2^64), NOT necessarily canonical (may be in [p, 2^64))
+__device__ __forceinline__ uint64_t gl_reduce128_nc(uint64_t hi, uint64_t lo) {
+    const uint32_t hh = (uint32_t)(hi >> 32), hl = (uint32_t)hi;
+    uint64_t t0 = lo - hh;
+    if (lo < hh) t0 -= GL_EPS;                    // borrow: + p (mod 2^64)
+    const uint64_t t1 = ((uint64_t)hl << 32) - hl;  // hl * (2^32 - 1)
     uint64_t t2 = t0 + t1;
-    if (t2 < t1) t2 += GL_EPS;  // carry: subtract p (mod 2^64 adds eps)
-    return gl_canon(t2);
+    if (t2 < t1) t2 += GL_EPS;                    // carry: - p (mod 2^64)
+    return t2;
 }
-__device__ __forceinline__ uint64_t gl_mul(uint64_t a, uint64_t b) {
-    return gl_reduce128(__umul64hi(a, b), a * b);
+__device__ __forceinline__ uint64_t gl_reduce128(uint64_t hi, uint64_t lo) { return gl_canon(gl_reduce128_nc(hi, lo)); }
+// 64 x 64 -> 128 from four 32 x 32 + 64 multiply-adds (v_mad_u64_u32); the compiler's own
+// expansion of a * b and __umul64hi(a, b) computes the partial products twice.
+__device__ __forceinline__ void gl_mul128(uint64_t a, uint64_t b, uint64_t& hi, uint64_t& lo) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const uint64_t t0 = (uint64_t)a0 * b0;
+    const uint64_t t1 = (uint64_t)a0 * b1 + (t0 >> 32);
+    const uint64_t t2 = (uint64_t)a1 * b0 + (uint32_t)t1;
+    hi = (uint64_t)a1 * b1 + (t1 >> 32) + (t2 >> 32);
+    lo = (t2 << 32) | (uint32_t)t0;
 }
+// inputs: any 64-bit representatives; output in [0, 2^64) (non-canonical)
+__device__ __forceinline__ uint64_t gl_mul_nc(uint64_t a, uint64_t b) {
+    uint64_t hi, lo;
+    gl_mul128(a, b, hi, lo);
+    return gl_reduce128_nc(hi, lo);
+}
+__device__ __forceinline__ uint64_t gl_mul(uint64_t a, uint64_t b) { return gl_canon(gl_mul_nc(a, b)); }
 __device__ __forceinline__ uint64_t gl_sqr(uint64_t a) { return gl_mul(a, a); }
 // multiply by a small constant c < 2^32
 __device__ __forceinline__ uint64_t gl_mul_small(uint64_t a, uint32_t c) {

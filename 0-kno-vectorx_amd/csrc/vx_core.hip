@@ -43,6 +43,38 @@ int32_t vx_get_shift_tab(vx_ctx* ctx, uint64_t base, PowTab* out) {
     return VX_OK;
 }
 
+int32_t vx_get_tw2(vx_ctx* ctx, int log_s, int inverse, Tw2* out) {
+    const int lo_bits = (log_s + 1) / 2, hi_bits = log_s - lo_bits;
+    const int key = log_s * 2 + (inverse ? 1 : 0);
+    auto it = ctx->tw2.find(key);
+    if (it == ctx->tw2.end()) {
+        const size_t nlo = (size_t)1 << lo_bits, nhi = (size_t)1 << hi_bits;
+        std::vector<uint64_t> h(nlo + nhi);
+        uint64_t w = glh::root(log_s);
+        if (inverse) w = glh::inv(w);
+        uint64_t acc = 1;
+        for (size_t j = 0; j < nlo; ++j) {
+            h[j] = acc;
+            acc = glh::mul(acc, w);
+        }
+        const uint64_t wh = acc;  // w^(2^lo_bits)
+        acc = 1;
+        for (size_t j = 0; j < nhi; ++j) {
+            h[nlo + j] = acc;
+            acc = glh::mul(acc, wh);
+        }
+        uint64_t* d = nullptr;
+        VX_HIP(hipMalloc(&d, h.size() * 8));
+        VX_HIP(hipMemcpyAsync(d, h.data(), h.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        VX_HIP(hipStreamSynchronize(ctx->stream));
+        it = ctx->tw2.emplace(key, d).first;
+    }
+    out->lo = it->second;
+    out->hi = it->second + ((size_t)1 << lo_bits);
+    out->lo_bits = lo_bits;
+    return VX_OK;
+}
+
 void vx_pool_trim(vx_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->pool_free)
@@ -147,6 +179,7 @@ int32_t vx_ctx_destroy(vx_ctx* ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->shift_tabs) hipFree(kv.second.d);
+    for (auto& kv : ctx->tw2) hipFree(kv.second);
     hipFree(ctx->tw_fwd.d);
     hipFree(ctx->tw_inv.d);
     hipFree(ctx->w12_fwd);

@@ -55,6 +55,7 @@ struct vx_ctx {
     PowTab tw_fwd, tw_inv;       // base = omega_{2^32}, omega_{2^32}^-1
     uint64_t *w12_fwd, *w12_inv;  // omega_4096^e, e < 2048
     std::map<uint64_t, PowTab> shift_tabs;
+    std::map<int, uint64_t*> tw2;  // key = log_s * 2 + inverse: two-level table of w_{2^log_s}
     uint64_t* scratch;
     size_t scratch_n;
     void* pinned;  // small pinned staging area
@@ -109,3 +110,11 @@ int32_t vx_fri_fold_dev(vx_ctx* ctx, const uint64_t* evals, int log_n, int arity
 int32_t vx_fri_layer_tree_dev(vx_ctx* ctx, const uint64_t* evals, int log_n, int arity_bits, int cap_height, vx_tree** out);
 int32_t vx_fri_leaves_dev(vx_ctx* ctx, const uint64_t* evals, int log_n, int arity_bits, const uint64_t* leaf_idx, size_t n_idx,
                           uint64_t* out);
+
+// two-level root table for one sub-transform size: lo[j] = w_S^j (j < 2^lo_bits), hi[j] = w_S^(j << lo_bits)
+struct Tw2 {
+    const uint64_t* lo;
+    const uint64_t* hi;
+    int lo_bits;
+};
+int32_t vx_get_tw2(vx_ctx* ctx, int log_s, int inverse, Tw2* out);

@@ -17,6 +17,9 @@
 // coefficients simply live in bit-reversed positions in between.  The LDE's
 // zero padding and coset scaling (c_k *= shift^k) are fused into the first
 // DIT pass, which reads only the n = N >> rate_bits real coefficients.
+#include <stdlib.h>
+#include <utility>
+
 #include "gl.cuh"
 #include "vx_internal.h"
 
@@ -33,6 +36,9 @@ struct PassArgs {
     int expand_bits;      // DIT first pass of an LDE: src holds S >> expand_bits coefficients
     int log_coeff;        // log2 of the coefficient count (bit-reversal width for shift^k)
     const uint64_t* shift_tab;  // three-level powers of the coset shift, or null
+    const uint64_t* tw2_lo;     // two-level table of w_{2^log_sub}: lo[j] = w^j, hi[j] = w^(j << tw2_bits)
+    const uint64_t* tw2_hi;
+    int tw2_bits;
 };
 
 __device__ __forceinline__ uint64_t tab3_pow(const uint64_t* tab, uint64_t e) {
@@ -137,6 +143,240 @@ __global__ __launch_bounds__(256) void k_ntt_pass(PassArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// v2 tile kernel: register-resident radix-16 rounds.  A 4096-element tile (index iota = rho*T +
+// tau, rho = row, tau = column) is held 16 elements per lane; one ROUND transforms the 4-bit
+// window [f, f+4) of iota (f = 8, 4, 0) entirely in registers, so a 12-stage pass needs 2-3 LDS
+// exchanges instead of 12 barrier-separated LDS stages.  Inside a round every twiddle is a
+// power of w_16 = 2^156 = -2^60 (mod p): multiplications by w_16^k are 64-bit shifts plus the
+// 2^64 = 2^32 - 1 reduction, no integer multiplier.  General multiplications remain only for
+// the between-round twiddle w^(rho_low * k) (one per element per round, table w_4096^e) and
+// the between-pass twiddle of the four-step plan.  DIT rounds are the transposed flow graph.
+template <int R_>
+__device__ __forceinline__ uint64_t gl_shl(uint64_t x) {  // x * 2^R_, canonical in/out, 0 <= R_ < 96
+    if constexpr (R_ == 0) return x;
+    else if constexpr (R_ < 64) return gl_reduce128(x >> (64 - R_), x << R_);
+    else {
+        constexpr int s = R_ - 64;
+        const uint64_t A = s ? (x >> (64 - s)) : 0, B = x << s;
+        const uint32_t bh = (uint32_t)(B >> 32), bl = (uint32_t)B;
+        uint64_t t = ((uint64_t)bl << 32) - bl;  // bl * (2^32 - 1) < p
+        t = gl_sub(t, bh);
+        return gl_sub(t, A << 32);
+    }
+}
+// |w_16^K| as a shift, and its sign: forward (156K mod 192), inverse (-156K mod 192)
+template <int K, int INV>
+struct W16 {
+    static constexpr int E = ((INV ? 192 - 156 : 156) * K) % 192;
+    static constexpr int SH = E % 96;
+    static constexpr bool NEG = E >= 96;
+};
+template <int K, int INV>
+__device__ __forceinline__ void bfly_dif(uint64_t& u, uint64_t& v) {  // (u+v, (u-v) w_16^K)
+    const uint64_t s = gl_add(u, v);
+    const uint64_t d = W16<K, INV>::NEG ? gl_sub(v, u) : gl_sub(u, v);
+    u = s;
+    v = gl_shl<W16<K, INV>::SH>(d);
+}
+template <int K, int INV>
+__device__ __forceinline__ void bfly_dit(uint64_t& u, uint64_t& v) {  // (u + v w, u - v w)
+    const uint64_t t = gl_shl<W16<K, INV>::SH>(v);
+    const uint64_t a = gl_add(u, t), b = gl_sub(u, t);
+    u = W16<K, INV>::NEG ? b : a;
+    v = W16<K, INV>::NEG ? a : b;
+}
+// DFT over the top Q bits of the register index e (2^(4-Q) independent groups)
+template <int Q, int INV, int S, int E>
+__device__ __forceinline__ void dif_stage_pair(uint64_t* x) {
+    // S = stage (span 2^S in field index), E = register index of the upper element's partner base
+    constexpr int G = 4 - Q;                 // low bits = group
+    constexpr int a = E >> G;                // field index
+    if constexpr (((a >> S) & 1) == 0) {
+        constexpr int h = 1 << S;
+        constexpr int j = a & (h - 1);
+        constexpr int K = j * (8 >> S);      // w_{2h}^j = w_16^(j * 8/h)
+        bfly_dif<K, INV>(x[E], x[E + (h << G)]);
+    }
+}
+template <int Q, int INV, int S, int E>
+__device__ __forceinline__ void dit_stage_pair(uint64_t* x) {
+    constexpr int G = 4 - Q;
+    constexpr int a = E >> G;
+    if constexpr (((a >> S) & 1) == 0) {
+        constexpr int h = 1 << S;
+        constexpr int j = a & (h - 1);
+        constexpr int K = j * (8 >> S);
+        bfly_dit<K, INV>(x[E], x[E + (h << G)]);
+    }
+}
+template <int Q, int INV, int S, int... Es>
+__device__ __forceinline__ void dif_stage(uint64_t* x, std::integer_sequence<int, Es...>) {
+    (dif_stage_pair<Q, INV, S, Es>(x), ...);
+}
+template <int Q, int INV, int S, int... Es>
+__device__ __forceinline__ void dit_stage(uint64_t* x, std::integer_sequence<int, Es...>) {
+    (dit_stage_pair<Q, INV, S, Es>(x), ...);
+}
+template <int Q, int INV>
+__device__ __forceinline__ void dif_round_q(uint64_t* x) {
+    using I = std::make_integer_sequence<int, 16>;
+    if constexpr (Q >= 4) dif_stage<Q, INV, 3>(x, I{});
+    if constexpr (Q >= 3) dif_stage<Q, INV, 2>(x, I{});
+    if constexpr (Q >= 2) dif_stage<Q, INV, 1>(x, I{});
+    dif_stage<Q, INV, 0>(x, I{});
+}
+template <int Q, int INV>
+__device__ __forceinline__ void dit_round_q(uint64_t* x) {
+    using I = std::make_integer_sequence<int, 16>;
+    dit_stage<Q, INV, 0>(x, I{});
+    if constexpr (Q >= 2) dit_stage<Q, INV, 1>(x, I{});
+    if constexpr (Q >= 3) dit_stage<Q, INV, 2>(x, I{});
+    if constexpr (Q >= 4) dit_stage<Q, INV, 3>(x, I{});
+}
+template <int MODE, int INV>
+__device__ __forceinline__ void tile_round(uint64_t* x, int q) {
+    switch (q) {  // wave-uniform
+    case 4: MODE ? dit_round_q<4, INV>(x) : dif_round_q<4, INV>(x); break;
+    case 3: MODE ? dit_round_q<3, INV>(x) : dif_round_q<3, INV>(x); break;
+    case 2: MODE ? dit_round_q<2, INV>(x) : dif_round_q<2, INV>(x); break;
+    default: MODE ? dit_round_q<1, INV>(x) : dif_round_q<1, INV>(x); break;
+    }
+}
+__device__ __forceinline__ int tile_iota(int tid, int e, int f) {
+    return (tid & ((1 << f) - 1)) | (e << f) | ((tid >> f) << (f + 4));
+}
+__device__ __forceinline__ int tile_pad(int i) { return i + (i >> 4); }
+__device__ __forceinline__ void tile_exchange(uint64_t* x, uint64_t* lds, int tid, int f_from, int f_to) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lds[tile_pad(tile_iota(tid, e, f_from))] = x[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = lds[tile_pad(tile_iota(tid, e, f_to))];
+}
+// multiply x[e] by w_{2^(b+q)}^(rho_low * k), k = bitrev_q(field index of e), rho_low = rho mod 2^b
+__device__ __forceinline__ void tile_twiddle(uint64_t* x, const uint64_t* w12, int tid, int f, int q, int b, int lT) {
+    const int g = 4 - q;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int k = (int)(__brev((unsigned)(e >> g)) >> (32 - q));
+        const int rho_low = (tile_iota(tid, e, f) >> lT) & ((1 << b) - 1);
+        const int idx = (rho_low * k) << (12 - b - q);
+        if (idx) {
+            const uint64_t w = w12[idx & 2047];
+            const uint64_t v = gl_mul(x[e], w);
+            x[e] = (idx & 2048) ? gl_neg(v) : v;
+        }
+    }
+}
+
+template <int MODE, int INV>
+__global__ __launch_bounds__(256) void k_ntt_tile(PassArgs a) {
+    __shared__ __attribute__((aligned(16))) uint64_t lds[4096 + 256 + 2048];
+    uint64_t* const w12s = lds + 4096 + 256;  // w_4096^e, e < 2048, staged once: the per-element
+    const int lr = a.log_rows, lT = 12 - lr, T = 1 << lT;  // twiddle lookups are LDS reads, not gathers
+    const int tid = threadIdx.x;
+    if (lr > 4) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w12s[tid + 256 * j] = a.w12[tid + 256 * j];
+        // visible after the first tile_exchange barrier, which precedes every use... except a
+        // twiddle right after round A: make it explicit
+        __syncthreads();
+    }
+    const size_t m = (size_t)1 << (a.log_sub - lr);
+    const size_t tiles_per_sub = m >> lT;
+    const size_t tile = blockIdx.x;
+    const size_t sub = tile / tiles_per_sub;
+    const size_t col0 = (tile - sub * tiles_per_sub) << lT;
+    const size_t base = (sub << a.log_sub) + col0;
+    const uint64_t* src = a.src + blockIdx.y * a.src_col_stride;
+    uint64_t* dst = a.dst + blockIdx.y * a.dst_col_stride;
+    const int nr = (lr + 3) >> 2;
+    const int qA = lr < 4 ? lr : 4, qB = lr - 4 < 4 ? lr - 4 : 4, qC = lr - 8;
+    uint64_t x[16];
+    if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = tile_iota(tid, e, 8);
+            x[e] = src[base + (size_t)(i >> lT) * m + (i & (T - 1))];
+        }
+        tile_round<0, INV>(x, qA);
+        if (lr - qA > 0) tile_twiddle(x, w12s, tid, 8, qA, lr - qA, lT);
+        int f_last = 8;
+        if (nr >= 2) {
+            tile_exchange(x, lds, tid, 8, 4);
+            tile_round<0, INV>(x, qB);
+            if (lr - 4 - qB > 0) tile_twiddle(x, w12s, tid, 4, qB, lr - 4 - qB, lT);
+            f_last = 4;
+        }
+        if (nr == 3) {
+            tile_exchange(x, lds, tid, 4, 0);
+            tile_round<0, INV>(x, qC);
+            tile_exchange(x, lds, tid, 0, 8);  // back to the coalesced mapping for the store
+            f_last = 8;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = tile_iota(tid, e, f_last);
+            const int rho = i >> lT, tau = i & (T - 1);
+            uint64_t v = x[e];
+            if (m > 1) {
+                const uint64_t ex = (uint64_t)(col0 + tau) * brev32((uint32_t)rho, lr);
+                const uint64_t w = gl_mul_nc(a.tw2_hi[ex >> a.tw2_bits], a.tw2_lo[ex & (((uint64_t)1 << a.tw2_bits) - 1)]);
+                v = gl_mul(v, w);
+            }
+            if (a.scale > 1) v = gl_mul(v, a.scale);
+            dst[base + (size_t)rho * m + tau] = v;
+        }
+    } else {
+        const int f_first = nr == 1 ? 8 : (nr == 2 ? 4 : 0);
+        const int f_load = f_first == 0 ? 8 : f_first;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = tile_iota(tid, e, f_load);
+            const int rho = i >> lT, tau = i & (T - 1);
+            const size_t g = base + (size_t)rho * m + tau;
+            uint64_t v;
+            if (a.expand_bits) {
+                v = 0;
+                if ((g & (((size_t)1 << a.expand_bits) - 1)) == 0) {
+                    const size_t qq = g >> a.expand_bits;
+                    v = src[qq];
+                    if (a.shift_tab) v = gl_mul(v, tab3_pow(a.shift_tab, brev32((uint32_t)qq, a.log_coeff)));
+                }
+            } else {
+                v = src[g];
+                if (a.shift_tab && m == 1) v = gl_mul(v, tab3_pow(a.shift_tab, brev32((uint32_t)g, a.log_coeff)));
+            }
+            if (m > 1) {
+                const uint64_t ex = (uint64_t)(col0 + tau) * brev32((uint32_t)rho, lr);
+                const uint64_t w = gl_mul_nc(a.tw2_hi[ex >> a.tw2_bits], a.tw2_lo[ex & (((uint64_t)1 << a.tw2_bits) - 1)]);
+                v = gl_mul(v, w);
+            }
+            x[e] = v;
+        }
+        if (nr == 3) {
+            tile_exchange(x, lds, tid, 8, 0);
+            tile_round<1, INV>(x, qC);
+            tile_exchange(x, lds, tid, 0, 4);
+        }
+        if (nr >= 2) {
+            if (lr - 4 - qB > 0) tile_twiddle(x, w12s, tid, 4, qB, lr - 4 - qB, lT);
+            tile_round<1, INV>(x, qB);
+            tile_exchange(x, lds, tid, 4, 8);
+        }
+        if (lr - qA > 0) tile_twiddle(x, w12s, tid, 8, qA, lr - qA, lT);
+        tile_round<1, INV>(x, qA);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = tile_iota(tid, e, 8);
+            dst[base + (size_t)(i >> lT) * m + (i & (T - 1))] = x[e];
+        }
+    }
+}
+
 // out[i] = in[bitrev(i)] (per column); in != out
 __global__ void k_bitrev_copy(const uint64_t* in, uint64_t* out, int log_n, size_t in_stride, size_t out_stride) {
     size_t n = (size_t)1 << log_n;
@@ -179,9 +419,16 @@ static inline size_t lds_bytes(int lr, int lT) {
     size_t T = (size_t)1 << lT;
     return ((size_t)1 << lr) * (T > 1 ? T + 1 : 1) * 8;
 }
+static bool g_ntt_v1 = getenv("VX_NTT_V1") != nullptr;  // debugging aid: force the LDS-stage kernel
 template <int MODE>
-static int32_t launch_pass(vx_ctx* ctx, PassArgs& a, int log_n, size_t n_cols) {
+static int32_t launch_pass(vx_ctx* ctx, PassArgs& a, int log_n, size_t n_cols, int inverse) {
     size_t tiles = (size_t)1 << (log_n - a.log_rows - a.log_T);
+    if (a.log_rows + a.log_T == 12 && !g_ntt_v1) {
+        if (inverse) hipLaunchKernelGGL((k_ntt_tile<MODE, 1>), dim3((unsigned)tiles, (unsigned)n_cols), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_ntt_tile<MODE, 0>), dim3((unsigned)tiles, (unsigned)n_cols), dim3(256), 0, ctx->stream, a);
+        VX_HIP(hipGetLastError());
+        return VX_OK;
+    }
     hipLaunchKernelGGL(k_ntt_pass<MODE>, dim3((unsigned)tiles, (unsigned)n_cols), dim3(256), lds_bytes(a.log_rows, a.log_T),
                        ctx->stream, a);
     VX_HIP(hipGetLastError());
@@ -207,7 +454,12 @@ static int32_t ntt_dif(vx_ctx* ctx, const uint64_t* src, size_t src_stride, uint
         a.log_sub = ls;
         a.log_rows = c;
         a.log_T = (ls - c) < (12 - c) ? (ls - c) : (12 - c);
-        VX_TRY(launch_pass<0>(ctx, a, L, n_cols));
+        {
+            Tw2 t2;
+            VX_TRY(vx_get_tw2(ctx, ls, inverse, &t2));
+            a.tw2_lo = t2.lo, a.tw2_hi = t2.hi, a.tw2_bits = t2.lo_bits;
+        }
+        VX_TRY(launch_pass<0>(ctx, a, L, n_cols, inverse));
         a.src = dst;
         a.src_col_stride = dst_stride;
         ls -= c;
@@ -215,7 +467,7 @@ static int32_t ntt_dif(vx_ctx* ctx, const uint64_t* src, size_t src_stride, uint
     a.log_sub = a.log_rows = last;
     a.log_T = 0;
     a.scale = scale;
-    return launch_pass<0>(ctx, a, L, n_cols);
+    return launch_pass<0>(ctx, a, L, n_cols, inverse);
 }
 
 // bit-reversed positions -> natural.  With expand_bits = r the source holds 2^(L-r)
@@ -237,7 +489,7 @@ static int32_t ntt_dit(vx_ctx* ctx, const uint64_t* src, size_t src_stride, uint
     a.expand_bits = expand_bits;
     a.log_coeff = L - expand_bits;
     a.shift_tab = shift_tab;
-    VX_TRY(launch_pass<1>(ctx, a, L, n_cols));
+    VX_TRY(launch_pass<1>(ctx, a, L, n_cols, inverse));
     a.src = dst;
     a.src_col_stride = dst_stride;
     a.expand_bits = 0;
@@ -249,7 +501,12 @@ static int32_t ntt_dit(vx_ctx* ctx, const uint64_t* src, size_t src_stride, uint
         a.log_sub = ls;
         a.log_rows = c;
         a.log_T = (ls - c) < (12 - c) ? (ls - c) : (12 - c);
-        VX_TRY(launch_pass<1>(ctx, a, L, n_cols));
+        {
+            Tw2 t2;
+            VX_TRY(vx_get_tw2(ctx, ls, inverse, &t2));
+            a.tw2_lo = t2.lo, a.tw2_hi = t2.hi, a.tw2_bits = t2.lo_bits;
+        }
+        VX_TRY(launch_pass<1>(ctx, a, L, n_cols, inverse));
     }
     return VX_OK;
 }

@@ -74,9 +74,16 @@ def ntt_roofline(ctx, iters=10):
     launches = 1 + (NTT_LOG_N > 12) + (NTT_LOG_N > 20)
     alg_bytes = 16.0 * n * NTT_COLS
     achieved = alg_bytes / (ms * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "r01_ntt_traffic.json")
+    if os.path.exists(tpath):  # PMC counters cannot be read from inside the bench: committed rocprofv3 --pmc result
+        t = json.load(open(tpath))
+        if t["shape"].startswith(f"forward NTT 2^{NTT_LOG_N} x {NTT_COLS}"):
+            traffic = round(t["hbm_bytes_per_transform"] / 1e9, 3)
+            traffic_src = "profiles/r01_ntt_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), calibrated on known 8-B/lane streams; GB per transform"
     return {
-        "bound": "hbm", "kernel": "k_ntt_pass", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "bound": "hbm", "kernel": "k_ntt_tile", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "per": f"one forward NTT of 2^{NTT_LOG_N} x {NTT_COLS} columns = {launches} launches, {alg_bytes / 1e9:.3f} GB algorithmic (16*n*c)",
         "ms_per_transform": round(ms, 4), "ms_per_launch": round(ms / launches, 4),
     }
