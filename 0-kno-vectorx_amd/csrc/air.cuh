@@ -29,6 +29,28 @@ struct Fp {  // device base-field element
     __device__ __forceinline__ static Fp from(uint64_t x) { return {x}; }
 };
 
+// host-side extension-field element (verifier: constraints evaluated at zeta)
+struct Fx {
+    uint64_t a, b;
+    static constexpr uint64_t P_ = 0xFFFFFFFF00000001ULL;
+    static inline uint64_t addm(uint64_t x, uint64_t y) {
+        uint64_t s = x + y;
+        return (s < x || s >= P_) ? s - P_ : s;
+    }
+    static inline uint64_t subm(uint64_t x, uint64_t y) { return x >= y ? x - y : x + (P_ - y); }
+    static inline uint64_t mulm(uint64_t x, uint64_t y) { return (uint64_t)(((unsigned __int128)x * y) % P_); }
+    Fx operator+(Fx o) const { return {addm(a, o.a), addm(b, o.b)}; }
+    Fx operator-(Fx o) const { return {subm(a, o.a), subm(b, o.b)}; }
+    Fx operator*(Fx o) const {
+        return {addm(mulm(a, o.a), mulm(7, mulm(b, o.b))), addm(mulm(a, o.b), mulm(b, o.a))};
+    }
+    static Fx from(uint64_t x) { return {x % P_, 0}; }
+};
+struct HostRow {
+    const Fx* v;
+    Fx operator[](int col) const { return v[col]; }
+};
+
 template <class F>
 struct Consumer {
     F acc[2], alpha[2], z_last, l_first, l_last;

@@ -29,18 +29,32 @@ VX_HD constexpr int OUT(int w) {
          : w < 12 ? GB(4 + ((w & 3) + 2) % 4, W_C2, 0)
                   : GB(4 + ((w & 3) + 1) % 4, W_D2, 0);
 }
-static __device__ const uint64_t IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
-                                         0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+#define BLK_IV_INIT {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL, \
+                     0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL}
+// the tables exist twice -- in device memory for the kernels, in host memory for the verifier
+static __device__ const uint64_t IV[8] = BLK_IV_INIT;
 static __device__ const uint8_t ORDER[16][16] = BLK_ORDER_INIT;
 static __device__ const uint8_t MS_SRC[15][16] = BLK_MS_SRC_INIT;
 static __device__ const uint8_t RC_SLOT[16] = BLK_RC_SLOT_INIT;
+static const uint64_t IV_H[8] = BLK_IV_INIT;
+static const uint8_t MS_SRC_H[15][16] = BLK_MS_SRC_INIT;
+static const uint8_t RC_SLOT_H[16] = BLK_RC_SLOT_INIT;
+#if defined(__HIP_DEVICE_COMPILE__)
+VX_HD uint64_t iv(int i) { return IV[i]; }
+VX_HD int ms_src(int r, int s) { return MS_SRC[r][s]; }
+VX_HD int rc_slot(int r) { return RC_SLOT[r]; }
+#else
+VX_HD uint64_t iv(int i) { return IV_H[i]; }
+VX_HD int ms_src(int r, int s) { return MS_SRC_H[r][s]; }
+VX_HD int rc_slot(int r) { return RC_SLOT_H[r]; }
+#endif
 }  // namespace blk
 
 struct BlakeAir {
     static constexpr int ID = 3, COLS = blk::COLS, PUB = 16, PERIODIC = 16, PERIOD_LOG = 4;
 
     template <class F, class Row, class C>
-    __device__ static void eval(const Row& loc, const Row& nxt, const F* sel, const F* pub, C& c) {
+    __host__ __device__ static void eval(const Row& loc, const Row& nxt, const F* sel, const F* pub, C& c) {
         using namespace blk;
         const F one = F::from(1), two = F::from(2), two32 = F::from(1ULL << 32);
         F g_on = sel[0];
@@ -133,7 +147,7 @@ struct BlakeAir {
                 F cell = loc[col0 + i], want;
                 if (wd < 8) want = loc[H(wd, i)];
                 else {
-                    const int bit = (int)((IV[wd - 8] >> i) & 1);
+                    const int bit = (int)((iv(wd - 8) >> i) & 1);
                     if (wd == 12 && i < 32) want = bit ? one - loc[TB0 + i] : loc[TB0 + i];
                     else if (wd == 14) want = bit ? one - fin : fin;
                     else want = F::from((uint64_t)bit);
@@ -147,7 +161,7 @@ struct BlakeAir {
 #pragma unroll 1
         for (int wd = 0; wd < 8; ++wd) {
             const int lo0 = OUT(wd), hi0 = OUT(8 + wd), t0 = GB(wd % 4, wd / 4, 0), v0 = GB(wd % 4, 2 + wd / 4, 0);
-            const uint64_t ivp = wd == 0 ? (IV[0] ^ 0x01010020ULL) : IV[wd];
+            const uint64_t ivp = wd == 0 ? (iv(0) ^ 0x01010020ULL) : iv(wd);
 #pragma unroll 1
             for (int i = 0; i < 64; ++i) {
                 const F h = loc[H(wd, i)], hn = nxt[H(wd, i)];
@@ -165,16 +179,16 @@ struct BlakeAir {
 #pragma unroll 1
             for (int h = 0; h < 2; ++h) {
                 const F n_ = nxt[MS(s, h)];
-                F acc = sel[0] * (n_ - loc[MS(MS_SRC[0][s], h)]);
+                F acc = sel[0] * (n_ - loc[MS(ms_src(0, s), h)]);
 #pragma unroll 1
-                for (int r = 1; r < 15; ++r) acc = acc + sel[r] * (n_ - loc[MS(MS_SRC[r][s], h)]);
+                for (int r = 1; r < 15; ++r) acc = acc + sel[r] * (n_ - loc[MS(ms_src(r, s), h)]);
                 c.constraint(acc);
             }
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
-            F acc = sel[0] * loc[MS(RC_SLOT[0], h)];
+            F acc = sel[0] * loc[MS(rc_slot(0), h)];
 #pragma unroll 1
-            for (int r = 1; r < 16; ++r) acc = acc + sel[r] * loc[MS(RC_SLOT[r], h)];
+            for (int r = 1; r < 16; ++r) acc = acc + sel[r] * loc[MS(rc_slot(r), h)];
             c.constraint(acc - limb(0, MB0, h));
         }
         const F first = loc[FIRST];

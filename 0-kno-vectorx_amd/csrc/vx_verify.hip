@@ -1,0 +1,390 @@
+// Host-side verifier for the STARK proofs vx_stark_prove emits: the `circuit.verify` half of
+// the reference's library seam (/root/reference circuits/header_range.rs:170).  Mirrors starky
+// v0.2.0 verify_stark_proof_with_challenges + plonky2 v0.2.0 verify_fri_proof
+// (fri_combine_initial, compute_evaluation, verify_merkle_proof_to_cap); crates pinned at
+// Cargo.lock:4848-4905, not vendored.  Verification is cheap scalar work (a few thousand
+// Poseidon permutations) and stays on the host, as in the reference.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "air.cuh"
+#include "air_blake.cuh"
+#include "poseidon_constants.h"
+#include "vx_internal.h"
+
+namespace {
+const uint64_t V_RC[360] = VX_POSEIDON_RC_INIT;
+const uint64_t V_MDS[12] = VX_POSEIDON_MDS_CIRC_INIT;
+void v_poseidon(uint64_t* s) {
+    for (int r = 0; r < 30; ++r) {
+        for (int i = 0; i < 12; ++i) s[i] = glh::add(s[i], V_RC[12 * r + i]);
+        const int nsb = (r < 4 || r >= 26) ? 12 : 1;
+        for (int i = 0; i < nsb; ++i) {
+            const uint64_t x = s[i], x2 = glh::mul(x, x), x3 = glh::mul(x2, x), x4 = glh::mul(x2, x2);
+            s[i] = glh::mul(x3, x4);
+        }
+        uint64_t o[12];
+        for (int row = 0; row < 12; ++row) {
+            unsigned __int128 acc = 0;
+            for (int i = 0; i < 12; ++i) acc += (unsigned __int128)s[(i + row) % 12] * V_MDS[i];
+            if (row == 0) acc += (unsigned __int128)s[0] * VX_POSEIDON_MDS_DIAG0;
+            o[row] = (uint64_t)(acc % glh::P);
+        }
+        memcpy(s, o, sizeof o);
+    }
+}
+void v_hash_or_noop(const uint64_t* in, size_t len, uint64_t* out4) {
+    uint64_t s[12] = {0};
+    if (len <= 4) {
+        memcpy(s, in, len * 8);
+    } else {
+        for (size_t off = 0; off < len; off += 8) {
+            const size_t k = len - off < 8 ? len - off : 8;
+            memcpy(s, in + off, k * 8);
+            v_poseidon(s);
+        }
+    }
+    memcpy(out4, s, 32);
+}
+bool v_merkle(const uint64_t* leaf, size_t leaf_len, size_t idx, const uint64_t* sib, size_t n_sib, const uint64_t* cap) {
+    uint64_t cur[4];
+    v_hash_or_noop(leaf, leaf_len, cur);
+    for (size_t k = 0; k < n_sib; ++k) {
+        uint64_t s[12] = {0};
+        if (idx & 1) {
+            memcpy(s, sib + 4 * k, 32);
+            memcpy(s + 4, cur, 32);
+        } else {
+            memcpy(s, cur, 32);
+            memcpy(s + 4, sib + 4 * k, 32);
+        }
+        v_poseidon(s);
+        memcpy(cur, s, 32);
+        idx >>= 1;
+    }
+    return memcmp(cur, cap + 4 * idx, 32) == 0;
+}
+struct VChallenger {
+    uint64_t st[12] = {0}, in[8], out[8];
+    int n_in = 0, n_out = 0;
+    void duplex() {
+        for (int i = 0; i < n_in; ++i) st[i] = in[i];
+        n_in = 0;
+        v_poseidon(st);
+        memcpy(out, st, sizeof out);
+        n_out = 8;
+    }
+    void observe(uint64_t x) {
+        n_out = 0;
+        in[n_in++] = x;
+        if (n_in == 8) duplex();
+    }
+    void observe(const uint64_t* x, size_t n) {
+        for (size_t i = 0; i < n; ++i) observe(x[i]);
+    }
+    uint64_t challenge() {
+        if (n_in > 0 || n_out == 0) duplex();
+        return out[--n_out];
+    }
+    Fx ext() {
+        const uint64_t a = challenge(), b = challenge();
+        return {a, b};
+    }
+};
+Fx fx_inv(Fx x) {
+    const uint64_t n = glh::sub(glh::mul(x.a, x.a), glh::mul(7, glh::mul(x.b, x.b)));
+    const uint64_t ni = glh::inv(n);
+    return {glh::mul(x.a, ni), glh::mul(glh::sub(0, x.b), ni)};
+}
+Fx fx_pow(Fx x, uint64_t e) {
+    Fx r{1, 0};
+    while (e) {
+        if (e & 1) r = r * x;
+        x = x * x;
+        e >>= 1;
+    }
+    return r;
+}
+bool fx_eq(Fx x, Fx y) { return x.a == y.a && x.b == y.b; }
+
+struct AirV {
+    int id, cols, pub, periodic, period_log;
+    void (*periodic_values)(std::vector<uint64_t>&);
+    void (*eval)(const HostRow&, const HostRow&, const Fx*, const Fx*, Consumer<Fx>&);
+};
+template <class Air>
+void eval_host(const HostRow& l, const HostRow& n, const Fx* per, const Fx* pub, Consumer<Fx>& c) {
+    Air::template eval<Fx>(l, n, per, pub, c);
+}
+void v_no_periodic(std::vector<uint64_t>& v) { v.clear(); }
+void v_mix_periodic(std::vector<uint64_t>& v) { v = {0, 0, 0, 1, 3, 5, 7, 11}; }
+void v_blake_periodic(std::vector<uint64_t>& v) {
+    v.assign(256, 0);
+    for (int k = 0; k < 16; ++k) v[k * 16 + k] = 1;
+}
+const AirV V_AIRS[] = {
+    {FibAir::ID, FibAir::COLS, FibAir::PUB, FibAir::PERIODIC, FibAir::PERIOD_LOG, v_no_periodic, eval_host<FibAir>},
+    {MixAir::ID, MixAir::COLS, MixAir::PUB, MixAir::PERIODIC, MixAir::PERIOD_LOG, v_mix_periodic, eval_host<MixAir>},
+    {BlakeAir::ID, BlakeAir::COLS, BlakeAir::PUB, BlakeAir::PERIODIC, BlakeAir::PERIOD_LOG, v_blake_periodic, eval_host<BlakeAir>},
+};
+size_t brev(size_t x, int bits) {
+    size_t r = 0;
+    for (int i = 0; i < bits; ++i) r = (r << 1) | ((x >> i) & 1);
+    return r;
+}
+int32_t v_fail(char* err, size_t errlen, const char* fmt, ...) {
+    if (err && errlen) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(err, errlen, fmt, ap);
+        va_end(ap);
+    }
+    return VX_ERR_STATEMENT;
+}
+#define NEED(cond, ...) \
+    do {                \
+        if (!(cond)) return v_fail(err, errlen, __VA_ARGS__); \
+    } while (0)
+}  // namespace
+
+extern "C" {
+
+int32_t vx_stark_verify(const vx_stark_config* cfg, const uint64_t* pr, size_t len, int expect_air,
+                        const uint64_t* expect_public, size_t n_expect_public, char* err, size_t errlen) {
+    if (!cfg || !pr) return VX_ERR_ARG;
+    size_t pos = 0;
+    auto have = [&](size_t k) { return pos + k <= len; };
+    NEED(have(10), "proof truncated (header)");
+    NEED(pr[0] == 0x314b524154535856ULL, "bad magic");
+    const int air_id = (int)pr[1], L = (int)pr[2];
+    const size_t c = pr[3], nq = pr[4];
+    const int r = (int)pr[5], cap_h = (int)pr[6];
+    const size_t n_queries = pr[7];
+    const int pow_bits = (int)pr[8];
+    const size_t n_layers = pr[9];
+    pos = 10;
+    NEED(r == cfg->rate_bits && cap_h == cfg->cap_height && (int)n_queries == cfg->num_queries && pow_bits == cfg->pow_bits, "config mismatch");
+    NEED(L >= 2 && L <= 26 && n_layers <= 16, "bad shape");
+    const AirV* air = nullptr;
+    for (const AirV& a : V_AIRS)
+        if (a.id == air_id) air = &a;
+    NEED(air && (expect_air == 0 || expect_air == air_id), "unexpected AIR %d", air_id);
+    // FRI reduction plan (ConstantArityBits)
+    std::vector<int> arities;
+    {
+        int d = L;
+        while (d > cfg->final_poly_bits && d + r - cfg->arity_bits >= cap_h) {
+            arities.push_back(cfg->arity_bits);
+            d -= cfg->arity_bits;
+        }
+    }
+    NEED(have(n_layers + 2) && n_layers == arities.size(), "FRI plan mismatch");
+    for (size_t i = 0; i < n_layers; ++i) NEED((int)pr[pos + i] == arities[i], "FRI plan mismatch");
+    pos += n_layers;
+    const size_t final_len = pr[pos], n_pub = pr[pos + 1];
+    pos += 2;
+    const int LN = L + r;
+    const size_t n = (size_t)1 << L, N = (size_t)1 << LN;
+    int final_log = LN;
+    for (int a : arities) final_log -= a;
+    NEED(c == (size_t)air->cols && n_pub == (size_t)air->pub && nq == 4 && final_len == (((size_t)1 << final_log) >> r), "shape mismatch");
+    for (size_t i = 0; i < len; ++i) NEED(pr[i] < glh::P || i < pos, "non-canonical element at word %zu", i);
+    NEED(have(n_pub), "proof truncated (public inputs)");
+    const uint64_t* pub = pr + pos;
+    pos += n_pub;
+    if (expect_public) {
+        NEED(n_expect_public == n_pub, "public input count differs");
+        for (size_t i = 0; i < n_pub; ++i) NEED(pub[i] == expect_public[i], "public input %zu differs", i);
+    }
+    const size_t cap_words = (size_t)4 << cap_h;
+    NEED(have(2 * cap_words + 2 * (2 * c + nq)), "proof truncated (caps/openings)");
+    const uint64_t* cap_t = pr + pos;
+    const uint64_t* cap_q = pr + pos + cap_words;
+    pos += 2 * cap_words;
+    std::vector<Fx> o_local(c), o_next(c), o_quot(nq);
+    for (size_t j = 0; j < c; ++j) o_local[j] = {pr[pos + 2 * j], pr[pos + 2 * j + 1]};
+    pos += 2 * c;
+    for (size_t j = 0; j < c; ++j) o_next[j] = {pr[pos + 2 * j], pr[pos + 2 * j + 1]};
+    pos += 2 * c;
+    for (size_t j = 0; j < nq; ++j) o_quot[j] = {pr[pos + 2 * j], pr[pos + 2 * j + 1]};
+    pos += 2 * nq;
+
+    VChallenger ch;
+    ch.observe(pub, n_pub);
+    ch.observe(cap_t, cap_words);
+    const uint64_t alphas[2] = {ch.challenge(), ch.challenge()};
+    ch.observe(cap_q, cap_words);
+    const Fx zeta = ch.ext();
+    const uint64_t wn = glh::root(L), last = glh::inv(wn), ninv = glh::inv(n % glh::P);
+    const Fx zeta_next = zeta * Fx{wn, 0};
+    // ---- constraint identity at zeta
+    {
+        const Fx zn = fx_pow(zeta, n), one{1, 0};
+        const Fx zh = zn - one;
+        Consumer<Fx> cons;
+        cons.acc[0] = cons.acc[1] = {0, 0};
+        cons.alpha[0] = {alphas[0], 0};
+        cons.alpha[1] = {alphas[1], 0};
+        cons.z_last = zeta - Fx{last, 0};
+        cons.l_first = zh * Fx{ninv, 0} * fx_inv(zeta - one);
+        cons.l_last = zh * Fx{glh::mul(ninv, last), 0} * fx_inv(zeta - Fx{last, 0});
+        std::vector<Fx> per(air->periodic ? air->periodic : 1), pubx(n_pub ? n_pub : 1);
+        if (air->periodic) {
+            std::vector<uint64_t> pv;
+            air->periodic_values(pv);
+            const size_t p = (size_t)1 << air->period_log;
+            const Fx y = fx_pow(zeta, n >> air->period_log);
+            const uint64_t wp_inv = glh::inv(glh::root(air->period_log)), pinv = glh::inv(p % glh::P);
+            for (int j = 0; j < air->periodic; ++j) {
+                std::vector<uint64_t> coef(p);
+                for (size_t k = 0; k < p; ++k) {
+                    uint64_t acc = 0, w = glh::pow(wp_inv, k), cur = 1;
+                    for (size_t i = 0; i < p; ++i) {
+                        acc = glh::add(acc, glh::mul(pv[j * p + i], cur));
+                        cur = glh::mul(cur, w);
+                    }
+                    coef[k] = glh::mul(acc, pinv);
+                }
+                Fx a{0, 0};
+                for (size_t k = p; k-- > 0;) a = a * y + Fx{coef[k], 0};
+                per[j] = a;
+            }
+        }
+        for (size_t i = 0; i < n_pub; ++i) pubx[i] = {pub[i], 0};
+        HostRow loc{o_local.data()}, nxt{o_next.data()};
+        air->eval(loc, nxt, per.data(), pubx.data(), cons);
+        for (int k = 0; k < 2; ++k) {
+            const Fx q = o_quot[2 * k] + o_quot[2 * k + 1] * zn;
+            NEED(fx_eq(cons.acc[k], zh * q), "constraint identity fails at zeta (challenge %d)", k);
+        }
+    }
+    for (size_t j = 0; j < c; ++j) ch.observe(o_local[j].a), ch.observe(o_local[j].b);
+    for (size_t j = 0; j < nq; ++j) ch.observe(o_quot[j].a), ch.observe(o_quot[j].b);
+    for (size_t j = 0; j < c; ++j) ch.observe(o_next[j].a), ch.observe(o_next[j].b);
+    const Fx alpha = ch.ext();
+    std::vector<const uint64_t*> layer_caps;
+    std::vector<Fx> betas;
+    for (size_t l = 0; l < n_layers; ++l) {
+        NEED(have(cap_words), "proof truncated (FRI caps)");
+        layer_caps.push_back(pr + pos);
+        ch.observe(pr + pos, cap_words);
+        pos += cap_words;
+        betas.push_back(ch.ext());
+    }
+    NEED(have(2 * final_len + 1), "proof truncated (final poly)");
+    std::vector<Fx> fpoly(final_len);
+    for (size_t k = 0; k < final_len; ++k) {
+        fpoly[k] = {pr[pos + 2 * k], pr[pos + 2 * k + 1]};
+        ch.observe(fpoly[k].a), ch.observe(fpoly[k].b);
+    }
+    pos += 2 * final_len;
+    const uint64_t nonce = pr[pos++];
+    ch.observe(nonce);
+    const uint64_t resp = ch.challenge();
+    NEED(pow_bits == 0 || (resp >> (64 - pow_bits)) == 0, "proof of work invalid");
+    // reduced openings
+    Fx apow{1, 0}, y0{0, 0}, y1{0, 0};
+    for (size_t j = 0; j < c + nq; ++j) {
+        if (j < c) {
+            y0 = y0 + apow * o_local[j];
+            y1 = y1 + apow * o_next[j];
+        } else y0 = y0 + apow * o_quot[j - c];
+        apow = apow * alpha;
+    }
+    const Fx alpha_c = fx_pow(alpha, c);
+    const int depth0 = LN - cap_h;
+    const uint64_t wN = glh::root(LN);
+    for (size_t qi = 0; qi < n_queries; ++qi) {
+        size_t x_index = ch.challenge() % N;
+        NEED(have(c + nq + 8 * (size_t)depth0), "proof truncated (query %zu)", qi);
+        const uint64_t* row_t = pr + pos;
+        const uint64_t* sib_t = row_t + c;
+        const uint64_t* row_q = sib_t + 4 * depth0;
+        const uint64_t* sib_q = row_q + nq;
+        pos += c + nq + 8 * (size_t)depth0;
+        NEED(v_merkle(row_t, c, x_index, sib_t, depth0, cap_t), "trace Merkle proof invalid (query %zu)", qi);
+        NEED(v_merkle(row_q, nq, x_index, sib_q, depth0, cap_q), "quotient Merkle proof invalid (query %zu)", qi);
+        uint64_t x = glh::mul(7, glh::pow(wN, brev(x_index, LN)));
+        Fx s1{0, 0}, ap{1, 0};
+        for (size_t j = 0; j < c; ++j) {
+            s1 = s1 + ap * Fx{row_t[j], 0};
+            ap = ap * alpha;
+        }
+        Fx s0 = s1;
+        for (size_t j = 0; j < nq; ++j) {
+            s0 = s0 + ap * Fx{row_q[j], 0};
+            ap = ap * alpha;
+        }
+        Fx ev = alpha_c * (s0 - y0) * fx_inv(Fx{x, 0} - zeta) + (s1 - y1) * fx_inv(Fx{x, 0} - zeta_next);
+        int cur_log = LN;
+        for (size_t l = 0; l < n_layers; ++l) {
+            const int a = arities[l];
+            const size_t arity = (size_t)1 << a, within = x_index & (arity - 1);
+            const int depth = cur_log - a - cap_h;
+            NEED(have(2 * (arity - 1) + 4 * (size_t)depth), "proof truncated (query %zu layer %zu)", qi, l);
+            std::vector<uint64_t> leaf(2 * arity);
+            for (size_t t = 0, src = 0; t < arity; ++t) {
+                if (t == within) {
+                    leaf[2 * t] = ev.a, leaf[2 * t + 1] = ev.b;
+                } else {
+                    leaf[2 * t] = pr[pos + 2 * src], leaf[2 * t + 1] = pr[pos + 2 * src + 1];
+                    ++src;
+                }
+            }
+            pos += 2 * (arity - 1);
+            NEED(v_merkle(leaf.data(), 2 * arity, x_index >> a, pr + pos, depth, layer_caps[l]), "FRI layer %zu Merkle proof invalid (query %zu)", l, qi);
+            pos += 4 * (size_t)depth;
+            // compute_evaluation: interpolate the coset {x g^i} and evaluate at beta
+            const uint64_t g = glh::root(a);
+            std::vector<Fx> evn(arity);
+            for (size_t t = 0; t < arity; ++t) evn[brev(t, a)] = {leaf[2 * t], leaf[2 * t + 1]};
+            const uint64_t start = glh::mul(x, glh::pow(g, arity - brev(within, a)));
+            std::vector<uint64_t> pts(arity);
+            uint64_t gp = 1;
+            for (size_t t = 0; t < arity; ++t) {
+                pts[t] = glh::mul(start, gp);
+                gp = glh::mul(gp, g);
+            }
+            Fx acc{0, 0};
+            for (size_t i = 0; i < arity; ++i) {
+                Fx num{1, 0};
+                uint64_t den = 1;
+                for (size_t j = 0; j < arity; ++j) {
+                    if (j == i) continue;
+                    num = num * (betas[l] - Fx{pts[j], 0});
+                    den = glh::mul(den, glh::sub(pts[i], pts[j]));
+                }
+                acc = acc + evn[i] * num * Fx{glh::inv(den), 0};
+            }
+            ev = acc;
+            x = glh::pow(x, arity);
+            x_index >>= a;
+            cur_log -= a;
+        }
+        Fx fp{0, 0};
+        for (size_t k = final_len; k-- > 0;) fp = fp * Fx{x, 0} + fpoly[k];
+        NEED(fx_eq(fp, ev), "final polynomial evaluation mismatch (query %zu)", qi);
+    }
+    NEED(pos == len, "trailing data in proof (%zu of %zu words used)", pos, len);
+    return VX_OK;
+}
+
+int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob, size_t len, uint32_t max_headers,
+                               uint32_t trusted_block, const uint8_t trusted_hash[32], uint32_t target_block,
+                               const uint8_t out96[96], char* err, size_t errlen) {
+    if (!cfg || !blob || !trusted_hash || !out96) return VX_ERR_ARG;
+    NEED(len > 16 && blob[0] == 0x3145474e41525248ULL, "bad header_range blob");
+    NEED(blob[1] == max_headers && blob[2] == trusted_block && blob[3] == target_block, "blob is for a different request");
+    NEED(memcmp(blob + 4, out96, 96) == 0, "public outputs differ from the blob");
+    uint64_t pub[16];
+    for (int j = 0; j < 8; ++j) {
+        uint32_t a, b;
+        memcpy(&a, trusted_hash + 4 * j, 4);
+        memcpy(&b, out96 + 4 * j, 4);  // target_header_hash = first 32 output bytes
+        pub[j] = a;
+        pub[8 + j] = b;
+    }
+    return vx_stark_verify(cfg, blob + 16, len - 16, VX_AIR_BLAKE_CHAIN, pub, 16, err, errlen);
+}
+}

@@ -22,7 +22,7 @@ SYMBOLS = [
     "vx_ntt", "vx_lde", "vx_lde_rows",
     "vx_poseidon_permute_batch", "vx_merkle_build", "vx_merkle_free", "vx_merkle_cap", "vx_merkle_open", "vx_merkle_leaf_digests",
     "vx_fri_fold", "vx_fri_layer_tree", "vx_fri_leaves", "vx_fri_pow",
-    "vx_stark_default_config", "vx_stark_proof_bound", "vx_stark_prove", "vx_header_range_proof_bound", "vx_header_range_prove",
+    "vx_stark_default_config", "vx_stark_proof_bound", "vx_stark_prove", "vx_stark_verify", "vx_header_range_proof_bound", "vx_header_range_prove", "vx_header_range_verify",
     "vx_blake2b_256_batch", "vx_sha256_pairs", "vx_verify_subchain", "vx_blake_chain_trace",
 ]
 
@@ -81,6 +81,8 @@ def load_library():
         "vx_stark_proof_bound": [C.c_int, C.POINTER(StarkConfig), C.c_int, C.POINTER(sz)],
         "vx_header_range_proof_bound": [C.POINTER(StarkConfig), sz, C.POINTER(sz)],
         "vx_header_range_prove": [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.POINTER(StarkConfig), vp, vp, sz, C.POINTER(sz)],
+        "vx_stark_verify": [C.POINTER(StarkConfig), vp, sz, C.c_int, vp, sz, C.c_char_p, sz],
+        "vx_header_range_verify": [C.POINTER(StarkConfig), vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, C.c_char_p, sz],
         "vx_stark_prove": [vp, C.c_int, C.POINTER(StarkConfig), vp, C.c_int, vp, sz, vp, sz, C.POINTER(sz)],
         "vx_blake2b_256_batch": [vp, vp, sz, vp, sz, vp], "vx_sha256_pairs": [vp, vp, sz, vp],
         "vx_verify_subchain": [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp],
@@ -99,6 +101,38 @@ def load_library():
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def default_stark_config(**over):
+    cfg = StarkConfig()
+    load_library().vx_stark_default_config(C.byref(cfg))
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def stark_verify(proof, cfg=None, expect_air=0, expect_public=None):
+    """Host-side verification (no GPU needed).  Raises VxError(VX_ERR_STATEMENT) with the reason."""
+    L = load_library()
+    cfg = cfg or default_stark_config()
+    pr = np.ascontiguousarray(proof, dtype=np.uint64)
+    pub = None if expect_public is None else np.ascontiguousarray(expect_public, dtype=np.uint64)
+    err = C.create_string_buffer(256)
+    rc = L.vx_stark_verify(C.byref(cfg), _ptr(pr), pr.size, expect_air, None if pub is None else _ptr(pub), 0 if pub is None else pub.size, err, 256)
+    if rc != 0:
+        raise VxError(rc, err.value.decode())
+
+
+def header_range_verify(blob, max_headers, trusted_block, trusted_hash, target_block, out96, cfg=None):
+    L = load_library()
+    cfg = cfg or default_stark_config()
+    b = np.ascontiguousarray(blob, dtype=np.uint64)
+    th = np.frombuffer(bytes(trusted_hash), dtype=np.uint8).copy()
+    o = np.frombuffer(bytes(out96), dtype=np.uint8).copy()
+    err = C.create_string_buffer(256)
+    rc = L.vx_header_range_verify(C.byref(cfg), _ptr(b), b.size, max_headers, trusted_block, _ptr(th), target_block, _ptr(o), err, 256)
+    if rc != 0:
+        raise VxError(rc, err.value.decode())
 
 
 class Buffer:

@@ -132,7 +132,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("VX_BENCH_FORCE_DIST"):  # the env override exercises the RCCL path on one GPU
         import torch
         import torch.distributed as dist_mod
 

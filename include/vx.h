@@ -165,6 +165,11 @@ int32_t vx_stark_proof_bound(int air_id, const vx_stark_config* cfg, int log_n, 
 int32_t vx_stark_prove(vx_ctx* ctx, int air_id, const vx_stark_config* cfg, const vx_buf* trace, int log_n,
                        const uint64_t* public_inputs, size_t n_public, uint64_t* proof_out, size_t proof_cap,
                        size_t* proof_len);
+/* `circuit.verify` (circuits/header_range.rs:170): host-side verification of a proof produced by
+ * vx_stark_prove.  expect_air 0 = any; expect_public may be NULL.  VX_OK, or VX_ERR_STATEMENT with
+ * a reason written to err (optional buffer).  Needs no GPU and no ctx. */
+int32_t vx_stark_verify(const vx_stark_config* cfg, const uint64_t* proof, size_t proof_len, int expect_air,
+                        const uint64_t* expect_public, size_t n_expect_public, char* err, size_t errlen);
 
 /* ---- K8: witness hashing for the header chain
  * (plonky2x curta_blake2b_variable via circuits/builder/header.rs:14-19; SimpleMerkleTree /
@@ -209,6 +214,11 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
                               uint32_t max_headers, uint32_t trusted_block, const uint8_t trusted_hash[32],
                               uint32_t target_block, const vx_stark_config* cfg, uint8_t out96[96], uint64_t* proof_out,
                               size_t proof_cap, size_t* proof_len);
+/* HeaderRangeCircuit verify: checks the blob of vx_header_range_prove against the request
+ * (blocks, trusted hash) and the claimed 96 output bytes, then verifies the STARK. */
+int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob, size_t blob_len, uint32_t max_headers,
+                               uint32_t trusted_block, const uint8_t trusted_hash[32], uint32_t target_block,
+                               const uint8_t out96[96], char* err, size_t errlen);
 
 #ifdef __cplusplus
 }

@@ -97,3 +97,22 @@ def test_header_range_prove_end_to_end(ctx, vx, oracle):
     with pytest.raises(vx.VxError) as e:
         ctx.header_range_prove(ctx.from_host(h), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
     assert e.value.code == -5
+
+
+def test_product_verifier_on_gpu_proofs(ctx, vx):
+    """prove on the GPU, verify with the product's host verifier (circuit.prove / circuit.verify pair)."""
+    ch = vx.synth.Chain(16, profile="Ptiny", stride=512)
+    cfg = ctx.stark_config(num_queries=12)
+    out96, blob = ctx.header_range_prove(ctx.from_host(ch.headers), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
+    vx.lib.header_range_verify(blob, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg)
+    with pytest.raises(vx.VxError):  # wrong request
+        vx.lib.header_range_verify(blob, 16, ch.trusted_block, bytes(32), ch.target_block, out96, cfg)
+    with pytest.raises(vx.VxError):  # wrong claimed output
+        vx.lib.header_range_verify(blob, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, bytes(32) + out96[32:], cfg)
+    bad = blob.copy()
+    bad[len(bad) // 2] ^= np.uint64(1)
+    with pytest.raises(vx.VxError):
+        vx.lib.header_range_verify(bad, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg)
+    for air, log_n in ((S.FibAir, 12), (S.MixAir, 13)):
+        trace, pub = air.trace(log_n)
+        vx.lib.stark_verify(ctx.stark_prove(air.ID, ctx.from_host(trace), log_n, pub), expect_air=air.ID, expect_public=pub)
