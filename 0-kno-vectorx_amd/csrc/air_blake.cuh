@@ -8,7 +8,7 @@
 //   G evaluations), r = 13 FIN1 (T = H ^ v_lo, V' = v_hi), r = 14 FIN2 (H = T ^ V' = h_out),
 //   r = 15 PAD (H = next h_in, digest register D updated).
 // Columns: 8 G x 8 words x 64 bits, 64 carries, 32 message-schedule limbs, 64 range-check bits,
-// H register (512 bits), digest register D (8 limbs), flags and byte counter.
+// H register (512 bits), digest register D (8 limbs), flags, byte counter, block number.
 // Constraint ORDER is protocol: oracle/blake_air.py restates it independently.
 #pragma once
 #include "air.cuh"
@@ -17,7 +17,7 @@
 namespace blk {
 constexpr int W_A1 = 0, W_D1 = 1, W_C1 = 2, W_B1 = 3, W_A2 = 4, W_D2 = 5, W_C2 = 6, W_B2 = 7;
 constexpr int CAR0 = 4096, MS0 = 4160, MB0 = 4192, H0 = 4256, D0 = 4768;
-constexpr int ACT = 4776, FIN = 4777, FIRST = 4778, CAP = 4779, T = 4780, INC = 4781, TB0 = 4782, IB0 = 4814, COLS = 4822;
+constexpr int ACT = 4776, FIN = 4777, FIRST = 4778, CAP = 4779, T = 4780, INC = 4781, TB0 = 4782, IB0 = 4814, NUM = 4822, FA = 4823, COLS = 4824;
 VX_HD constexpr int GB(int k, int w, int i) { return (k * 8 + w) * 64 + i; }
 VX_HD constexpr int CAR(int k, int j) { return CAR0 + k * 8 + j; }
 VX_HD constexpr int MS(int s, int h) { return MS0 + 2 * s + h; }
@@ -51,7 +51,7 @@ VX_HD int rc_slot(int r) { return RC_SLOT_H[r]; }
 }  // namespace blk
 
 struct BlakeAir {
-    static constexpr int ID = 3, COLS = blk::COLS, PUB = 16, PERIODIC = 16, PERIOD_LOG = 4;
+    static constexpr int ID = 3, COLS = blk::COLS, PUB = 18, PERIODIC = 16, PERIOD_LOG = 4;
 
     template <class F, class Row, class C>
     __host__ __device__ static void eval(const Row& loc, const Row& nxt, const F* sel, const F* pub, C& c) {
@@ -86,6 +86,7 @@ struct BlakeAir {
         boolean(FIN);
         boolean(FIRST);
         boolean(CAP);
+        boolean(FA);
         // ---- 2. carries
 #pragma unroll 1
         for (int k = 0; k < 8; ++k)
@@ -196,14 +197,18 @@ struct BlakeAir {
         for (int s = 0; s < 4; ++s)
 #pragma unroll 1
             for (int h = 0; h < 2; ++h) c.constraint(sel[0] * first * (loc[MS(s, h)] - loc[D0 + 2 * s + h]));
+        // block number: bytes 32..36 = SCALE compact int, 4-byte mode: 4 * number + 2 (decoder.rs:64-66)
+        c.constraint(sel[0] * first * (loc[MS(4, 0)] - (F::from(4) * loc[NUM] + two)));
         // ---- 7. per-block registers
         const F in_block = one - sel[15];
         {
-            const int regs[6] = {ACT, FIN, FIRST, CAP, T, INC};
+            const int regs[8] = {ACT, FIN, FIRST, CAP, T, INC, NUM, FA};
 #pragma unroll 1
-            for (int q = 0; q < 6; ++q) c.constraint(in_block * (nxt[regs[q]] - loc[regs[q]]));
+            for (int q = 0; q < 8; ++q) c.constraint(in_block * (nxt[regs[q]] - loc[regs[q]]));
         }
         c.constraint(loc[CAP] - loc[ACT] * fin);
+        c.constraint(loc[FA] - first * loc[ACT]);
+        c.transition(sel[15] * (nxt[NUM] - loc[NUM] - nxt[FA]));  // sequential numbers (subchain_verification.rs:166-168)
         c.constraint(sel[15] * (nxt[FIRST] - fin));
         c.constraint(sel[15] * (nxt[T] - (one - fin) * loc[T] - nxt[INC]));
         {
@@ -233,5 +238,7 @@ struct BlakeAir {
 #pragma unroll 1
         for (int j = 0; j < 8; ++j) c.last_row(loc[D0 + j] - pub[8 + j]);
         c.last_row(fin - one);
+        c.first_row(loc[NUM] - pub[16]);
+        c.last_row(loc[NUM] - pub[17]);
     }
 };

@@ -17,7 +17,7 @@ struct BlockDesc {
     uint32_t t, inc;
     uint32_t D[8];     // digest register before this block
     uint8_t fin, first, act, pad;
-    uint32_t pad2;
+    uint32_t num;      // block number of the header this chunk belongs to
 };
 
 __device__ __forceinline__ uint64_t b_rotr(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const 
         for (int k = 0; k < 8; ++k) h[k] = IV[k];
         h[0] ^= 0x01010020ULL;
         for (int k = 0; k < 16; ++k) m[k] = k < 4 ? ((uint64_t)d.D[2 * k] | ((uint64_t)d.D[2 * k + 1] << 32)) : 0;
+        m[4] = 4ULL * d.num + 2;  // bytes 32..36: SCALE compact (4-byte mode) of the last block number
     }
     // ---- G area (columns 0 .. 4159): zero unless this row uses it
     GRec rec[8];
@@ -179,6 +180,8 @@ __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const 
     tr[(size_t)CAP * n + row] = cap ? 1 : 0;
     tr[(size_t)T * n + row] = d.t;
     tr[(size_t)INC * n + row] = d.inc;
+    tr[(size_t)NUM * n + row] = d.num;
+    tr[(size_t)FA * n + row] = (d.first && d.act) ? 1 : 0;
     put_bits(tr, n, row, TB0, d.t, 32);
     put_bits(tr, n, row, IB0, d.inc, 8);
 }
@@ -186,18 +189,20 @@ __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const 
 extern "C" {
 
 int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_headers,
-                             const uint8_t trusted_hash[32], int log_n, vx_buf* trace_out, uint64_t public_inputs_out[16],
-                             uint8_t* digests_out) {
+                             const uint8_t trusted_hash[32], uint32_t first_block_number, int log_n, vx_buf* trace_out,
+                             uint64_t public_inputs_out[18], uint8_t* digests_out) {
     if (!ctx || !headers || !sizes || !trusted_hash || !trace_out || !public_inputs_out) return VX_ERR_ARG;
     VX_CHECK(stride % 128 == 0 && stride > 0, "blake trace: stride %zu must be a positive multiple of 128", stride);
     VX_CHECK(n_headers >= 1 && n_headers * stride <= headers->n * 8, "blake trace: headers exceed the buffer");
     VX_CHECK(log_n >= 4 && log_n <= 24, "blake trace: log_n %d out of range", log_n);
+    VX_CHECK(first_block_number >= (1u << 14) && (uint64_t)first_block_number + n_headers <= (1u << 30),
+             "blake trace: block numbers %u.. are outside the 4-byte SCALE compact range [2^14, 2^30) this AIR covers", first_block_number);
     const size_t n = (size_t)1 << log_n, n_blocks = n >> 4;
     VX_CHECK(trace_out->n >= n * blk::COLS, "blake trace: trace buffer holds %zu < %zu elements", trace_out->n, n * (size_t)blk::COLS);
     std::vector<uint32_t> base(n_headers);
     size_t n_real = 0;
     for (size_t i = 0; i < n_headers; ++i) {
-        VX_CHECK(sizes[i] <= stride && sizes[i] >= 32, "blake trace: header %zu has size %u", i, sizes[i]);
+        VX_CHECK(sizes[i] <= stride && sizes[i] >= 36, "blake trace: header %zu has size %u", i, sizes[i]);
         base[i] = (uint32_t)n_real;
         n_real += (sizes[i] + 127) / 128;
     }
@@ -236,6 +241,7 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
             d.inc = d.fin ? sizes[i] - 128 * cidx : 128;
             d.t = d.fin ? sizes[i] : 128 * (cidx + 1);
             d.msg_off = i * stride + 128 * (size_t)cidx;
+            d.num = first_block_number + (uint32_t)i;
             memcpy(d.D, D, 32);
         }
         memcpy(D, dig.data() + 32 * i, 32);
@@ -245,8 +251,9 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
         memset(&d, 0, sizeof d);
         d.fin = d.first = 1;
         d.act = 0;
-        d.inc = d.t = 32;
+        d.inc = d.t = 36;
         d.msg_off = ~0ULL;
+        d.num = first_block_number + (uint32_t)n_headers - 1;
         memcpy(d.D, D, 32);
     }
     VX_HIP(hipMemcpyAsync(d_desc, descs.data(), n_blocks * sizeof(BlockDesc), hipMemcpyHostToDevice, ctx->stream));
@@ -261,6 +268,8 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
         public_inputs_out[j] = a;
         public_inputs_out[8 + j] = b;
     }
+    public_inputs_out[16] = first_block_number;
+    public_inputs_out[17] = first_block_number + (uint64_t)n_headers - 1;
     if (digests_out) memcpy(digests_out, dig.data(), dig.size());
     return VX_OK;
 }
@@ -291,8 +300,8 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
     while (((size_t)1 << log_n) < 16 * chunks) ++log_n;
     vx_buf* trace = nullptr;
     VX_TRY(vx_alloc(ctx, ((size_t)blk::COLS) << log_n, &trace));
-    uint64_t pub[16];
-    int32_t rc = vx_blake_chain_trace(ctx, headers, stride, sizes, n_fetched, trusted_hash, log_n, trace, pub, nullptr);
+    uint64_t pub[18];
+    int32_t rc = vx_blake_chain_trace(ctx, headers, stride, sizes, n_fetched, trusted_hash, trusted_block + 1, log_n, trace, pub, nullptr);
     size_t plen = 0;
     if (rc == VX_OK) {
         uint8_t tgt[32];
@@ -303,7 +312,7 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
         if (memcmp(tgt, out96, 32) != 0) rc = vx_fail(ctx, VX_ERR_STATEMENT, "header_range: chain digest differs from the subchain target hash");
     }
     if (rc == VX_OK)
-        rc = vx_stark_prove(ctx, VX_AIR_BLAKE_CHAIN, cfg, trace, log_n, pub, 16, proof_out && proof_cap > 16 ? proof_out + 16 : nullptr,
+        rc = vx_stark_prove(ctx, VX_AIR_BLAKE_CHAIN, cfg, trace, log_n, pub, 18, proof_out && proof_cap > 16 ? proof_out + 16 : nullptr,
                             proof_cap > 16 ? proof_cap - 16 : 0, &plen);
     (void)vx_free(ctx, trace);
     *proof_len = plen + 16;

@@ -377,7 +377,8 @@ int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob,
     NEED(len > 16 && blob[0] == 0x3145474e41525248ULL, "bad header_range blob");
     NEED(blob[1] == max_headers && blob[2] == trusted_block && blob[3] == target_block, "blob is for a different request");
     NEED(memcmp(blob + 4, out96, 96) == 0, "public outputs differ from the blob");
-    uint64_t pub[16];
+    NEED(target_block > trusted_block, "empty block range");
+    uint64_t pub[18];
     for (int j = 0; j < 8; ++j) {
         uint32_t a, b;
         memcpy(&a, trusted_hash + 4 * j, 4);
@@ -385,6 +386,8 @@ int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob,
         pub[j] = a;
         pub[8 + j] = b;
     }
-    return vx_stark_verify(cfg, blob + 16, len - 16, VX_AIR_BLAKE_CHAIN, pub, 16, err, errlen);
+    pub[16] = (uint64_t)trusted_block + 1;
+    pub[17] = target_block;
+    return vx_stark_verify(cfg, blob + 16, len - 16, VX_AIR_BLAKE_CHAIN, pub, 18, err, errlen);
 }
 }

@@ -27,7 +27,7 @@ SYMBOLS = [
 ]
 
 VX_AIR_FIBONACCI, VX_AIR_MIX, VX_AIR_BLAKE_CHAIN = 1, 2, 3
-VX_BLAKE_AIR_COLS = 4822
+VX_BLAKE_AIR_COLS = 4824
 
 
 class StarkConfig(C.Structure):
@@ -86,7 +86,7 @@ def load_library():
         "vx_stark_prove": [vp, C.c_int, C.POINTER(StarkConfig), vp, C.c_int, vp, sz, vp, sz, C.POINTER(sz)],
         "vx_blake2b_256_batch": [vp, vp, sz, vp, sz, vp], "vx_sha256_pairs": [vp, vp, sz, vp],
         "vx_verify_subchain": [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp],
-        "vx_blake_chain_trace": [vp, vp, sz, vp, sz, vp, C.c_int, vp, vp, vp],
+        "vx_blake_chain_trace": [vp, vp, sz, vp, sz, vp, C.c_uint32, C.c_int, vp, vp, vp],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -342,13 +342,13 @@ class Context:
         self._ck(self.L.vx_sha256_pairs(self.h, _ptr(p), p.shape[0], _ptr(out)))
         return out
 
-    def blake_chain_trace(self, headers_buf, stride, sizes, trusted_hash, log_n, trace_buf=None):
+    def blake_chain_trace(self, headers_buf, stride, sizes, trusted_hash, first_block_number, log_n, trace_buf=None):
         sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
         th = np.frombuffer(bytes(trusted_hash), dtype=np.uint8).copy()
         trace_buf = trace_buf or self.alloc(VX_BLAKE_AIR_COLS << log_n)
-        pub = np.zeros(16, dtype=np.uint64)
+        pub = np.zeros(18, dtype=np.uint64)
         dig = np.zeros((sizes.size, 32), dtype=np.uint8)
-        self._ck(self.L.vx_blake_chain_trace(self.h, headers_buf.h, stride, _ptr(sizes), sizes.size, _ptr(th), log_n, trace_buf.h, _ptr(pub), _ptr(dig)))
+        self._ck(self.L.vx_blake_chain_trace(self.h, headers_buf.h, stride, _ptr(sizes), sizes.size, _ptr(th), first_block_number, log_n, trace_buf.h, _ptr(pub), _ptr(dig)))
         return trace_buf, pub, dig
 
     def verify_subchain(self, headers_buf, stride, sizes, max_headers, trusted_block, trusted_hash, target_block):

@@ -35,7 +35,7 @@ PROFILE = "P15k"
 # 30,720 compressions x 16 rows -> 2^19 rows, 4822 columns), measured on a 1024-column slab.
 NTT_LOG_N = 19
 NTT_COLS = 1024
-BLAKE_COLS = 4822
+BLAKE_COLS = 4824
 
 
 class Workload:
@@ -184,7 +184,7 @@ def main():
                             f"30,720 Blake2b compressions -> BlakeChainAir trace 2^19 rows x {BLAKE_COLS} columns",
                 "complete_proof": False,
                 "stages": ["verify_subchain: Blake2b header hashes, SCALE decode, link + numbering checks, SHA-256 Merkle roots -> 96-B output (native on GPU)",
-                           "BlakeChainAir witness: chaining values + 2^19 x 4822 trace generated on the GPU",
+                           "BlakeChainAir witness: chaining values + 2^19 x 4824 trace generated on the GPU",
                            "STARK prove (starky-style, rate_bits 1, cap 4, 84 queries, 16 PoW bits): LDE + Poseidon Merkle caps, quotient, openings, "
                            "FRI batch/fold/PoW/queries, proof bytes"],
                 "missing": ["SHA-256 Merkle-root / header-decoding / block-numbering AIRs (checked natively, not yet in a STARK)",

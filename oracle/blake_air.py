@@ -35,8 +35,9 @@ D0 = 4768
 ACT, FIN, FIRST, CAP, T, INC = 4776, 4777, 4778, 4779, 4780, 4781
 TB0 = 4782
 IB0 = 4814
-COLS = 4822
-PUB = 16
+NUM, FA = 4822, 4823  # block number of the current header; FA = FIRST * ACT
+COLS = 4824
+PUB = 18
 PERIODIC = 16
 PERIOD_LOG = 4
 
@@ -108,13 +109,17 @@ def rotr(x, n):
     return ((x >> n) | (x << (64 - n))) & M64
 
 
-def gen_blocks(messages, n_blocks, trusted_hash):
-    """Block descriptors for the given messages (each must start with the previous digest)."""
+def gen_blocks(messages, n_blocks, trusted_hash, first_number):
+    """Block descriptors for the given messages (each must start with the previous digest and carry
+    its block number as a 4-byte SCALE compact int at bytes 32..36)."""
     import hashlib
 
     blocks, D = [], trusted_hash
+    num = first_number - 1
     for msg in messages:
         assert msg[:32] == D, "message does not link to the previous digest"
+        num += 1
+        assert int.from_bytes(msg[32:36], "little") == 4 * num + 2, "block number is not the 4-byte compact encoding of the expected number"
         h = list(IVP)
         nchunks = max(1, (len(msg) + 127) // 128)
         t = 0
@@ -123,14 +128,14 @@ def gen_blocks(messages, n_blocks, trusted_hash):
             fin = c == nchunks - 1
             inc = len(chunk) if fin else 128
             t += inc
-            blocks.append(dict(m=chunk + bytes(128 - len(chunk)), h=list(h), t=t, inc=inc, fin=fin, first=c == 0, act=1, D=D))
+            blocks.append(dict(m=chunk + bytes(128 - len(chunk)), h=list(h), t=t, inc=inc, fin=fin, first=c == 0, act=1, D=D, num=num))
             h = compress(h, blocks[-1]["m"], t, fin)[0]
         D = hashlib.blake2b(msg, digest_size=32).digest()
         assert b"".join(x.to_bytes(8, "little") for x in h[:4]) == D
     assert len(blocks) <= n_blocks, f"{len(blocks)} compressions do not fit {n_blocks} blocks"
-    while len(blocks) < n_blocks:  # padding: inactive one-chunk messages that still satisfy the link rule
-        blocks.append(dict(m=D + bytes(96), h=list(IVP), t=32, inc=32, fin=True, first=True, act=0, D=D))
-    return blocks, D
+    while len(blocks) < n_blocks:  # padding: inactive one-chunk messages that still satisfy the link + number rules
+        blocks.append(dict(m=D + (4 * num + 2).to_bytes(4, "little") + bytes(92), h=list(IVP), t=36, inc=36, fin=True, first=True, act=0, D=D, num=num))
+    return blocks, D, num
 
 
 def compress(h, m_bytes, t, fin):
@@ -168,10 +173,12 @@ def compress(h, m_bytes, t, fin):
     return h_out, recs, v0, m
 
 
-def gen_trace(messages, log_n, trusted_hash):
-    """Full trace [COLS][n] (uint64) + public inputs (16 limbs: trusted, target)."""
+def gen_trace(messages, log_n, trusted_hash, first_number=None):
+    """Full trace [COLS][n] (uint64) + public inputs (trusted / target hash limbs, first / last number)."""
     n = 1 << log_n
-    blocks, target = gen_blocks(messages, n // 16, trusted_hash)
+    if first_number is None:
+        first_number = (int.from_bytes(messages[0][32:36], "little") - 2) // 4
+    blocks, target, last_number = gen_blocks(messages, n // 16, trusted_hash, first_number)
     tr = np.zeros((COLS, n), dtype=np.uint64)
 
     def put_bits(row, col0, val, nbits=64):
@@ -193,6 +200,7 @@ def gen_trace(messages, log_n, trusted_hash):
             # flags / registers
             tr[ACT, row], tr[FIN, row], tr[FIRST, row], tr[CAP, row] = blk["act"], int(blk["fin"]), int(blk["first"]), int(cap)
             tr[T, row], tr[INC, row] = blk["t"], blk["inc"]
+            tr[NUM, row], tr[FA, row] = blk["num"], int(blk["first"] and blk["act"])
             put_bits(row, TB0, blk["t"], 32)
             put_bits(row, IB0, blk["inc"], 8)
             dl = digest_limbs if (r == 15 and cap) else d_limbs
@@ -237,7 +245,7 @@ def gen_trace(messages, log_n, trusted_hash):
                     put_bits(row, GB(w % 4, w // 4, 0), blk["h"][w] ^ vfin[w])
                     put_bits(row, GB(w % 4, 2 + w // 4, 0), vfin[8 + w])
     lt, lg = [int.from_bytes(trusted_hash[4 * j: 4 * j + 4], "little") for j in range(8)], [int.from_bytes(target[4 * j: 4 * j + 4], "little") for j in range(8)]
-    return tr, lt + lg, target
+    return tr, lt + lg + [first_number, last_number], target
 
 
 # ----------------------------------------------------------------------------- constraints
@@ -266,7 +274,7 @@ class BlakeChainAir:
         # ---- 1. booleans
         for col in range(0, 4096):
             c.constraint(loc[col] * (loc[col] - 1))
-        for col in list(range(MB0, MB0 + 64)) + list(range(H0, H0 + 512)) + list(range(TB0, TB0 + 32)) + list(range(IB0, IB0 + 8)) + [ACT, FIN, FIRST, CAP]:
+        for col in list(range(MB0, MB0 + 64)) + list(range(H0, H0 + 512)) + list(range(TB0, TB0 + 32)) + list(range(IB0, IB0 + 8)) + [ACT, FIN, FIRST, CAP, FA]:
             c.constraint(loc[col] * (loc[col] - 1))
         # ---- 2. carries
         for k in range(8):
@@ -359,11 +367,15 @@ class BlakeChainAir:
         for s in range(4):
             for h in range(2):
                 c.constraint(sel[0] * loc[FIRST] * (loc[MS(s, h)] - loc[D0 + 2 * s + h]))
+        # block number: bytes 32..36 of a header = SCALE compact, 4-byte mode: 4 * number + 2 (decoder.rs:64-66)
+        c.constraint(sel[0] * loc[FIRST] * (loc[MS(4, 0)] - (4 * loc[NUM] + 2)))
         # ---- 7. per-block registers
         in_block = 1 - sel[15]
-        for col in (ACT, FIN, FIRST, CAP, T, INC):
+        for col in (ACT, FIN, FIRST, CAP, T, INC, NUM, FA):
             c.constraint(in_block * (nxt[col] - loc[col]))
         c.constraint(loc[CAP] - loc[ACT] * loc[FIN])
+        c.constraint(loc[FA] - loc[FIRST] * loc[ACT])
+        c.transition(sel[15] * (nxt[NUM] - loc[NUM] - nxt[FA]))  # numbers are sequential (subchain_verification.rs:166-168)
         c.constraint(sel[15] * (nxt[FIRST] - loc[FIN]))
         c.constraint(sel[15] * (nxt[T] - (1 - loc[FIN]) * loc[T] - nxt[INC]))
         tb = loc[TB0 + 31]
@@ -386,6 +398,8 @@ class BlakeChainAir:
         for j in range(8):
             c.last_row(loc[D0 + j] - pub[8 + j])
         c.last_row(loc[FIN] - 1)
+        c.first_row(loc[NUM] - pub[16])
+        c.last_row(loc[NUM] - pub[17])
 
 
 def first_violation(tr, pub, rows=None):

@@ -19,7 +19,7 @@ def chain_msgs(ch):
 @pytest.mark.parametrize("n_headers,log_n", [(1, 6), (2, 7), (5, 9)])
 def test_trace_matches_oracle(ctx, vx, n_headers, log_n):
     ch = vx.synth.Chain(n_headers, profile="Ptiny", stride=512)
-    buf, pub, dig = ctx.blake_chain_trace(ctx.from_host(ch.headers), 512, ch.sizes, ch.trusted_hash, log_n)
+    buf, pub, dig = ctx.blake_chain_trace(ctx.from_host(ch.headers), 512, ch.sizes, ch.trusted_hash, ch.trusted_block + 1, log_n)
     want, wpub, target = B.gen_trace(chain_msgs(ch), log_n, ch.trusted_hash)
     got = buf.download().reshape(B.COLS, 1 << log_n)
     bad = np.argwhere(got != want)
@@ -32,15 +32,15 @@ def test_edge_sizes_trace(ctx, vx):
     """Chunk-boundary lengths: 128 (one full final chunk), 129, 255, 256, 257 and the 32-byte minimum."""
     trusted = hashlib.sha256(b"edge").digest()
     msgs, d = [], trusted
-    for n in (128, 129, 255, 256, 257, 32, 33):
-        m = d + bytes((7 * i + n) & 0xFF for i in range(n - 32))
+    for k, n in enumerate((128, 129, 255, 256, 257, 36, 37)):
+        m = d + (4 * (50000 + k) + 2).to_bytes(4, "little") + bytes((7 * i + n) & 0xFF for i in range(n - 36))
         msgs.append(m)
         d = hashlib.blake2b(m, digest_size=32).digest()
     hdr = np.zeros((len(msgs), 384), dtype=np.uint8)
     for i, m in enumerate(msgs):
         hdr[i, : len(m)] = np.frombuffer(m, dtype=np.uint8)
     sizes = [len(m) for m in msgs]
-    buf, pub, dig = ctx.blake_chain_trace(ctx.from_host(hdr), 384, sizes, trusted, 8)
+    buf, pub, dig = ctx.blake_chain_trace(ctx.from_host(hdr), 384, sizes, trusted, 50000, 8)
     want, wpub, target = B.gen_trace(msgs, 8, trusted)
     assert (buf.download().reshape(B.COLS, 256) == want).all() and dig[-1].tobytes() == d == target
 
@@ -48,7 +48,7 @@ def test_edge_sizes_trace(ctx, vx):
 def test_proof_bytes_and_verification(ctx, vx, oracle):
     ch = vx.synth.Chain(2, profile="Ptiny", stride=512)
     log_n = 7
-    buf, pub, _ = ctx.blake_chain_trace(ctx.from_host(ch.headers), 512, ch.sizes, ch.trusted_hash, log_n)
+    buf, pub, _ = ctx.blake_chain_trace(ctx.from_host(ch.headers), 512, ch.sizes, ch.trusted_hash, ch.trusted_block + 1, log_n)
     got = ctx.stark_prove(B.ID, buf, log_n, pub)
     trace, wpub, _ = B.gen_trace(chain_msgs(ch), log_n, ch.trusted_hash)
     want = S.prove(B.BlakeChainAir, trace, wpub)
@@ -60,12 +60,12 @@ def test_larger_chain_verifies_and_forgeries_fail(ctx, vx, oracle):
     ch = vx.synth.Chain(16, profile="Ptiny", stride=512)
     log_n = 10
     hb = ctx.from_host(ch.headers)
-    buf, pub, _ = ctx.blake_chain_trace(hb, 512, ch.sizes, ch.trusted_hash, log_n)
+    buf, pub, _ = ctx.blake_chain_trace(hb, 512, ch.sizes, ch.trusted_hash, ch.trusted_block + 1, log_n)
     proof = ctx.stark_prove(B.ID, buf, log_n, pub, ctx.stark_config(num_queries=20))
     cfg = dict(S.DEFAULT_CFG, num_queries=20)
     info = S.verify(proof, cfg, expect_air=B.ID)
     limbs = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "little") for j in range(8)]  # noqa: E731
-    assert info["public_inputs"] == limbs(ch.trusted_hash) + limbs(ch.target_hash)
+    assert info["public_inputs"] == limbs(ch.trusted_hash) + limbs(ch.target_hash) + [ch.trusted_block + 1, ch.target_block]
     # a trace with one flipped witness bit must not verify
     tr = buf.download().reshape(B.COLS, 1 << log_n)
     tr[B.GB(3, 2, 5), 100] ^= np.uint64(1)
@@ -90,7 +90,7 @@ def test_header_range_prove_end_to_end(ctx, vx, oracle):
     assert blob[4:16].tobytes() == out96
     info = S.verify(blob[16:], dict(S.DEFAULT_CFG, num_queries=12), expect_air=B.ID)
     limbs = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "little") for j in range(8)]  # noqa: E731
-    assert info["public_inputs"] == limbs(ch.trusted_hash) + limbs(out96[:32])
+    assert info["public_inputs"] == limbs(ch.trusted_hash) + limbs(out96[:32]) + [ch.trusted_block + 1, ch.target_block]
     # a chain that violates the statement never reaches the prover
     h = ch.headers.copy()
     h[5, 3] ^= 1
@@ -107,6 +107,8 @@ def test_product_verifier_on_gpu_proofs(ctx, vx):
     vx.lib.header_range_verify(blob, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg)
     with pytest.raises(vx.VxError):  # wrong request
         vx.lib.header_range_verify(blob, 16, ch.trusted_block, bytes(32), ch.target_block, out96, cfg)
+    with pytest.raises(vx.VxError):  # wrong block range
+        vx.lib.header_range_verify(blob, 16, ch.trusted_block + 1, ch.trusted_hash, ch.target_block, out96, cfg)
     with pytest.raises(vx.VxError):  # wrong claimed output
         vx.lib.header_range_verify(blob, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, bytes(32) + out96[32:], cfg)
     bad = blob.copy()

@@ -11,10 +11,10 @@ from oracle import stark_ref as S
 S.register_air(B.BlakeChainAir)
 
 
-def make(lengths, trusted=hashlib.sha256(b"t").digest()):
+def make(lengths, trusted=hashlib.sha256(b"t").digest(), first=70000):
     msgs, d = [], trusted
-    for n in lengths:
-        m = d + bytes((3 * i + n) & 0xFF for i in range(n - 32))
+    for k, n in enumerate(lengths):
+        m = d + (4 * (first + k) + 2).to_bytes(4, "little") + bytes((3 * i + n) & 0xFF for i in range(n - 36))
         msgs.append(m)
         d = hashlib.blake2b(m, digest_size=32).digest()
     return msgs, trusted, d
@@ -31,6 +31,10 @@ def test_trace_satisfies_constraints_and_detects_corruption(oracle):
         assert B.first_violation(bad, pub, rows=range(max(0, row - 1), row + 1)) is not None, (col, row)
     # wrong claimed target
     assert B.first_violation(tr, pub[:8] + [pub[8] ^ 1] + pub[9:], rows=[127]) is not None
+    # wrong claimed block numbers
+    assert B.first_violation(tr, pub[:16] + [pub[16] + 1, pub[17]], rows=[0]) is not None
+    assert B.first_violation(tr, pub[:17] + [pub[17] + 1], rows=[127]) is not None
+    assert pub[16:] == [70000, 70001]
 
 
 def test_prove_verify(oracle):
@@ -44,7 +48,12 @@ def test_prove_verify(oracle):
         S.verify(bad, dict(S.DEFAULT_CFG, num_queries=8))
 
 
-def test_broken_link_rejected():
+def test_broken_link_or_numbering_rejected():
     msgs, trusted, _ = make([100, 100])
     with pytest.raises(AssertionError):
         B.gen_trace([msgs[0], b"\x00" * 32 + msgs[1][32:]], 6, trusted)
+    # second header skips a number: the witness generator refuses, and a forced trace violates the AIR
+    d1 = hashlib.blake2b(msgs[0], digest_size=32).digest()
+    skip = d1 + (4 * 70002 + 2).to_bytes(4, "little") + msgs[1][36:]
+    with pytest.raises(AssertionError):
+        B.gen_trace([msgs[0], skip], 6, trusted)

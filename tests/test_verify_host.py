@@ -34,8 +34,8 @@ def test_accepts_reference_proofs_and_rejects_tampering(vx, oracle, air, log_n):
 
 def test_blake_chain_proof(vx, oracle):
     trusted = hashlib.sha256(b"v").digest()
-    m1 = trusted + bytes(range(200))
-    m2 = hashlib.blake2b(m1, digest_size=32).digest() + b"y" * 70
+    m1 = trusted + (4 * 123456 + 2).to_bytes(4, "little") + bytes(range(200))
+    m2 = hashlib.blake2b(m1, digest_size=32).digest() + (4 * 123457 + 2).to_bytes(4, "little") + b"y" * 70
     tr, pub, target = B.gen_trace([m1, m2], 6, trusted)
     cfg = dict(S.DEFAULT_CFG, num_queries=6)
     proof = S.prove(B.BlakeChainAir, tr, pub, cfg)
