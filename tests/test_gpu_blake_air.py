@@ -118,3 +118,24 @@ def test_product_verifier_on_gpu_proofs(ctx, vx):
     for air, log_n in ((S.FibAir, 12), (S.MixAir, 13)):
         trace, pub = air.trace(log_n)
         vx.lib.stark_verify(ctx.stark_prove(air.ID, ctx.from_host(trace), log_n, pub), expect_air=air.ID, expect_public=pub)
+
+
+@pytest.mark.parametrize("n_headers,profile", [(256, "P15k"), (512, "P15k")])
+def test_full_size_header_range(ctx, vx, n_headers, profile):
+    """BASELINE.json configs[1] and [2] at full size: too big for the python prover, so the checks are
+    size-independent properties -- outputs equal the hashlib mirror, the product's host verifier accepts
+    the proof, a single flipped word is rejected, and proving twice gives identical bytes."""
+    ch = vx.synth.Chain(n_headers, profile=profile)
+    hb = ctx.from_host(ch.headers)
+    cfg = ctx.stark_config()
+    out96, blob = ctx.header_range_prove(hb, ch.stride, ch.sizes, n_headers, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
+    assert out96 == ch.expected_outputs(n_headers)
+    first = blob.copy()
+    vx.lib.header_range_verify(first, n_headers, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg)
+    bad = first.copy()
+    bad[len(bad) // 3] ^= np.uint64(1)
+    with pytest.raises(vx.VxError):
+        vx.lib.header_range_verify(bad, n_headers, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg)
+    _, again = ctx.header_range_prove(hb, ch.stride, ch.sizes, n_headers, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
+    assert (again == first).all()
+    hb.free()
