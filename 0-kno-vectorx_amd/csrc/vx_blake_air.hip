@@ -288,11 +288,16 @@ int32_t vx_header_range_proof_bound(const vx_stark_config* cfg, size_t n_chunks,
 
 int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_fetched,
                               uint32_t max_headers, uint32_t trusted_block, const uint8_t trusted_hash[32], uint32_t target_block,
-                              const vx_stark_config* cfg, uint8_t out96[96], uint64_t* proof_out, size_t proof_cap,
-                              size_t* proof_len) {
+                              const vx_justification* just, const vx_stark_config* cfg, uint8_t out96[96], uint64_t* proof_out,
+                              size_t proof_cap, size_t* proof_len) {
     if (!ctx || !cfg || !proof_len || !out96) return VX_ERR_ARG;
     // 1. statement + public outputs (map/reduce chain rules, Merkle roots)
     VX_TRY(vx_verify_subchain(ctx, headers, stride, sizes, n_fetched, max_headers, trusted_block, trusted_hash, target_block, out96));
+    // 1b. the target header is justified by > 2/3 of the committed authority set (header_range.rs:49-54)
+    if (just)
+        VX_TRY(vx_verify_simple_justification(ctx, target_block, out96, just->authority_set_id, just->authority_set_hash, just->precommit,
+                                              just->pubkeys, just->signatures, just->validator_signed, just->num_authorities,
+                                              just->max_authorities));
     // 2. Blake2b parent-hash-chain STARK over every compression of every header
     size_t chunks = 0;
     for (size_t i = 0; i < n_fetched; ++i) chunks += (sizes[i] + 127) / 128;

@@ -1,0 +1,402 @@
+// verify_simple_justification on the GPU (statement level): the native counterpart of
+// /root/reference circuits/builder/justification.rs:195-257 and of the hint's own checks
+// (justification.rs:29-83 -> circuits/input/mod.rs:241-260):
+//   1. authority-set commitment  = chained SHA-256 of the public keys      (justification.rs:127-162)
+//   2. precommit decoding        = byte 0 == 1, hash / number / set id     (decoder.rs:159-200)
+//   3. Ed25519 verification of every signed vote over the SAME 53-byte precommit
+//      (justification.rs:229-243; ed25519-dalek `verify`: [s]B - [k]A compressed == R)
+//   4. threshold                 = signed * 3 > n * 2                       (justification.rs:164-186)
+// One lane per signature; GF(2^255-19) as 8 x 32-bit limbs with plain schoolbook products and the
+// 2^256 = 38 fold -- 300 signatures per proof are far off the hot path, so the code is written
+// for obviousness, not speed.  (The in-circuit EdDSA / SHA-256 AIRs are future work: DESIGN.md.)
+#include <string.h>
+
+#include "ed25519_constants.h"
+#include "vx_internal.h"
+
+namespace {
+struct U256 {
+    uint32_t w[8];
+};
+__device__ const uint32_t FE_P[8] = ED_P_INIT;
+// group order L = 2^252 + 27742317777372353535851937790883648493
+__device__ const uint32_t SC_L[8] = ED_L_INIT;
+// d = -121665/121666, sqrt(-1), base point (x, y)
+__device__ const uint32_t ED_D[8] = ED_D_INIT;
+__device__ const uint32_t ED_D2[8] = ED_D2_INIT;
+__device__ const uint32_t ED_SQRTM1[8] = ED_SQRTM1_INIT;
+__device__ const uint32_t ED_BX[8] = ED_BX_INIT;
+__device__ const uint32_t ED_BY[8] = ED_BY_INIT;
+
+__device__ bool u256_geq(const uint32_t* a, const uint32_t* b) {
+    for (int i = 7; i >= 0; --i) {
+        if (a[i] > b[i]) return true;
+        if (a[i] < b[i]) return false;
+    }
+    return true;
+}
+__device__ uint32_t u256_add(uint32_t* r, const uint32_t* a, const uint32_t* b) {
+    uint64_t c = 0;
+    for (int i = 0; i < 8; ++i) {
+        c += (uint64_t)a[i] + b[i];
+        r[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return (uint32_t)c;
+}
+__device__ uint32_t u256_sub(uint32_t* r, const uint32_t* a, const uint32_t* b) {
+    int64_t c = 0;
+    for (int i = 0; i < 8; ++i) {
+        c += (int64_t)a[i] - b[i];
+        r[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return (uint32_t)(c & 1);
+}
+// canonical representative in [0, p)
+__device__ void fe_canon(U256& a) {
+    while (u256_geq(a.w, FE_P)) u256_sub(a.w, a.w, FE_P);
+}
+__device__ U256 fe_add(const U256& a, const U256& b) {
+    U256 r;
+    uint32_t c = u256_add(r.w, a.w, b.w);
+    while (c) {  // 2^256 = 38 (mod p)
+        uint32_t t[8] = {38, 0, 0, 0, 0, 0, 0, 0};
+        c = u256_add(r.w, r.w, t);
+    }
+    return r;
+}
+__device__ U256 fe_sub(const U256& a, const U256& b) {
+    U256 bb = b;
+    fe_canon(bb);
+    U256 r, np;  // a + (p - b), p - b in (0, p]
+    u256_sub(np.w, FE_P, bb.w);
+    return fe_add(a, np);
+}
+__device__ U256 fe_mul(const U256& a, const U256& b) {
+    uint32_t t[16];
+    for (int i = 0; i < 16; ++i) t[i] = 0;
+    for (int i = 0; i < 8; ++i) {
+        uint64_t c = 0;
+        for (int j = 0; j < 8; ++j) {
+            c += (uint64_t)a.w[i] * b.w[j] + t[i + j];
+            t[i + j] = (uint32_t)c;
+            c >>= 32;
+        }
+        t[i + 8] = (uint32_t)c;
+    }
+    // fold the high half: hi * 2^256 = hi * 38
+    U256 r;
+    uint64_t c = 0;
+    for (int i = 0; i < 8; ++i) {
+        c += (uint64_t)t[i] + (uint64_t)t[i + 8] * 38;
+        r.w[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    while (c) {  // c < 39
+        uint64_t cc = c * 38;
+        c = 0;
+        for (int i = 0; i < 8; ++i) {
+            cc += r.w[i];
+            r.w[i] = (uint32_t)cc;
+            cc >>= 32;
+        }
+        c = cc;
+    }
+    return r;
+}
+__device__ U256 fe_pow(const U256& a, const uint32_t* e) {  // e: 256-bit exponent
+    U256 r;
+    for (int i = 0; i < 8; ++i) r.w[i] = i == 0;
+    for (int bit = 255; bit >= 0; --bit) {
+        r = fe_mul(r, r);
+        if ((e[bit >> 5] >> (bit & 31)) & 1) r = fe_mul(r, a);
+    }
+    return r;
+}
+__device__ bool fe_eq(U256 a, U256 b) {
+    fe_canon(a);
+    fe_canon(b);
+    for (int i = 0; i < 8; ++i)
+        if (a.w[i] != b.w[i]) return false;
+    return true;
+}
+__device__ U256 fe_from(const uint32_t* c) {
+    U256 r;
+    for (int i = 0; i < 8; ++i) r.w[i] = c[i];
+    return r;
+}
+struct Pt {
+    U256 X, Y, Z, T;
+};
+__device__ Pt pt_add(const Pt& p, const Pt& q) {  // extended twisted Edwards, a = -1 (add-2008-hwcd-3)
+    U256 A = fe_mul(fe_sub(p.Y, p.X), fe_sub(q.Y, q.X));
+    U256 B = fe_mul(fe_add(p.Y, p.X), fe_add(q.Y, q.X));
+    U256 C = fe_mul(fe_mul(p.T, q.T), fe_from(ED_D2));
+    U256 D = fe_mul(p.Z, q.Z);
+    D = fe_add(D, D);
+    U256 E = fe_sub(B, A), F = fe_sub(D, C), G = fe_add(D, C), H = fe_add(B, A);
+    return {fe_mul(E, F), fe_mul(G, H), fe_mul(F, G), fe_mul(E, H)};
+}
+__device__ Pt pt_identity() {
+    Pt r;
+    for (int i = 0; i < 8; ++i) r.X.w[i] = r.T.w[i] = 0, r.Y.w[i] = r.Z.w[i] = i == 0;
+    return r;
+}
+__device__ Pt pt_scalar_mul(const Pt& p, const uint32_t* k) {  // variable time, 256-bit scalar
+    Pt acc = pt_identity();
+    for (int bit = 255; bit >= 0; --bit) {
+        acc = pt_add(acc, acc);
+        if ((k[bit >> 5] >> (bit & 31)) & 1) acc = pt_add(acc, p);
+    }
+    return acc;
+}
+// RFC 8032 5.1.3 decoding; false when the encoding is not a curve point
+__device__ bool pt_decode(const uint8_t* s, Pt* out) {
+    U256 y;
+    for (int i = 0; i < 8; ++i) y.w[i] = (uint32_t)s[4 * i] | ((uint32_t)s[4 * i + 1] << 8) | ((uint32_t)s[4 * i + 2] << 16) | ((uint32_t)s[4 * i + 3] << 24);
+    const uint32_t sign = y.w[7] >> 31;
+    y.w[7] &= 0x7FFFFFFF;
+    if (u256_geq(y.w, FE_P)) return false;
+    U256 one;
+    for (int i = 0; i < 8; ++i) one.w[i] = i == 0;
+    const U256 y2 = fe_mul(y, y);
+    const U256 u = fe_sub(y2, one), v = fe_add(fe_mul(y2, fe_from(ED_D)), one);
+    // x = u v^3 (u v^7)^((p-5)/8)
+    const U256 v3 = fe_mul(fe_mul(v, v), v), v7 = fe_mul(fe_mul(v3, v3), v);
+    const uint32_t e58[8] = ED_EXP_P58_INIT;
+    U256 x = fe_mul(fe_mul(u, v3), fe_pow(fe_mul(u, v7), e58));
+    const U256 vx2 = fe_mul(v, fe_mul(x, x));
+    U256 zero;
+    for (int i = 0; i < 8; ++i) zero.w[i] = 0;
+    if (!fe_eq(vx2, u)) {
+        if (!fe_eq(vx2, fe_sub(zero, u))) return false;
+        x = fe_mul(x, fe_from(ED_SQRTM1));
+    }
+    fe_canon(x);
+    bool xz = true;
+    for (int i = 0; i < 8; ++i) xz &= x.w[i] == 0;
+    if (xz && sign) return false;
+    if ((x.w[0] & 1) != sign) x = fe_sub(zero, x);
+    *out = {x, y, one, fe_mul(x, y)};
+    return true;
+}
+__device__ void pt_encode(const Pt& p, uint8_t* out) {
+    const uint32_t em2[8] = ED_EXP_PM2_INIT;
+    const U256 zi = fe_pow(p.Z, em2);
+    U256 x = fe_mul(p.X, zi), y = fe_mul(p.Y, zi);
+    fe_canon(x);
+    fe_canon(y);
+    y.w[7] |= (x.w[0] & 1) << 31;
+    for (int i = 0; i < 8; ++i)
+        for (int b = 0; b < 4; ++b) out[4 * i + b] = (uint8_t)(y.w[i] >> (8 * b));
+}
+
+// ---- SHA-512 (FIPS 180-4)
+__device__ const uint64_t K512[80] = SHA512_K_INIT;
+__device__ __forceinline__ uint64_t r64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+__device__ void sha512(const uint8_t* msg, size_t len, uint8_t* out64) {  // len < 240
+    uint64_t h[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                     0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+    uint8_t buf[256];
+    const size_t total = (len + 17 <= 128) ? 128 : 256;
+    for (size_t i = 0; i < total; ++i) buf[i] = i < len ? msg[i] : 0;
+    buf[len] = 0x80;
+    const uint64_t bits = (uint64_t)len * 8;
+    for (int i = 0; i < 8; ++i) buf[total - 1 - i] = (uint8_t)(bits >> (8 * i));
+    for (size_t off = 0; off < total; off += 128) {
+        uint64_t w[80];
+        for (int i = 0; i < 16; ++i) {
+            uint64_t v = 0;
+            for (int b = 0; b < 8; ++b) v = (v << 8) | buf[off + 8 * i + b];
+            w[i] = v;
+        }
+        for (int i = 16; i < 80; ++i) {
+            const uint64_t s0 = r64(w[i - 15], 1) ^ r64(w[i - 15], 8) ^ (w[i - 15] >> 7);
+            const uint64_t s1 = r64(w[i - 2], 19) ^ r64(w[i - 2], 61) ^ (w[i - 2] >> 6);
+            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        }
+        uint64_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 80; ++i) {
+            const uint64_t S1 = r64(e, 14) ^ r64(e, 18) ^ r64(e, 41), ch = (e & f) ^ (~e & g);
+            const uint64_t t1 = hh + S1 + ch + K512[i] + w[i];
+            const uint64_t S0 = r64(a, 28) ^ r64(a, 34) ^ r64(a, 39), mj = (a & b) ^ (a & c) ^ (b & c);
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + S0 + mj;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    for (int i = 0; i < 8; ++i)
+        for (int b = 0; b < 8; ++b) out64[8 * i + b] = (uint8_t)(h[i] >> (56 - 8 * b));
+}
+// 512-bit little-endian integer mod L, bit-serial (r = 2r + bit; conditional subtract)
+__device__ void sc_reduce512(const uint8_t* in64, uint32_t* out) {
+    uint32_t r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int bit = 511; bit >= 0; --bit) {
+        uint32_t carry = (in64[bit >> 3] >> (bit & 7)) & 1;
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t nc = r[i] >> 31;
+            r[i] = (r[i] << 1) | carry;
+            carry = nc;
+        }
+        if (u256_geq(r, SC_L)) u256_sub(r, r, SC_L);  // r < L < 2^253 before doubling: no carry out
+    }
+    for (int i = 0; i < 8; ++i) out[i] = r[i];
+}
+
+// SHA-256 (two-block chain step) -- device copy kept local to this file
+__device__ const uint32_t K256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+__device__ __forceinline__ uint32_t r32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+__device__ void sha256(const uint8_t* msg, size_t len, uint8_t* out32) {  // len <= 64
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    uint8_t buf[128];
+    const size_t total = (len + 9 <= 64) ? 64 : 128;
+    for (size_t i = 0; i < total; ++i) buf[i] = i < len ? msg[i] : 0;
+    buf[len] = 0x80;
+    const uint64_t bits = (uint64_t)len * 8;
+    for (int i = 0; i < 8; ++i) buf[total - 1 - i] = (uint8_t)(bits >> (8 * i));
+    for (size_t off = 0; off < total; off += 64) {
+        uint32_t w[64];
+        for (int i = 0; i < 16; ++i) w[i] = ((uint32_t)buf[off + 4 * i] << 24) | ((uint32_t)buf[off + 4 * i + 1] << 16) | ((uint32_t)buf[off + 4 * i + 2] << 8) | buf[off + 4 * i + 3];
+        for (int i = 16; i < 64; ++i) {
+            const uint32_t s0 = r32(w[i - 15], 7) ^ r32(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = r32(w[i - 2], 17) ^ r32(w[i - 2], 19) ^ (w[i - 2] >> 10);
+            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        }
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 64; ++i) {
+            const uint32_t t1 = hh + (r32(e, 6) ^ r32(e, 11) ^ r32(e, 25)) + ((e & f) ^ (~e & g)) + K256[i] + w[i];
+            const uint32_t t2 = (r32(a, 2) ^ r32(a, 13) ^ r32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    for (int i = 0; i < 8; ++i)
+        for (int b = 0; b < 4; ++b) out32[4 * i + b] = (uint8_t)(h[i] >> (24 - 8 * b));
+}
+}  // namespace
+
+// ok[i] = 1 iff signature i verifies (ed25519-dalek `verify`: s canonical, A decodes,
+// compress([s]B - [k]A) == R bytes), k = SHA-512(R || A || M) mod L
+__global__ __launch_bounds__(64) void k_ed25519_verify(const uint8_t* pubkeys, const uint8_t* sigs, const uint8_t* msg, uint32_t msg_len,
+                                                       const uint8_t* enabled, size_t n, uint8_t* ok) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!enabled[i]) {
+        ok[i] = 2;  // not signed: skipped (justification.rs:59-62)
+        return;
+    }
+    const uint8_t* pk = pubkeys + 32 * i;
+    const uint8_t* sg = sigs + 64 * i;
+    uint32_t s[8];
+    for (int j = 0; j < 8; ++j) s[j] = (uint32_t)sg[32 + 4 * j] | ((uint32_t)sg[33 + 4 * j] << 8) | ((uint32_t)sg[34 + 4 * j] << 16) | ((uint32_t)sg[35 + 4 * j] << 24);
+    Pt A;
+    if (u256_geq(s, SC_L) || !pt_decode(pk, &A)) {
+        ok[i] = 0;
+        return;
+    }
+    uint8_t buf[64 + 128], dig[64];
+    for (int j = 0; j < 32; ++j) buf[j] = sg[j], buf[32 + j] = pk[j];
+    for (uint32_t j = 0; j < msg_len; ++j) buf[64 + j] = msg[j];
+    sha512(buf, 64 + msg_len, dig);
+    uint32_t k[8];
+    sc_reduce512(dig, k);
+    // -A
+    U256 zero;
+    for (int j = 0; j < 8; ++j) zero.w[j] = 0;
+    Pt nA = {fe_sub(zero, A.X), A.Y, A.Z, fe_sub(zero, A.T)};
+    U256 one;
+    for (int j = 0; j < 8; ++j) one.w[j] = j == 0;
+    const U256 bx = fe_from(ED_BX), by = fe_from(ED_BY);
+    const Pt B = {bx, by, one, fe_mul(bx, by)};
+    const Pt R = pt_add(pt_scalar_mul(B, s), pt_scalar_mul(nA, k));
+    uint8_t enc[32];
+    pt_encode(R, enc);
+    bool eq = true;
+    for (int j = 0; j < 32; ++j) eq &= enc[j] == sg[j];
+    ok[i] = eq ? 1 : 0;
+}
+// chained SHA-256 commitment of the first n public keys (one lane; 300 short hashes)
+__global__ void k_authority_set_hash(const uint8_t* pubkeys, size_t n, uint8_t* out32) {
+    if (blockIdx.x || threadIdx.x) return;
+    uint8_t cur[32], buf[64];
+    sha256(pubkeys, 32, cur);
+    for (size_t i = 1; i < n; ++i) {
+        for (int j = 0; j < 32; ++j) buf[j] = cur[j], buf[32 + j] = pubkeys[32 * i + j];
+        sha256(buf, 64, cur);
+    }
+    for (int j = 0; j < 32; ++j) out32[j] = cur[j];
+}
+
+extern "C" {
+
+int32_t vx_ed25519_verify_batch(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* sigs, const uint8_t* msg, uint32_t msg_len,
+                                const uint8_t* enabled, size_t n, uint8_t* ok_out) {
+    if (!ctx || !pubkeys || !sigs || !msg || !enabled || !ok_out) return VX_ERR_ARG;
+    VX_CHECK(msg_len <= 128 && n >= 1 && n <= 65536, "ed25519 batch: bad sizes");
+    uint64_t* sc;
+    const size_t bytes = 32 * n + 64 * n + 128 + n + n;
+    VX_TRY(vx_scratch(ctx, (bytes + 7) / 8 + 8, &sc));
+    uint8_t* d = (uint8_t*)sc;
+    uint8_t *d_pk = d, *d_sg = d + 32 * n, *d_msg = d_sg + 64 * n, *d_en = d_msg + 128, *d_ok = d_en + n;
+    VX_HIP(hipMemcpyAsync(d_pk, pubkeys, 32 * n, hipMemcpyHostToDevice, ctx->stream));
+    VX_HIP(hipMemcpyAsync(d_sg, sigs, 64 * n, hipMemcpyHostToDevice, ctx->stream));
+    VX_HIP(hipMemcpyAsync(d_msg, msg, msg_len, hipMemcpyHostToDevice, ctx->stream));
+    VX_HIP(hipMemcpyAsync(d_en, enabled, n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_ed25519_verify, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, (const uint8_t*)d_pk, (const uint8_t*)d_sg,
+                       (const uint8_t*)d_msg, msg_len, (const uint8_t*)d_en, n, d_ok);
+    VX_HIP(hipGetLastError());
+    VX_HIP(hipMemcpyAsync(ok_out, d_ok, n, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipStreamSynchronize(ctx->stream));
+    return VX_OK;
+}
+
+int32_t vx_verify_simple_justification(vx_ctx* ctx, uint32_t block_number, const uint8_t block_hash[32], uint64_t authority_set_id,
+                                       const uint8_t authority_set_hash[32], const uint8_t precommit[53], const uint8_t* pubkeys,
+                                       const uint8_t* signatures, const uint8_t* validator_signed, uint32_t num_authorities,
+                                       uint32_t max_authorities) {
+    if (!ctx || !block_hash || !authority_set_hash || !precommit || !pubkeys || !signatures || !validator_signed) return VX_ERR_ARG;
+    VX_CHECK(max_authorities >= 1 && max_authorities <= 4096 && num_authorities <= max_authorities, "justification: %u authorities of max %u", num_authorities, max_authorities);
+    // justification.rs:134-137: at least one authority
+    if (num_authorities == 0) return vx_fail(ctx, VX_ERR_STATEMENT, "justification: no authorities");
+    // 1. authority-set commitment over the first num_authorities keys
+    uint64_t* sc;
+    VX_TRY(vx_scratch(ctx, (32 * (size_t)max_authorities + 7) / 8 + 8, &sc));
+    uint8_t* d_pk = (uint8_t*)sc;
+    uint8_t* d_out = d_pk + 32 * (size_t)max_authorities;
+    VX_HIP(hipMemcpyAsync(d_pk, pubkeys, 32 * (size_t)num_authorities, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_authority_set_hash, dim3(1), dim3(1), 0, ctx->stream, (const uint8_t*)d_pk, (size_t)num_authorities, d_out);
+    VX_HIP(hipGetLastError());
+    uint8_t commit[32];
+    VX_HIP(hipMemcpyAsync(commit, d_out, 32, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipStreamSynchronize(ctx->stream));
+    if (memcmp(commit, authority_set_hash, 32) != 0) return vx_fail(ctx, VX_ERR_STATEMENT, "justification: authority set commitment mismatch");
+    // 2. precommit (decoder.rs:159-200)
+    if (precommit[0] != 1) return vx_fail(ctx, VX_ERR_STATEMENT, "justification: precommit type byte is %u", precommit[0]);
+    uint32_t bn = 0;
+    uint64_t sid = 0;
+    for (int i = 0; i < 4; ++i) bn |= (uint32_t)precommit[33 + i] << (8 * i);
+    for (int i = 0; i < 8; ++i) sid |= (uint64_t)precommit[45 + i] << (8 * i);
+    if (bn != block_number || sid != authority_set_id || memcmp(precommit + 1, block_hash, 32) != 0)
+        return vx_fail(ctx, VX_ERR_STATEMENT, "justification: precommit does not match block number / set id / block hash");
+    // 3. signatures of the validators marked as signed (only the first num_authorities can count)
+    std::vector<uint8_t> en(max_authorities), ok(max_authorities);
+    uint32_t n_signed = 0;
+    for (uint32_t i = 0; i < max_authorities; ++i) {
+        en[i] = validator_signed[i] ? 1 : 0;
+        n_signed += en[i];
+    }
+    VX_TRY(vx_ed25519_verify_batch(ctx, pubkeys, signatures, precommit, 53, en.data(), max_authorities, ok.data()));
+    for (uint32_t i = 0; i < max_authorities; ++i)
+        if (en[i] && ok[i] != 1) return vx_fail(ctx, VX_ERR_STATEMENT, "justification: signature %u is invalid", i);
+    // 4. threshold: signed * 3 > n * 2
+    if (!((uint64_t)n_signed * 3 > (uint64_t)num_authorities * 2))
+        return vx_fail(ctx, VX_ERR_STATEMENT, "justification: %u of %u signed, not more than 2/3", n_signed, num_authorities);
+    return VX_OK;
+}
+}

@@ -24,10 +24,34 @@ SYMBOLS = [
     "vx_fri_fold", "vx_fri_layer_tree", "vx_fri_leaves", "vx_fri_pow",
     "vx_stark_default_config", "vx_stark_proof_bound", "vx_stark_prove", "vx_stark_verify", "vx_header_range_proof_bound", "vx_header_range_prove", "vx_header_range_verify",
     "vx_blake2b_256_batch", "vx_sha256_pairs", "vx_verify_subchain", "vx_blake_chain_trace",
+    "vx_ed25519_verify_batch", "vx_verify_simple_justification",
 ]
 
 VX_AIR_FIBONACCI, VX_AIR_MIX, VX_AIR_BLAKE_CHAIN = 1, 2, 3
 VX_BLAKE_AIR_COLS = 4824
+
+
+class JustificationStruct(C.Structure):
+    _fields_ = [("authority_set_id", C.c_uint64), ("authority_set_hash", C.c_void_p), ("precommit", C.c_void_p), ("pubkeys", C.c_void_p),
+                ("signatures", C.c_void_p), ("validator_signed", C.c_void_p), ("num_authorities", C.c_uint32), ("max_authorities", C.c_uint32)]
+
+
+class PackedJustification:
+    """Host buffers of a synth.Justification in the layout vx_justification expects (kept alive here)."""
+
+    def __init__(self, just, max_authorities=None):
+        n = len(just.pubkeys)
+        mx = n if max_authorities is None else max_authorities
+        self.pk = np.zeros(32 * mx, dtype=np.uint8)
+        self.sg = np.zeros(64 * mx, dtype=np.uint8)
+        self.en = np.zeros(mx, dtype=np.uint8)
+        self.pk[: 32 * n] = np.frombuffer(b"".join(just.pubkeys), dtype=np.uint8)
+        self.sg[: 64 * n] = np.frombuffer(b"".join(just.signatures), dtype=np.uint8)
+        self.en[:n] = np.array(just.signed, dtype=np.uint8)
+        self.sh = np.frombuffer(bytes(just.authority_set_hash), dtype=np.uint8).copy()
+        self.pc = np.frombuffer(bytes(just.precommit), dtype=np.uint8).copy()
+        self.struct = JustificationStruct(just.set_id, self.sh.ctypes.data, self.pc.ctypes.data, self.pk.ctypes.data, self.sg.ctypes.data,
+                                          self.en.ctypes.data, just.num_authorities, mx)
 
 
 class StarkConfig(C.Structure):
@@ -80,13 +104,15 @@ def load_library():
         "vx_stark_default_config": [C.POINTER(StarkConfig)],
         "vx_stark_proof_bound": [C.c_int, C.POINTER(StarkConfig), C.c_int, C.POINTER(sz)],
         "vx_header_range_proof_bound": [C.POINTER(StarkConfig), sz, C.POINTER(sz)],
-        "vx_header_range_prove": [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.POINTER(StarkConfig), vp, vp, sz, C.POINTER(sz)],
+        "vx_header_range_prove": [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.POINTER(JustificationStruct), C.POINTER(StarkConfig), vp, vp, sz, C.POINTER(sz)],
         "vx_stark_verify": [C.POINTER(StarkConfig), vp, sz, C.c_int, vp, sz, C.c_char_p, sz],
         "vx_header_range_verify": [C.POINTER(StarkConfig), vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, C.c_char_p, sz],
         "vx_stark_prove": [vp, C.c_int, C.POINTER(StarkConfig), vp, C.c_int, vp, sz, vp, sz, C.POINTER(sz)],
         "vx_blake2b_256_batch": [vp, vp, sz, vp, sz, vp], "vx_sha256_pairs": [vp, vp, sz, vp],
         "vx_verify_subchain": [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp],
         "vx_blake_chain_trace": [vp, vp, sz, vp, sz, vp, C.c_uint32, C.c_int, vp, vp, vp],
+        "vx_ed25519_verify_batch": [vp, vp, vp, vp, C.c_uint32, vp, sz, vp],
+        "vx_verify_simple_justification": [vp, C.c_uint32, vp, u64, vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -314,8 +340,9 @@ class Context:
         self._ck(self.L.vx_stark_prove(self.h, air_id, C.byref(cfg), trace_buf.h, log_n, _ptr(pub), pub.size, _ptr(out), out.size, C.byref(need)))
         return out[: need.value]
 
-    def header_range_prove(self, headers_buf, stride, sizes, max_headers, trusted_block, trusted_hash, target_block, cfg=None, out=None):
-        """HeaderRangeCircuit::prove for a chain resident in HBM -> (96-byte output, proof blob words)."""
+    def header_range_prove(self, headers_buf, stride, sizes, max_headers, trusted_block, trusted_hash, target_block, cfg=None, out=None, just=None):
+        """HeaderRangeCircuit::prove for a chain resident in HBM -> (96-byte output, proof blob words).
+        just: PackedJustification (or None to skip the justification check)."""
         cfg = cfg or self.stark_config()
         sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
         th = np.frombuffer(bytes(trusted_hash), dtype=np.uint8).copy()
@@ -326,7 +353,8 @@ class Context:
             out = np.empty(need.value, dtype=np.uint64)
         out96 = np.zeros(96, dtype=np.uint8)
         self._ck(self.L.vx_header_range_prove(self.h, headers_buf.h, stride, _ptr(sizes), sizes.size, max_headers, trusted_block, _ptr(th),
-                                              target_block, C.byref(cfg), _ptr(out96), _ptr(out), out.size, C.byref(need)))
+                                              target_block, C.byref(just.struct) if just is not None else None, C.byref(cfg), _ptr(out96),
+                                              _ptr(out), out.size, C.byref(need)))
         return out96.tobytes(), out[: need.value]
 
     # K8 / statement
@@ -350,6 +378,32 @@ class Context:
         dig = np.zeros((sizes.size, 32), dtype=np.uint8)
         self._ck(self.L.vx_blake_chain_trace(self.h, headers_buf.h, stride, _ptr(sizes), sizes.size, _ptr(th), first_block_number, log_n, trace_buf.h, _ptr(pub), _ptr(dig)))
         return trace_buf, pub, dig
+
+    def ed25519_verify_batch(self, pubkeys, sigs, msg, enabled=None):
+        pk = np.ascontiguousarray(np.frombuffer(b"".join(pubkeys), dtype=np.uint8))
+        sg = np.ascontiguousarray(np.frombuffer(b"".join(sigs), dtype=np.uint8))
+        n = pk.size // 32
+        en = np.ones(n, dtype=np.uint8) if enabled is None else np.ascontiguousarray(enabled, dtype=np.uint8)
+        m = np.frombuffer(bytes(msg), dtype=np.uint8).copy()
+        ok = np.zeros(n, dtype=np.uint8)
+        self._ck(self.L.vx_ed25519_verify_batch(self.h, _ptr(pk), _ptr(sg), _ptr(m), m.size, _ptr(en), n, _ptr(ok)))
+        return ok
+
+    def verify_simple_justification(self, block_number, block_hash, set_id, set_hash, just, max_authorities=None):
+        """`just`: synth.Justification-like object (precommit, pubkeys, signatures, signed, num_authorities)."""
+        n = len(just.pubkeys)
+        mx = n if max_authorities is None else max_authorities
+        pk = np.zeros(32 * mx, dtype=np.uint8)
+        sg = np.zeros(64 * mx, dtype=np.uint8)
+        en = np.zeros(mx, dtype=np.uint8)
+        pk[: 32 * n] = np.frombuffer(b"".join(just.pubkeys), dtype=np.uint8)
+        sg[: 64 * n] = np.frombuffer(b"".join(just.signatures), dtype=np.uint8)
+        en[:n] = np.array(just.signed, dtype=np.uint8)
+        bh = np.frombuffer(bytes(block_hash), dtype=np.uint8).copy()
+        sh = np.frombuffer(bytes(set_hash), dtype=np.uint8).copy()
+        pc = np.frombuffer(bytes(just.precommit), dtype=np.uint8).copy()
+        self._ck(self.L.vx_verify_simple_justification(self.h, block_number, _ptr(bh), set_id, _ptr(sh), _ptr(pc), _ptr(pk), _ptr(sg), _ptr(en),
+                                                       just.num_authorities, mx))
 
     def verify_subchain(self, headers_buf, stride, sizes, max_headers, trusted_block, trusted_hash, target_block):
         sizes = np.ascontiguousarray(sizes, dtype=np.uint32)

@@ -206,16 +206,44 @@ int32_t vx_verify_subchain(vx_ctx* ctx, const vx_buf* headers, size_t stride, co
                            size_t n_fetched, uint32_t max_headers, uint32_t trusted_block,
                            const uint8_t trusted_hash[32], uint32_t target_block, uint8_t out96[96]);
 
+/* ---- justification, statement level (circuits/builder/justification.rs:195-257 and the hint's native
+ * checks :29-83 -> circuits/input/mod.rs:241-260).  All byte arrays are host buffers.
+ * vx_ed25519_verify_batch: ok_out[i] = 1 valid, 0 invalid, 2 skipped (enabled[i] == 0); semantics of
+ * ed25519-dalek `verify` (canonical s, compress([s]B - [k]A) == R), the reference's verify_signature.
+ * vx_verify_simple_justification: authority-set commitment == authority_set_hash, precommit matches
+ * (block number, set id, block hash), every validator marked signed has a valid signature over the
+ * precommit, signed * 3 > num_authorities * 2.  pubkeys / signatures / validator_signed have
+ * max_authorities entries (32 / 64 / 1 bytes each).  VX_ERR_STATEMENT when any rule fails. */
+int32_t vx_ed25519_verify_batch(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* sigs, const uint8_t* msg, uint32_t msg_len,
+                                const uint8_t* enabled, size_t n, uint8_t* ok_out);
+int32_t vx_verify_simple_justification(vx_ctx* ctx, uint32_t block_number, const uint8_t block_hash[32],
+                                       uint64_t authority_set_id, const uint8_t authority_set_hash[32],
+                                       const uint8_t precommit[53], const uint8_t* pubkeys, const uint8_t* signatures,
+                                       const uint8_t* validator_signed, uint32_t num_authorities, uint32_t max_authorities);
+
 /* ---- top level: HeaderRangeCircuit::prove (circuits/header_range.rs:26-59 via Circuit::prove, :167).
  * Inputs as vx_verify_subchain.  Output blob (uint64 words): "HRRANGE1", max_headers, trusted_block,
  * target_block, the 96 public output bytes (12 words), then the BlakeChainAir STARK proof.
  * What the blob proves today is listed in DESIGN.md section 2 (the justification / Merkle-root /
  * numbering gadgets are checked natively by vx_verify_subchain but not yet inside a STARK). */
+/* The justification witness of circuits/vars.rs:40-46 (host buffers; what HintSimpleJustification
+ * returns, justification.rs:69-82) plus the two EVM inputs it is checked against. */
+typedef struct vx_justification {
+    uint64_t authority_set_id;
+    const uint8_t* authority_set_hash; /* 32 bytes */
+    const uint8_t* precommit;          /* 53 bytes */
+    const uint8_t* pubkeys;            /* max_authorities x 32 */
+    const uint8_t* signatures;         /* max_authorities x 64 */
+    const uint8_t* validator_signed;   /* max_authorities x 1 */
+    uint32_t num_authorities, max_authorities;
+} vx_justification;
 int32_t vx_header_range_proof_bound(const vx_stark_config* cfg, size_t n_chunks, size_t* n_words);
+/* just may be NULL (subchain only); otherwise verify_simple_justification for (target_block, target
+ * header hash) is checked on the GPU before proving, as HeaderRangeCircuit::define does (:49-54). */
 int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_fetched,
                               uint32_t max_headers, uint32_t trusted_block, const uint8_t trusted_hash[32],
-                              uint32_t target_block, const vx_stark_config* cfg, uint8_t out96[96], uint64_t* proof_out,
-                              size_t proof_cap, size_t* proof_len);
+                              uint32_t target_block, const vx_justification* just, const vx_stark_config* cfg,
+                              uint8_t out96[96], uint64_t* proof_out, size_t proof_cap, size_t* proof_len);
 /* HeaderRangeCircuit verify: checks the blob of vx_header_range_prove against the request
  * (blocks, trusted hash) and the claimed 96 output bytes, then verifies the STARK. */
 int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob, size_t blob_len, uint32_t max_headers,

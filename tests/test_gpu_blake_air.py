@@ -91,6 +91,16 @@ def test_header_range_prove_end_to_end(ctx, vx, oracle):
     info = S.verify(blob[16:], dict(S.DEFAULT_CFG, num_queries=12), expect_air=B.ID)
     limbs = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "little") for j in range(8)]  # noqa: E731
     assert info["public_inputs"] == limbs(ch.trusted_hash) + limbs(out96[:32]) + [ch.trusted_block + 1, ch.target_block]
+    # with a justification: accepted when > 2/3 signed the target, refused otherwise
+    good = vx.lib.PackedJustification(vx.synth.Justification(ch.target_block, ch.target_hash, n_auth=9, n_signed=7), 12)
+    o2, b2 = ctx.header_range_prove(ctx.from_host(ch.headers), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg, just=good)
+    assert o2 == out96 and (b2 == blob).all()
+    for bad_j in (vx.synth.Justification(ch.target_block, ch.target_hash, n_auth=9, n_signed=6),
+                  vx.synth.Justification(ch.target_block, ch.hashes[3], n_auth=9)):
+        with pytest.raises(vx.VxError) as e:
+            ctx.header_range_prove(ctx.from_host(ch.headers), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg,
+                                   just=vx.lib.PackedJustification(bad_j, 12))
+        assert e.value.code == -5
     # a chain that violates the statement never reaches the prover
     h = ch.headers.copy()
     h[5, 3] ^= 1
