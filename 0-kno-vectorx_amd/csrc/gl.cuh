@@ -33,6 +33,13 @@ __device__ __forceinline__ uint64_t gl_sub(uint64_t a, uint64_t b) {
     const bool bw = __builtin_sub_overflow(a, b, &d);
     return d - (bw ? (uint64_t)GL_EPS : 0);  // + p (mod 2^64)
 }
+// a + b where b is CANONICAL and a is any 64-bit representative; result in [0, 2^64), not canonical.
+// (a + b < 2^64 + p, so after one wrap the value is below p and the + eps cannot wrap again.)
+__device__ __forceinline__ uint64_t gl_add_nc(uint64_t a, uint64_t b) {
+    uint64_t s;
+    const bool c = __builtin_add_overflow(a, b, &s);
+    return s + (c ? (uint64_t)GL_EPS : 0);
+}
 __device__ __forceinline__ uint64_t gl_neg(uint64_t a) { return a ? GL_P - a : 0; }
 __device__ __forceinline__ uint64_t gl_dbl(uint64_t a) { return gl_add(a, a); }
 

@@ -88,10 +88,12 @@ __device__ __forceinline__ void poseidon_mds(uint64_t* s) {
     yh[0] += (int64_t)hi[0] * VX_POSEIDON_MDS_DIAG0;
 #pragma unroll
     for (int r = 0; r < 12; ++r) {
-        // al + ah * 2^32 with al, ah < 2^42:  ah*2^32 = (ah>>32)*2^64 + (ah & eps) << 32
+        // al + ah * 2^32 with al, ah < 2^42:  ah*2^32 = (ah>>32)*2^64 + (ah & eps) << 32.  The sum is left
+        // NON-canonical (any value in [0, 2^64)): the round-constant add, the s-box multiplier and the
+        // next MDS split all accept that; poseidon_permute canonicalises once at the end.
         const uint64_t al = (uint64_t)yl[r], ah = (uint64_t)yh[r];
-        uint64_t t = gl_add(al, (ah & GL_EPS) << 32);
-        s[r] = gl_add(t, (ah >> 32) * GL_EPS);
+        const uint64_t t = gl_add_nc((ah & GL_EPS) << 32, al);  // al < 2^42 is canonical
+        s[r] = gl_add_nc(t, (ah >> 32) * GL_EPS);               // (ah >> 32) * eps < 2^42 is canonical
     }
 }
 
@@ -100,14 +102,14 @@ __device__ __forceinline__ void poseidon_permute(uint64_t* s) {
 #pragma unroll 1
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox(gl_add(s[i], POSEIDON_RC[rc + i]));
+        for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox(gl_add_nc(s[i], POSEIDON_RC[rc + i]));
         rc += 12;
         poseidon_mds(s);
     }
 #pragma unroll 1
     for (int r = 0; r < 22; ++r) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) s[i] = gl_add(s[i], POSEIDON_RC[rc + i]);
+        for (int i = 0; i < 12; ++i) s[i] = gl_add_nc(s[i], POSEIDON_RC[rc + i]);
         rc += 12;
         s[0] = poseidon_sbox(s[0]);
         poseidon_mds(s);
@@ -115,8 +117,10 @@ __device__ __forceinline__ void poseidon_permute(uint64_t* s) {
 #pragma unroll 1
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox(gl_add(s[i], POSEIDON_RC[rc + i]));
+        for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox(gl_add_nc(s[i], POSEIDON_RC[rc + i]));
         rc += 12;
         poseidon_mds(s);
     }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = gl_canon(s[i]);
 }

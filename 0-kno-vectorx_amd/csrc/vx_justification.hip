@@ -243,42 +243,6 @@ __device__ void sc_reduce512(const uint8_t* in64, uint32_t* out) {
     for (int i = 0; i < 8; ++i) out[i] = r[i];
 }
 
-// SHA-256 (two-block chain step) -- device copy kept local to this file
-__device__ const uint32_t K256[64] = {
-    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
-    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
-    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
-    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
-    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
-    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
-    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
-__device__ __forceinline__ uint32_t r32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
-__device__ void sha256(const uint8_t* msg, size_t len, uint8_t* out32) {  // len <= 64
-    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
-    uint8_t buf[128];
-    const size_t total = (len + 9 <= 64) ? 64 : 128;
-    for (size_t i = 0; i < total; ++i) buf[i] = i < len ? msg[i] : 0;
-    buf[len] = 0x80;
-    const uint64_t bits = (uint64_t)len * 8;
-    for (int i = 0; i < 8; ++i) buf[total - 1 - i] = (uint8_t)(bits >> (8 * i));
-    for (size_t off = 0; off < total; off += 64) {
-        uint32_t w[64];
-        for (int i = 0; i < 16; ++i) w[i] = ((uint32_t)buf[off + 4 * i] << 24) | ((uint32_t)buf[off + 4 * i + 1] << 16) | ((uint32_t)buf[off + 4 * i + 2] << 8) | buf[off + 4 * i + 3];
-        for (int i = 16; i < 64; ++i) {
-            const uint32_t s0 = r32(w[i - 15], 7) ^ r32(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = r32(w[i - 2], 17) ^ r32(w[i - 2], 19) ^ (w[i - 2] >> 10);
-            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
-        }
-        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
-        for (int i = 0; i < 64; ++i) {
-            const uint32_t t1 = hh + (r32(e, 6) ^ r32(e, 11) ^ r32(e, 25)) + ((e & f) ^ (~e & g)) + K256[i] + w[i];
-            const uint32_t t2 = (r32(a, 2) ^ r32(a, 13) ^ r32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
-            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
-        }
-        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
-    }
-    for (int i = 0; i < 8; ++i)
-        for (int b = 0; b < 4; ++b) out32[4 * i + b] = (uint8_t)(h[i] >> (24 - 8 * b));
-}
 }  // namespace
 
 // ok[i] = 1 iff signature i verifies (ed25519-dalek `verify`: s canonical, A decodes,
@@ -321,16 +285,40 @@ __global__ __launch_bounds__(64) void k_ed25519_verify(const uint8_t* pubkeys, c
     for (int j = 0; j < 32; ++j) eq &= enc[j] == sg[j];
     ok[i] = eq ? 1 : 0;
 }
-// chained SHA-256 commitment of the first n public keys (one lane; 300 short hashes)
-__global__ void k_authority_set_hash(const uint8_t* pubkeys, size_t n, uint8_t* out32) {
-    if (blockIdx.x || threadIdx.x) return;
-    uint8_t cur[32], buf[64];
-    sha256(pubkeys, 32, cur);
-    for (size_t i = 1; i < n; ++i) {
-        for (int j = 0; j < 32; ++j) buf[j] = cur[j], buf[32 + j] = pubkeys[32 * i + j];
-        sha256(buf, 64, cur);
+// host SHA-256 for the authority-set commitment: 300 dependent 64-byte hashes are ~30 us of scalar
+// work on the host and ~30 ms on a single GPU lane, so this one stays on the host
+static void h_sha256(const uint8_t* msg, size_t len, uint8_t* out32) {
+    static const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+        0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+        0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+        0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+        0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+        0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+        0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    auto rr = [](uint32_t x, int n) { return (x >> n) | (x << (32 - n)); };
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    uint8_t buf[128];
+    const size_t total = (len + 9 <= 64) ? 64 : 128;
+    memset(buf, 0, sizeof buf);
+    memcpy(buf, msg, len);
+    buf[len] = 0x80;
+    const uint64_t bits = (uint64_t)len * 8;
+    for (int i = 0; i < 8; ++i) buf[total - 1 - i] = (uint8_t)(bits >> (8 * i));
+    for (size_t off = 0; off < total; off += 64) {
+        uint32_t w[64];
+        for (int i = 0; i < 16; ++i) w[i] = ((uint32_t)buf[off + 4 * i] << 24) | ((uint32_t)buf[off + 4 * i + 1] << 16) | ((uint32_t)buf[off + 4 * i + 2] << 8) | buf[off + 4 * i + 3];
+        for (int i = 16; i < 64; ++i) w[i] = w[i - 16] + (rr(w[i - 15], 7) ^ rr(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] + (rr(w[i - 2], 17) ^ rr(w[i - 2], 19) ^ (w[i - 2] >> 10));
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 64; ++i) {
+            const uint32_t t1 = hh + (rr(e, 6) ^ rr(e, 11) ^ rr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+            const uint32_t t2 = (rr(a, 2) ^ rr(a, 13) ^ rr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
     }
-    for (int j = 0; j < 32; ++j) out32[j] = cur[j];
+    for (int i = 0; i < 8; ++i)
+        for (int b = 0; b < 4; ++b) out32[4 * i + b] = (uint8_t)(h[i] >> (24 - 8 * b));
 }
 
 extern "C" {
@@ -364,17 +352,14 @@ int32_t vx_verify_simple_justification(vx_ctx* ctx, uint32_t block_number, const
     VX_CHECK(max_authorities >= 1 && max_authorities <= 4096 && num_authorities <= max_authorities, "justification: %u authorities of max %u", num_authorities, max_authorities);
     // justification.rs:134-137: at least one authority
     if (num_authorities == 0) return vx_fail(ctx, VX_ERR_STATEMENT, "justification: no authorities");
-    // 1. authority-set commitment over the first num_authorities keys
-    uint64_t* sc;
-    VX_TRY(vx_scratch(ctx, (32 * (size_t)max_authorities + 7) / 8 + 8, &sc));
-    uint8_t* d_pk = (uint8_t*)sc;
-    uint8_t* d_out = d_pk + 32 * (size_t)max_authorities;
-    VX_HIP(hipMemcpyAsync(d_pk, pubkeys, 32 * (size_t)num_authorities, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_authority_set_hash, dim3(1), dim3(1), 0, ctx->stream, (const uint8_t*)d_pk, (size_t)num_authorities, d_out);
-    VX_HIP(hipGetLastError());
-    uint8_t commit[32];
-    VX_HIP(hipMemcpyAsync(commit, d_out, 32, hipMemcpyDeviceToHost, ctx->stream));
-    VX_HIP(hipStreamSynchronize(ctx->stream));
+    // 1. authority-set commitment over the first num_authorities keys (sequential chain: host)
+    uint8_t commit[32], buf[64];
+    h_sha256(pubkeys, 32, commit);
+    for (uint32_t i = 1; i < num_authorities; ++i) {
+        memcpy(buf, commit, 32);
+        memcpy(buf + 32, pubkeys + 32 * (size_t)i, 32);
+        h_sha256(buf, 64, commit);
+    }
     if (memcmp(commit, authority_set_hash, 32) != 0) return vx_fail(ctx, VX_ERR_STATEMENT, "justification: authority set commitment mismatch");
     // 2. precommit (decoder.rs:159-200)
     if (precommit[0] != 1) return vx_fail(ctx, VX_ERR_STATEMENT, "justification: precommit type byte is %u", precommit[0]);
