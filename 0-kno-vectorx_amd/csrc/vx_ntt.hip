@@ -39,6 +39,7 @@ struct PassArgs {
     const uint64_t* tw2_lo;     // two-level table of w_{2^log_sub}: lo[j] = w^j, hi[j] = w^(j << tw2_bits)
     const uint64_t* tw2_hi;
     int tw2_bits;
+    int dbg_skip;  // timing experiments only (VX_NTT_SKIP bit mask): 1 = tile twiddles, 2 = inter-pass twiddle, 4 = butterflies
 };
 
 __device__ __forceinline__ uint64_t tab3_pow(const uint64_t* tab, uint64_t e) {
@@ -302,18 +303,19 @@ __global__ __launch_bounds__(256) void k_ntt_tile(PassArgs a) {
             const int i = tile_iota(tid, e, 8);
             x[e] = src[base + (size_t)(i >> lT) * m + (i & (T - 1))];
         }
-        tile_round<0, INV>(x, qA);
-        if (lr - qA > 0) tile_twiddle(x, w12s, tid, 8, qA, lr - qA, lT);
+        const bool sk_tw = a.dbg_skip & 1, sk_ip = a.dbg_skip & 2, sk_bf = a.dbg_skip & 4;
+        if (!sk_bf) tile_round<0, INV>(x, qA);
+        if (lr - qA > 0 && !sk_tw) tile_twiddle(x, w12s, tid, 8, qA, lr - qA, lT);
         int f_last = 8;
         if (nr >= 2) {
             tile_exchange(x, lds, tid, 8, 4);
-            tile_round<0, INV>(x, qB);
-            if (lr - 4 - qB > 0) tile_twiddle(x, w12s, tid, 4, qB, lr - 4 - qB, lT);
+            if (!sk_bf) tile_round<0, INV>(x, qB);
+            if (lr - 4 - qB > 0 && !sk_tw) tile_twiddle(x, w12s, tid, 4, qB, lr - 4 - qB, lT);
             f_last = 4;
         }
         if (nr == 3) {
             tile_exchange(x, lds, tid, 4, 0);
-            tile_round<0, INV>(x, qC);
+            if (!sk_bf) tile_round<0, INV>(x, qC);
             tile_exchange(x, lds, tid, 0, 8);  // back to the coalesced mapping for the store
             f_last = 8;
         }
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256) void k_ntt_tile(PassArgs a) {
             const int i = tile_iota(tid, e, f_last);
             const int rho = i >> lT, tau = i & (T - 1);
             uint64_t v = x[e];
-            if (m > 1) {
+            if (m > 1 && !sk_ip) {
                 const uint64_t ex = (uint64_t)(col0 + tau) * brev32((uint32_t)rho, lr);
                 const uint64_t w = gl_mul_nc(a.tw2_hi[ex >> a.tw2_bits], a.tw2_lo[ex & (((uint64_t)1 << a.tw2_bits) - 1)]);
                 v = gl_mul(v, w);
@@ -420,9 +422,11 @@ static inline size_t lds_bytes(int lr, int lT) {
     return ((size_t)1 << lr) * (T > 1 ? T + 1 : 1) * 8;
 }
 static bool g_ntt_v1 = getenv("VX_NTT_V1") != nullptr;  // debugging aid: force the LDS-stage kernel
+static int g_ntt_skip = getenv("VX_NTT_SKIP") ? atoi(getenv("VX_NTT_SKIP")) : 0;  // timing experiments (wrong results!)
 template <int MODE>
 static int32_t launch_pass(vx_ctx* ctx, PassArgs& a, int log_n, size_t n_cols, int inverse) {
     size_t tiles = (size_t)1 << (log_n - a.log_rows - a.log_T);
+    a.dbg_skip = g_ntt_skip;
     if (a.log_rows + a.log_T == 12 && !g_ntt_v1) {
         if (inverse) hipLaunchKernelGGL((k_ntt_tile<MODE, 1>), dim3((unsigned)tiles, (unsigned)n_cols), dim3(256), 0, ctx->stream, a);
         else hipLaunchKernelGGL((k_ntt_tile<MODE, 0>), dim3((unsigned)tiles, (unsigned)n_cols), dim3(256), 0, ctx->stream, a);
