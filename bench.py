@@ -102,7 +102,7 @@ def cpu_baseline(vx):
     rc, _ = O.verify_subchain(ch.headers, ch.sizes, N_HEADERS, ch.trusted_block, ch.trusted_hash, ch.target_block)
     t_chain = time.perf_counter() - t0
     assert rc == 0
-    log_n, sample_cols = NTT_LOG_N, 16
+    log_n, sample_cols = (19 if N_HEADERS == 256 else 20), 16
     rng = np.random.default_rng(1)
     vals = rng.integers(0, 2, size=(sample_cols, 1 << log_n), dtype=np.uint64)  # bit columns, like the trace
     t0 = time.perf_counter()
@@ -129,7 +129,11 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headers", type=int, default=256, choices=(256, 512),
+                    help="256 = BASELINE.json configs[1] (the headline metric, default); 512 = configs[2]/[5]")
     args = ap.parse_args()
+    global N_HEADERS
+    N_HEADERS = args.headers
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -177,17 +181,17 @@ def main():
         assert int(res[1][0]) == 0x3145474E41525248 and res[1][4:16].tobytes() == res[0]
         roof = ntt_roofline(ctx)
         line = {
-            "metric": "header_range_256 proofs/sec", "value": round(world * args.steps / elapsed, 4), "unit": "proofs/s",
+            "metric": f"header_range_{N_HEADERS} proofs/sec", "value": round(world * args.steps / elapsed, 4), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks) / u8 (hashes)",
             "data": "synthetic",
             "config": {
-                "workload": f"header_range_256: {N_HEADERS} x 15,360-B synthetic Avail headers (P15k), one input per GPU; "
-                            f"30,720 Blake2b compressions -> BlakeChainAir trace 2^19 rows x {BLAKE_COLS} columns",
+                "workload": f"header_range_{N_HEADERS}: {N_HEADERS} x 15,360-B synthetic Avail headers (P15k), 300 authorities, one input per GPU; "
+                            f"{120 * N_HEADERS:,} Blake2b compressions -> BlakeChainAir trace 2^{19 if N_HEADERS == 256 else 20} rows x {BLAKE_COLS} columns",
                 "complete_proof": False,
                 "stages": ["verify_subchain: Blake2b header hashes, SCALE decode, link + numbering checks, SHA-256 Merkle roots -> 96-B output (native on GPU)",
                            "verify_simple_justification: authority-set SHA-256 chain, precommit, 300 Ed25519 verifications, 2/3 threshold (native on GPU)",
-                           "BlakeChainAir witness: chaining values + 2^19 x 4824 trace generated on the GPU",
+                           "BlakeChainAir witness: chaining values + trace generated on the GPU",
                            "STARK prove (starky-style, rate_bits 1, cap 4, 84 queries, 16 PoW bits): LDE + Poseidon Merkle caps, quotient, openings, "
                            "FRI batch/fold/PoW/queries, proof bytes"],
                 "missing": ["SHA-256 Merkle-root / header-decoding / block-numbering AIRs (checked natively, not yet in a STARK)",
