@@ -8,7 +8,8 @@
 //   G evaluations), r = 13 FIN1 (T = H ^ v_lo, V' = v_hi), r = 14 FIN2 (H = T ^ V' = h_out),
 //   r = 15 PAD (H = next h_in, digest register D updated).
 // Columns: 8 G x 8 words x 64 bits, 64 carries, 32 message-schedule limbs, 64 range-check bits,
-// H register (512 bits), digest register D (8 limbs), flags, byte counter, block number.
+// H register (512 bits), digest register D (8 limbs), flags, byte counter, block number,
+// zero-padding mask (8 mask bits + running count per row).
 // Constraint ORDER is protocol: oracle/blake_air.py restates it independently.
 #pragma once
 #include "air.cuh"
@@ -17,7 +18,7 @@
 namespace blk {
 constexpr int W_A1 = 0, W_D1 = 1, W_C1 = 2, W_B1 = 3, W_A2 = 4, W_D2 = 5, W_C2 = 6, W_B2 = 7;
 constexpr int CAR0 = 4096, MS0 = 4160, MB0 = 4192, H0 = 4256, D0 = 4768;
-constexpr int ACT = 4776, FIN = 4777, FIRST = 4778, CAP = 4779, T = 4780, INC = 4781, TB0 = 4782, IB0 = 4814, NUM = 4822, FA = 4823, COLS = 4824;
+constexpr int ACT = 4776, FIN = 4777, FIRST = 4778, CAP = 4779, T = 4780, INC = 4781, TB0 = 4782, IB0 = 4814, NUM = 4822, FA = 4823, MK0 = 4824, CNT = 4832, COLS = 4833;
 VX_HD constexpr int GB(int k, int w, int i) { return (k * 8 + w) * 64 + i; }
 VX_HD constexpr int CAR(int k, int j) { return CAR0 + k * 8 + j; }
 VX_HD constexpr int MS(int s, int h) { return MS0 + 2 * s + h; }
@@ -191,6 +192,32 @@ struct BlakeAir {
 #pragma unroll 1
             for (int r = 1; r < 16; ++r) acc = acc + sel[r] * loc[MS(rc_slot(r), h)];
             c.constraint(acc - limb(0, MB0, h));
+        }
+        // ---- 6b. bytes at positions >= inc are zero (RFC 7693 zero padding of the last chunk): row r sees
+        // word r's bits (MB); MK is a monotone mask over the 128 byte positions with popcount inc
+        {
+            const F in_blk = one - sel[15];
+#pragma unroll 1
+            for (int b = 0; b < 8; ++b) boolean(MK0 + b);
+#pragma unroll 1
+            for (int b = 0; b < 7; ++b) c.constraint(loc[MK0 + b + 1] * (one - loc[MK0 + b]));
+            c.constraint(in_blk * nxt[MK0] * (one - loc[MK0 + 7]));
+            F msum_l = loc[MK0], msum_n = nxt[MK0];
+#pragma unroll 1
+            for (int b = 1; b < 8; ++b) {
+                msum_l = msum_l + loc[MK0 + b];
+                msum_n = msum_n + nxt[MK0 + b];
+            }
+            c.constraint(sel[0] * (loc[CNT] - msum_l));
+            c.constraint(in_blk * (nxt[CNT] - loc[CNT] - msum_n));
+            c.constraint(sel[15] * (loc[CNT] - loc[INC]));
+#pragma unroll 1
+            for (int b = 0; b < 8; ++b) {
+                F byte = loc[MB0 + 8 * b + 7];
+#pragma unroll 1
+                for (int i = 6; i >= 0; --i) byte = byte + byte + loc[MB0 + 8 * b + i];
+                c.constraint((one - loc[MK0 + b]) * byte);
+            }
         }
         const F first = loc[FIRST];
 #pragma unroll 1

@@ -162,6 +162,8 @@ __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const 
         tr[(size_t)MS(s, 1) * n + row] = w >> 32;
     }
     put_bits(tr, n, row, MB0, m[r]);
+    for (int b = 0; b < 8; ++b) tr[(size_t)(MK0 + b) * n + row] = (uint32_t)(8 * r + b) < d.inc ? 1 : 0;
+    tr[(size_t)CNT * n + row] = d.inc < (uint32_t)(8 * (r + 1)) ? d.inc : (uint32_t)(8 * (r + 1));
     // ---- H register
     for (int w = 0; w < 8; ++w) {
         uint64_t hv = r <= 13 ? h[w] : (r == 14 ? h_out[w] : (d.fin ? (w == 0 ? IV[0] ^ 0x01010020ULL : IV[w]) : h_out[w]));

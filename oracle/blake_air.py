@@ -16,8 +16,8 @@ Layout: 16 rows per compression ("block"), r = row mod 16:
   r = 13     FIN1  : T = H ^ v[0..8), V' = v[8..16)        (in free G columns)
   r = 14     FIN2  : H = T ^ V' = h_out
   r = 15     PAD   : H = next block's h_in (IV^param after a final block), D updated
-Not enforced (documented gaps): zero padding of the final chunk beyond `inc`
-bytes; everything about block numbers / state & data roots (separate AIRs).
+Also enforced: zero padding of the final chunk beyond `inc` bytes (mask columns MK, counter CNT)
+and sequential SCALE block numbers.  Not covered: state & data roots (future AIRs).
 """
 import numpy as np
 
@@ -36,7 +36,8 @@ ACT, FIN, FIRST, CAP, T, INC = 4776, 4777, 4778, 4779, 4780, 4781
 TB0 = 4782
 IB0 = 4814
 NUM, FA = 4822, 4823  # block number of the current header; FA = FIRST * ACT
-COLS = 4824
+MK0, CNT = 4824, 4832  # MK[b]: byte 8r+b of the chunk lies below `inc`; CNT: running count of such bytes
+COLS = 4833
 PUB = 18
 PERIODIC = 16
 PERIOD_LOG = 4
@@ -215,6 +216,9 @@ def gen_trace(messages, log_n, trusted_hash, first_number=None):
                 tr[MS(s, 0), row] = m[order[s]] & 0xFFFFFFFF
                 tr[MS(s, 1), row] = m[order[s]] >> 32
             put_bits(row, MB0, m[r])
+            for b in range(8):
+                tr[MK0 + b, row] = 1 if 8 * r + b < blk["inc"] else 0
+            tr[CNT, row] = min(blk["inc"], 8 * (r + 1))
             # G area
             if r == 0:
                 for w in range(16):
@@ -364,6 +368,25 @@ class BlakeChainAir:
                 term = sel[r] * loc[MS(rc_slot(r), h)]
                 acc = term if acc is None else acc + term
             c.constraint(acc - limb(loc, MB0, h))
+        # ---- 6b. bytes at positions >= inc are zero (RFC 7693 zero padding of the last chunk): row r sees
+        # word r's bits (MB); MK is a monotone mask over the 128 byte positions with popcount inc
+        in_blk = 1 - sel[15]
+        for b in range(8):
+            c.constraint(loc[MK0 + b] * (loc[MK0 + b] - 1))
+        for b in range(7):
+            c.constraint(loc[MK0 + b + 1] * (1 - loc[MK0 + b]))
+        c.constraint(in_blk * nxt[MK0] * (1 - loc[MK0 + 7]))
+        msum_l, msum_n = loc[MK0], nxt[MK0]
+        for b in range(1, 8):
+            msum_l, msum_n = msum_l + loc[MK0 + b], msum_n + nxt[MK0 + b]
+        c.constraint(sel[0] * (loc[CNT] - msum_l))
+        c.constraint(in_blk * (nxt[CNT] - loc[CNT] - msum_n))
+        c.constraint(sel[15] * (loc[CNT] - loc[INC]))
+        for b in range(8):
+            byte = loc[MB0 + 8 * b + 7]
+            for i in range(6, -1, -1):
+                byte = byte + byte + loc[MB0 + 8 * b + i]
+            c.constraint((1 - loc[MK0 + b]) * byte)
         for s in range(4):
             for h in range(2):
                 c.constraint(sel[0] * loc[FIRST] * (loc[MS(s, h)] - loc[D0 + 2 * s + h]))
