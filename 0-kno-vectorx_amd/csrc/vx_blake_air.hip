@@ -12,6 +12,7 @@
 #include "air_blake.cuh"
 #include "vx_internal.h"
 
+
 struct BlockDesc {
     uint64_t msg_off;  // byte offset of the 128-byte chunk in the headers buffer; ~0 = padding block
     uint32_t t, inc;
@@ -276,15 +277,23 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
     return VX_OK;
 }
 
-static const uint64_t VX_HR_MAGIC = 0x3145474e41525248ULL;  // "HRRANGE1"
+static const uint64_t VX_HR_MAGIC = 0x3245474e41525248ULL;  // "HRRANGE2"
+static const size_t VX_HR_HDR = 18;  // magic, max_headers, trusted, target, out96 (12), len(blake proof), len(sha proof)
 
-int32_t vx_header_range_proof_bound(const vx_stark_config* cfg, size_t n_chunks, size_t* n_words) {
+static int sha_log_n(size_t n_keys) {
+    int log_n = 6;
+    while (((size_t)1 << log_n) < 64 * (2 * n_keys - 1)) ++log_n;
+    return log_n;
+}
+
+int32_t vx_header_range_proof_bound(const vx_stark_config* cfg, size_t n_chunks, size_t n_authorities, size_t* n_words) {
     if (!cfg || !n_words || n_chunks == 0) return VX_ERR_ARG;
     int log_n = 4;
-    while (((size_t)16 << (log_n - 4)) < 16 * n_chunks) ++log_n;
-    size_t w = 0;
-    int32_t rc = vx_stark_proof_bound(VX_AIR_BLAKE_CHAIN, cfg, log_n, &w);
-    *n_words = w + 16;
+    while (((size_t)1 << log_n) < 16 * n_chunks) ++log_n;
+    size_t w1 = 0, w2 = 0;
+    int32_t rc = vx_stark_proof_bound(VX_AIR_BLAKE_CHAIN, cfg, log_n, &w1);
+    if (rc == VX_OK && n_authorities) rc = vx_stark_proof_bound(VX_AIR_SHA_CHAIN, cfg, sha_log_n(n_authorities), &w2);
+    *n_words = w1 + w2 + VX_HR_HDR;
     return rc;
 }
 
@@ -300,6 +309,7 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
         VX_TRY(vx_verify_simple_justification(ctx, target_block, out96, just->authority_set_id, just->authority_set_hash, just->precommit,
                                               just->pubkeys, just->signatures, just->validator_signed, just->num_authorities,
                                               just->max_authorities));
+    const bool room = proof_out && proof_cap > VX_HR_HDR;
     // 2. Blake2b parent-hash-chain STARK over every compression of every header
     size_t chunks = 0;
     for (size_t i = 0; i < n_fetched; ++i) chunks += (sizes[i] + 127) / 128;
@@ -309,7 +319,7 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
     VX_TRY(vx_alloc(ctx, ((size_t)blk::COLS) << log_n, &trace));
     uint64_t pub[18];
     int32_t rc = vx_blake_chain_trace(ctx, headers, stride, sizes, n_fetched, trusted_hash, trusted_block + 1, log_n, trace, pub, nullptr);
-    size_t plen = 0;
+    size_t len1 = 0, len2 = 0;
     if (rc == VX_OK) {
         uint8_t tgt[32];
         for (int j = 0; j < 8; ++j) {
@@ -319,16 +329,35 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
         if (memcmp(tgt, out96, 32) != 0) rc = vx_fail(ctx, VX_ERR_STATEMENT, "header_range: chain digest differs from the subchain target hash");
     }
     if (rc == VX_OK)
-        rc = vx_stark_prove(ctx, VX_AIR_BLAKE_CHAIN, cfg, trace, log_n, pub, 18, proof_out && proof_cap > 16 ? proof_out + 16 : nullptr,
-                            proof_cap > 16 ? proof_cap - 16 : 0, &plen);
+        rc = vx_stark_prove(ctx, VX_AIR_BLAKE_CHAIN, cfg, trace, log_n, pub, 18, room ? proof_out + VX_HR_HDR : nullptr, room ? proof_cap - VX_HR_HDR : 0, &len1);
     (void)vx_free(ctx, trace);
-    *proof_len = plen + 16;
+    // 3. authority-set commitment STARK (compute_authority_set_commitment, justification.rs:127-162)
+    if ((rc == VX_OK || rc == VX_ERR_BUFSZ) && just) {
+        const int32_t rc1 = rc;
+        const int sl = sha_log_n(just->num_authorities);
+        vx_buf* st = nullptr;
+        VX_TRY(vx_alloc(ctx, ((size_t)VX_SHA_AIR_COLS) << sl, &st));
+        uint64_t spub[8];
+        uint8_t com[32];
+        rc = vx_sha_chain_trace(ctx, just->pubkeys, just->num_authorities, sl, st, spub, com);
+        if (rc == VX_OK && memcmp(com, just->authority_set_hash, 32) != 0) rc = vx_fail(ctx, VX_ERR_STATEMENT, "header_range: authority-set commitment mismatch");
+        if (rc == VX_OK) {
+            const size_t off = VX_HR_HDR + len1;
+            const bool room2 = rc1 == VX_OK && proof_out && proof_cap > off;
+            rc = vx_stark_prove(ctx, VX_AIR_SHA_CHAIN, cfg, st, sl, spub, 8, room2 ? proof_out + off : nullptr, room2 ? proof_cap - off : 0, &len2);
+            if (rc == VX_OK && rc1 != VX_OK) rc = rc1;
+        }
+        (void)vx_free(ctx, st);
+    }
+    *proof_len = VX_HR_HDR + len1 + len2;
     if (rc != VX_OK) return rc;
     proof_out[0] = VX_HR_MAGIC;
     proof_out[1] = max_headers;
     proof_out[2] = trusted_block;
     proof_out[3] = target_block;
     memcpy(proof_out + 4, out96, 96);
+    proof_out[16] = len1;
+    proof_out[17] = len2;
     return VX_OK;
 }
 }

@@ -17,6 +17,7 @@
 
 #include "air.cuh"
 #include "air_blake.cuh"
+#include "air_sha.cuh"
 #include "poseidon_constants.h"
 #include "vx_internal.h"
 
@@ -235,7 +236,15 @@ static void blake_periodic(std::vector<uint64_t>& v) {
     v.assign(16 * 16, 0);
     for (int k = 0; k < 16; ++k) v[k * 16 + k] = 1;  // sel_k: one-hot on row k of every 16-row block
 }
+static void sha_periodic(std::vector<uint64_t>& v) {
+    v.assign(4 * 64, 0);
+    v[0] = 1;                                     // sel_0
+    v[64 + 63] = 1;                               // sel_63
+    for (int r = 0; r <= 47; ++r) v[128 + r] = 1;  // schedule active
+    for (int r = 0; r < 64; ++r) v[192 + r] = shc::K_H[r];
+}
 static const AirDesc AIRS[] = {
+    {ShaAir::ID, ShaAir::COLS, ShaAir::PUB, ShaAir::PERIODIC, ShaAir::PERIOD_LOG, sha_periodic, launch_q<ShaAir>},
     {BlakeAir::ID, BlakeAir::COLS, BlakeAir::PUB, BlakeAir::PERIODIC, BlakeAir::PERIOD_LOG, blake_periodic, launch_q<BlakeAir>},
     {FibAir::ID, FibAir::COLS, FibAir::PUB, FibAir::PERIODIC, FibAir::PERIOD_LOG, no_periodic, launch_q<FibAir>},
     {MixAir::ID, MixAir::COLS, MixAir::PUB, MixAir::PERIODIC, MixAir::PERIOD_LOG, mix_periodic, launch_q<MixAir>},

@@ -10,6 +10,7 @@
 
 #include "air.cuh"
 #include "air_blake.cuh"
+#include "air_sha.cuh"
 #include "poseidon_constants.h"
 #include "vx_internal.h"
 
@@ -123,7 +124,15 @@ void v_blake_periodic(std::vector<uint64_t>& v) {
     v.assign(256, 0);
     for (int k = 0; k < 16; ++k) v[k * 16 + k] = 1;
 }
+void v_sha_periodic(std::vector<uint64_t>& v) {
+    v.assign(4 * 64, 0);
+    v[0] = 1;
+    v[64 + 63] = 1;
+    for (int r = 0; r <= 47; ++r) v[128 + r] = 1;
+    for (int r = 0; r < 64; ++r) v[192 + r] = shc::K_H[r];
+}
 const AirV V_AIRS[] = {
+    {ShaAir::ID, ShaAir::COLS, ShaAir::PUB, ShaAir::PERIODIC, ShaAir::PERIOD_LOG, v_sha_periodic, eval_host<ShaAir>},
     {FibAir::ID, FibAir::COLS, FibAir::PUB, FibAir::PERIODIC, FibAir::PERIOD_LOG, v_no_periodic, eval_host<FibAir>},
     {MixAir::ID, MixAir::COLS, MixAir::PUB, MixAir::PERIODIC, MixAir::PERIOD_LOG, v_mix_periodic, eval_host<MixAir>},
     {BlakeAir::ID, BlakeAir::COLS, BlakeAir::PUB, BlakeAir::PERIODIC, BlakeAir::PERIOD_LOG, v_blake_periodic, eval_host<BlakeAir>},
@@ -371,13 +380,15 @@ int32_t vx_stark_verify(const vx_stark_config* cfg, const uint64_t* pr, size_t l
 }
 
 int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob, size_t len, uint32_t max_headers,
-                               uint32_t trusted_block, const uint8_t trusted_hash[32], uint32_t target_block,
-                               const uint8_t out96[96], char* err, size_t errlen) {
+                               uint32_t trusted_block, const uint8_t trusted_hash[32], const uint8_t* authority_set_hash,
+                               uint32_t target_block, const uint8_t out96[96], char* err, size_t errlen) {
     if (!cfg || !blob || !trusted_hash || !out96) return VX_ERR_ARG;
-    NEED(len > 16 && blob[0] == 0x3145474e41525248ULL, "bad header_range blob");
+    NEED(len > 18 && blob[0] == 0x3245474e41525248ULL, "bad header_range blob");
     NEED(blob[1] == max_headers && blob[2] == trusted_block && blob[3] == target_block, "blob is for a different request");
     NEED(memcmp(blob + 4, out96, 96) == 0, "public outputs differ from the blob");
     NEED(target_block > trusted_block, "empty block range");
+    const size_t len1 = blob[16], len2 = blob[17];
+    NEED(len1 <= len && len2 <= len && 18 + len1 + len2 == len, "blob lengths are inconsistent");
     uint64_t pub[18];
     for (int j = 0; j < 8; ++j) {
         uint32_t a, b;
@@ -388,6 +399,16 @@ int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob,
     }
     pub[16] = (uint64_t)trusted_block + 1;
     pub[17] = target_block;
-    return vx_stark_verify(cfg, blob + 16, len - 16, VX_AIR_BLAKE_CHAIN, pub, 18, err, errlen);
+    int32_t rc = vx_stark_verify(cfg, blob + 18, len1, VX_AIR_BLAKE_CHAIN, pub, 18, err, errlen);
+    if (rc != VX_OK) return rc;
+    if (authority_set_hash) {  // the EVM input `authority_set_hash` (header_range.rs:35) must be the proven commitment
+        NEED(len2 > 0, "blob carries no authority-set commitment proof");
+        uint64_t spub[8];
+        for (int j = 0; j < 8; ++j)
+            spub[j] = ((uint64_t)authority_set_hash[4 * j] << 24) | ((uint64_t)authority_set_hash[4 * j + 1] << 16) |
+                      ((uint64_t)authority_set_hash[4 * j + 2] << 8) | authority_set_hash[4 * j + 3];
+        rc = vx_stark_verify(cfg, blob + 18 + len1, len2, VX_AIR_SHA_CHAIN, spub, 8, err, errlen);
+    }
+    return rc;
 }
 }

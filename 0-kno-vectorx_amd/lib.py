@@ -24,11 +24,12 @@ SYMBOLS = [
     "vx_fri_fold", "vx_fri_layer_tree", "vx_fri_leaves", "vx_fri_pow",
     "vx_stark_default_config", "vx_stark_proof_bound", "vx_stark_prove", "vx_stark_verify", "vx_header_range_proof_bound", "vx_header_range_prove", "vx_header_range_verify",
     "vx_blake2b_256_batch", "vx_sha256_pairs", "vx_verify_subchain", "vx_blake_chain_trace",
-    "vx_ed25519_verify_batch", "vx_verify_simple_justification",
+    "vx_ed25519_verify_batch", "vx_verify_simple_justification", "vx_sha_chain_trace",
 ]
 
 VX_AIR_FIBONACCI, VX_AIR_MIX, VX_AIR_BLAKE_CHAIN = 1, 2, 3
 VX_BLAKE_AIR_COLS = 4833
+VX_AIR_SHA_CHAIN, VX_SHA_AIR_COLS = 4, 1444
 
 
 class JustificationStruct(C.Structure):
@@ -103,15 +104,16 @@ def load_library():
         "vx_fri_leaves": [vp, vp, C.c_int, C.c_int, vp, sz, vp], "vx_fri_pow": [vp, vp, C.c_int, C.c_int, C.POINTER(u64)],
         "vx_stark_default_config": [C.POINTER(StarkConfig)],
         "vx_stark_proof_bound": [C.c_int, C.POINTER(StarkConfig), C.c_int, C.POINTER(sz)],
-        "vx_header_range_proof_bound": [C.POINTER(StarkConfig), sz, C.POINTER(sz)],
+        "vx_header_range_proof_bound": [C.POINTER(StarkConfig), sz, sz, C.POINTER(sz)],
         "vx_header_range_prove": [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.POINTER(JustificationStruct), C.POINTER(StarkConfig), vp, vp, sz, C.POINTER(sz)],
         "vx_stark_verify": [C.POINTER(StarkConfig), vp, sz, C.c_int, vp, sz, C.c_char_p, sz],
-        "vx_header_range_verify": [C.POINTER(StarkConfig), vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, C.c_char_p, sz],
+        "vx_header_range_verify": [C.POINTER(StarkConfig), vp, sz, C.c_uint32, C.c_uint32, vp, vp, C.c_uint32, vp, C.c_char_p, sz],
         "vx_stark_prove": [vp, C.c_int, C.POINTER(StarkConfig), vp, C.c_int, vp, sz, vp, sz, C.POINTER(sz)],
         "vx_blake2b_256_batch": [vp, vp, sz, vp, sz, vp], "vx_sha256_pairs": [vp, vp, sz, vp],
         "vx_verify_subchain": [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp],
         "vx_blake_chain_trace": [vp, vp, sz, vp, sz, vp, C.c_uint32, C.c_int, vp, vp, vp],
         "vx_ed25519_verify_batch": [vp, vp, vp, vp, C.c_uint32, vp, sz, vp],
+        "vx_sha_chain_trace": [vp, vp, sz, C.c_int, vp, vp, vp],
         "vx_verify_simple_justification": [vp, C.c_uint32, vp, u64, vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32],
     }
     for name, args in sig.items():
@@ -149,14 +151,25 @@ def stark_verify(proof, cfg=None, expect_air=0, expect_public=None):
         raise VxError(rc, err.value.decode())
 
 
-def header_range_verify(blob, max_headers, trusted_block, trusted_hash, target_block, out96, cfg=None):
+HR_HDR = 18  # words before the first proof in a header_range blob
+
+
+def split_blob(blob):
+    """(blake proof words, sha proof words) of a header_range blob."""
+    l1, l2 = int(blob[16]), int(blob[17])
+    return blob[HR_HDR: HR_HDR + l1], blob[HR_HDR + l1: HR_HDR + l1 + l2]
+
+
+def header_range_verify(blob, max_headers, trusted_block, trusted_hash, target_block, out96, cfg=None, authority_set_hash=None):
     L = load_library()
     cfg = cfg or default_stark_config()
     b = np.ascontiguousarray(blob, dtype=np.uint64)
     th = np.frombuffer(bytes(trusted_hash), dtype=np.uint8).copy()
     o = np.frombuffer(bytes(out96), dtype=np.uint8).copy()
+    ah = None if authority_set_hash is None else np.frombuffer(bytes(authority_set_hash), dtype=np.uint8).copy()
     err = C.create_string_buffer(256)
-    rc = L.vx_header_range_verify(C.byref(cfg), _ptr(b), b.size, max_headers, trusted_block, _ptr(th), target_block, _ptr(o), err, 256)
+    rc = L.vx_header_range_verify(C.byref(cfg), _ptr(b), b.size, max_headers, trusted_block, _ptr(th), None if ah is None else _ptr(ah), target_block,
+                                  _ptr(o), err, 256)
     if rc != 0:
         raise VxError(rc, err.value.decode())
 
@@ -348,7 +361,7 @@ class Context:
         th = np.frombuffer(bytes(trusted_hash), dtype=np.uint8).copy()
         chunks = int(((sizes.astype(np.int64) + 127) // 128).sum())
         need = C.c_size_t(0)
-        self._ck(self.L.vx_header_range_proof_bound(C.byref(cfg), chunks, C.byref(need)))
+        self._ck(self.L.vx_header_range_proof_bound(C.byref(cfg), chunks, just.struct.num_authorities if just is not None else 0, C.byref(need)))
         if out is None or out.size < need.value:
             out = np.empty(need.value, dtype=np.uint64)
         out96 = np.zeros(96, dtype=np.uint8)
@@ -378,6 +391,14 @@ class Context:
         dig = np.zeros((sizes.size, 32), dtype=np.uint8)
         self._ck(self.L.vx_blake_chain_trace(self.h, headers_buf.h, stride, _ptr(sizes), sizes.size, _ptr(th), first_block_number, log_n, trace_buf.h, _ptr(pub), _ptr(dig)))
         return trace_buf, pub, dig
+
+    def sha_chain_trace(self, pubkeys, log_n, trace_buf=None):
+        pk = np.ascontiguousarray(np.frombuffer(b"".join(pubkeys), dtype=np.uint8))
+        trace_buf = trace_buf or self.alloc(VX_SHA_AIR_COLS << log_n)
+        pub = np.zeros(8, dtype=np.uint64)
+        com = np.zeros(32, dtype=np.uint8)
+        self._ck(self.L.vx_sha_chain_trace(self.h, _ptr(pk), pk.size // 32, log_n, trace_buf.h, _ptr(pub), _ptr(com)))
+        return trace_buf, pub, com.tobytes()
 
     def ed25519_verify_batch(self, pubkeys, sigs, msg, enabled=None):
         pk = np.ascontiguousarray(np.frombuffer(b"".join(pubkeys), dtype=np.uint8))

@@ -195,6 +195,15 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
                              const uint8_t trusted_hash[32], uint32_t first_block_number, int log_n, vx_buf* trace_out,
                              uint64_t public_inputs_out[18], uint8_t* digests_out);
 
+/* ---- K8: ShaChainAir trace generation (compute_authority_set_commitment, justification.rs:127-162):
+ * the chained SHA-256 commitment h_0 = SHA256(pk_0), h_i = SHA256(h_{i-1} || pk_i) over n_keys 32-byte
+ * keys (host buffer).  Writes the 1444-column trace (64 rows per compression, 2*n_keys - 1
+ * compressions, padded with idle blocks), the 8 public inputs (the commitment as big-endian words)
+ * and optionally the 32 commitment bytes.  Prove with vx_stark_prove(ctx, VX_AIR_SHA_CHAIN, ...). */
+enum { VX_AIR_SHA_CHAIN = 4, VX_SHA_AIR_COLS = 1444 };
+int32_t vx_sha_chain_trace(vx_ctx* ctx, const uint8_t* pubkeys, size_t n_keys, int log_n, vx_buf* trace_out,
+                           uint64_t public_inputs_out[8], uint8_t commitment_out[32]);
+
 /* ---- statement level: verify_subchain (circuits/builder/subchain_verification.rs:56-303)
  * headers: n_fetched encoded headers (blocks trusted+1 .. target) resident in HBM at `stride`
  * bytes each (zero padded), sizes on the host.  max_headers = 256 / 512
@@ -222,8 +231,9 @@ int32_t vx_verify_simple_justification(vx_ctx* ctx, uint32_t block_number, const
                                        const uint8_t* validator_signed, uint32_t num_authorities, uint32_t max_authorities);
 
 /* ---- top level: HeaderRangeCircuit::prove (circuits/header_range.rs:26-59 via Circuit::prove, :167).
- * Inputs as vx_verify_subchain.  Output blob (uint64 words): "HRRANGE1", max_headers, trusted_block,
- * target_block, the 96 public output bytes (12 words), then the BlakeChainAir STARK proof.
+ * Inputs as vx_verify_subchain.  Output blob (uint64 words): "HRRANGE2", max_headers, trusted_block,
+ * target_block, the 96 public output bytes (12 words), the two proof lengths, then the BlakeChainAir
+ * STARK proof and (when a justification was given) the ShaChainAir proof of the authority-set commitment.
  * What the blob proves today is listed in DESIGN.md section 2 (the justification / Merkle-root /
  * numbering gadgets are checked natively by vx_verify_subchain but not yet inside a STARK). */
 /* The justification witness of circuits/vars.rs:40-46 (host buffers; what HintSimpleJustification
@@ -237,7 +247,7 @@ typedef struct vx_justification {
     const uint8_t* validator_signed;   /* max_authorities x 1 */
     uint32_t num_authorities, max_authorities;
 } vx_justification;
-int32_t vx_header_range_proof_bound(const vx_stark_config* cfg, size_t n_chunks, size_t* n_words);
+int32_t vx_header_range_proof_bound(const vx_stark_config* cfg, size_t n_chunks, size_t n_authorities, size_t* n_words);
 /* just may be NULL (subchain only); otherwise verify_simple_justification for (target_block, target
  * header hash) is checked on the GPU before proving, as HeaderRangeCircuit::define does (:49-54). */
 int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_fetched,
@@ -247,8 +257,8 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
 /* HeaderRangeCircuit verify: checks the blob of vx_header_range_prove against the request
  * (blocks, trusted hash) and the claimed 96 output bytes, then verifies the STARK. */
 int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob, size_t blob_len, uint32_t max_headers,
-                               uint32_t trusted_block, const uint8_t trusted_hash[32], uint32_t target_block,
-                               const uint8_t out96[96], char* err, size_t errlen);
+                               uint32_t trusted_block, const uint8_t trusted_hash[32], const uint8_t* authority_set_hash /* 32 B or NULL */,
+                               uint32_t target_block, const uint8_t out96[96], char* err, size_t errlen);
 
 #ifdef __cplusplus
 }

@@ -86,15 +86,24 @@ def test_header_range_prove_end_to_end(ctx, vx, oracle):
     cfg = ctx.stark_config(num_queries=12)
     out96, blob = ctx.header_range_prove(ctx.from_host(ch.headers), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
     assert out96 == ch.expected_outputs(16)
-    assert int(blob[0]) == 0x3145474E41525248 and [int(x) for x in blob[1:4]] == [16, ch.trusted_block, ch.target_block]
+    assert int(blob[0]) == 0x3245474E41525248 and [int(x) for x in blob[1:4]] == [16, ch.trusted_block, ch.target_block]
     assert blob[4:16].tobytes() == out96
-    info = S.verify(blob[16:], dict(S.DEFAULT_CFG, num_queries=12), expect_air=B.ID)
+    info = S.verify(vx.lib.split_blob(blob)[0], dict(S.DEFAULT_CFG, num_queries=12), expect_air=B.ID)
+    assert vx.lib.split_blob(blob)[1].size == 0
     limbs = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "little") for j in range(8)]  # noqa: E731
     assert info["public_inputs"] == limbs(ch.trusted_hash) + limbs(out96[:32]) + [ch.trusted_block + 1, ch.target_block]
     # with a justification: accepted when > 2/3 signed the target, refused otherwise
     good = vx.lib.PackedJustification(vx.synth.Justification(ch.target_block, ch.target_hash, n_auth=9, n_signed=7), 12)
     o2, b2 = ctx.header_range_prove(ctx.from_host(ch.headers), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg, just=good)
-    assert o2 == out96 and (b2 == blob).all()
+    assert o2 == out96 and (vx.lib.split_blob(b2)[0] == vx.lib.split_blob(blob)[0]).all()
+    from oracle import sha_air as A
+    S.register_air(A.ShaChainAir)
+    S.verify(vx.lib.split_blob(b2)[1], dict(S.DEFAULT_CFG, num_queries=12), expect_air=A.ID)
+    vx.lib.header_range_verify(b2, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, o2, cfg, authority_set_hash=good.sh.tobytes())
+    with pytest.raises(vx.VxError):
+        vx.lib.header_range_verify(b2, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, o2, cfg, authority_set_hash=bytes(32))
+    with pytest.raises(vx.VxError):  # a blob without the commitment proof cannot satisfy a request that names a set hash
+        vx.lib.header_range_verify(blob, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg, authority_set_hash=good.sh.tobytes())
     for bad_j in (vx.synth.Justification(ch.target_block, ch.target_hash, n_auth=9, n_signed=6),
                   vx.synth.Justification(ch.target_block, ch.hashes[3], n_auth=9)):
         with pytest.raises(vx.VxError) as e:
