@@ -5,10 +5,10 @@
 // curta's byte-lookup STARK (starkyx v1.0.0, not vendored); this AIR is a from-scratch
 // bit-decomposed ARX arithmetisation of RFC 7693, degree <= 3, 16 rows per compression:
 //   r = 0 INIT (out-state = initial work vector), r = 1..12 ROUND (row r holds round r-1's eight
-//   G evaluations), r = 13 FIN1 (T = H ^ v_lo, V' = v_hi), r = 14 FIN2 (H = T ^ V' = h_out),
+//   G evaluations), r = 13 FIN1 (T = H ^ v_lo, V' = v_hi, bits of H), r = 14 FIN2 (bits of h_out = T ^ V'),
 //   r = 15 PAD (H = next h_in, digest register D updated).
 // Columns: 8 G x 8 words x 64 bits, 64 carries, 32 message-schedule limbs, 64 range-check bits,
-// H register (512 bits), digest register D (8 limbs), flags, byte counter, block number,
+// H register (16 limbs; its bits only in free G cells of rows 13/14), digest register D (8 limbs), flags, byte counter, block number,
 // zero-padding mask (8 mask bits + running count per row).
 // Constraint ORDER is protocol: oracle/blake_air.py restates it independently.
 #pragma once
@@ -17,12 +17,17 @@
 
 namespace blk {
 constexpr int W_A1 = 0, W_D1 = 1, W_C1 = 2, W_B1 = 3, W_A2 = 4, W_D2 = 5, W_C2 = 6, W_B2 = 7;
-constexpr int CAR0 = 4096, MS0 = 4160, MB0 = 4192, H0 = 4256, D0 = 4768;
-constexpr int ACT = 4776, FIN = 4777, FIRST = 4778, CAP = 4779, T = 4780, INC = 4781, TB0 = 4782, IB0 = 4814, NUM = 4822, FA = 4823, MK0 = 4824, CNT = 4832, COLS = 4833;
+constexpr int CAR0 = 4096, MS0 = 4160, MB0 = 4192, HL0 = 4256, D0 = 4272;
+constexpr int ACT = 4280, FIN = 4281, FIRST = 4282, CAP = 4283, T = 4284, INC = 4285, TB0 = 4286, IB0 = 4318, NUM = 4326, FA = 4327, MK0 = 4328, CNT = 4336, COLS = 4337;
 VX_HD constexpr int GB(int k, int w, int i) { return (k * 8 + w) * 64 + i; }
 VX_HD constexpr int CAR(int k, int j) { return CAR0 + k * 8 + j; }
 VX_HD constexpr int MS(int s, int h) { return MS0 + 2 * s + h; }
-VX_HD constexpr int H(int w, int i) { return H0 + 64 * w + i; }
+VX_HD constexpr int HL(int w, int h) { return HL0 + 2 * w + h; }  // chaining value as 16 limbs
+// free G cells of the finalisation rows: row 13 holds T = H ^ v_lo (FT), V' = v_hi (FV), the bits of H (FH);
+// row 14 holds the bits of h_out (FT)
+VX_HD constexpr int FT(int w, int i) { return GB(w % 4, w / 4, i); }
+VX_HD constexpr int FV(int w, int i) { return GB(w % 4, 2 + w / 4, i); }
+VX_HD constexpr int FH(int w, int i) { return GB(w % 4, 4 + w / 4, i); }
 // first bit column of out-state word v[w] (the diagonal-step outputs of a row)
 VX_HD constexpr int OUT(int w) {
     return w < 4 ? GB(4 + w, W_A2, 0)
@@ -77,8 +82,6 @@ struct BlakeAir {
         for (int col = 0; col < 4096; ++col) boolean(col);
 #pragma unroll 1
         for (int col = MB0; col < MB0 + 64; ++col) boolean(col);
-#pragma unroll 1
-        for (int col = H0; col < H0 + 512; ++col) boolean(col);
 #pragma unroll 1
         for (int col = TB0; col < TB0 + 32; ++col) boolean(col);
 #pragma unroll 1
@@ -144,16 +147,18 @@ struct BlakeAir {
 #pragma unroll 1
         for (int wd = 0; wd < 16; ++wd) {
             const int col0 = OUT(wd);
+            if (wd < 8) {  // v[0..8) = h_in: compared limb-wise with the H register
+#pragma unroll 1
+                for (int h = 0; h < 2; ++h) c.constraint(sel[0] * (limb(0, col0, h) - loc[HL(wd, h)]));
+                continue;
+            }
 #pragma unroll 1
             for (int i = 0; i < 64; ++i) {
                 F cell = loc[col0 + i], want;
-                if (wd < 8) want = loc[H(wd, i)];
-                else {
-                    const int bit = (int)((iv(wd - 8) >> i) & 1);
-                    if (wd == 12 && i < 32) want = bit ? one - loc[TB0 + i] : loc[TB0 + i];
-                    else if (wd == 14) want = bit ? one - fin : fin;
-                    else want = F::from((uint64_t)bit);
-                }
+                const int bit = (int)((iv(wd - 8) >> i) & 1);
+                if (wd == 12 && i < 32) want = bit ? one - loc[TB0 + i] : loc[TB0 + i];
+                else if (wd == 14) want = bit ? one - fin : fin;
+                else want = F::from((uint64_t)bit);
                 c.constraint(sel[0] * (cell - want));
             }
         }
@@ -162,17 +167,22 @@ struct BlakeAir {
         for (int r = 0; r < 13; ++r) keep_h = keep_h + sel[r];
 #pragma unroll 1
         for (int wd = 0; wd < 8; ++wd) {
-            const int lo0 = OUT(wd), hi0 = OUT(8 + wd), t0 = GB(wd % 4, wd / 4, 0), v0 = GB(wd % 4, 2 + wd / 4, 0);
+            const int lo0 = OUT(wd), hi0 = OUT(8 + wd);
             const uint64_t ivp = wd == 0 ? (iv(0) ^ 0x01010020ULL) : iv(wd);
 #pragma unroll 1
             for (int i = 0; i < 64; ++i) {
-                const F h = loc[H(wd, i)], hn = nxt[H(wd, i)];
-                c.constraint(sel[12] * (nxt[t0 + i] - xorf(h, loc[lo0 + i])));
-                c.constraint(sel[12] * (nxt[v0 + i] - loc[hi0 + i]));
-                c.constraint(sel[13] * (hn - xorf(loc[t0 + i], loc[v0 + i])));
-                const F ib = F::from((ivp >> i) & 1);
-                c.constraint(sel[14] * (hn - (fin * ib + (one - fin) * h)));
-                c.constraint(keep_h * (hn - h));
+                c.constraint(sel[12] * (nxt[FT(wd, i)] - xorf(nxt[FH(wd, i)], loc[lo0 + i])));
+                c.constraint(sel[12] * (nxt[FV(wd, i)] - loc[hi0 + i]));
+                c.constraint(sel[13] * (nxt[FT(wd, i)] - xorf(loc[FT(wd, i)], loc[FV(wd, i)])));
+            }
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                const F hl = loc[HL(wd, h)], hn = nxt[HL(wd, h)];
+                const F ivl = F::from((ivp >> (32 * h)) & 0xFFFFFFFFULL);
+                c.constraint(sel[13] * (hl - limb(0, FH(wd, 0), h)));
+                c.constraint(sel[14] * (hl - limb(0, FT(wd, 0), h)));
+                c.constraint(sel[14] * (hn - (fin * ivl + (one - fin) * hl)));
+                c.constraint(keep_h * (hn - hl));
             }
         }
         // ---- 6. message schedule, range check, link
@@ -257,7 +267,7 @@ struct BlakeAir {
         for (int j = 0; j < 8; ++j) {
             const F d = loc[D0 + j], dn = nxt[D0 + j];
             c.transition((one - sel[14]) * (dn - d));
-            c.constraint(sel[14] * (dn - (cap * limb(0, H(j / 2, 0), j % 2) + (one - cap) * d)));
+            c.constraint(sel[14] * (dn - (cap * loc[HL(j / 2, j % 2)] + (one - cap) * d)));
         }
         // ---- 9. boundary
 #pragma unroll 1

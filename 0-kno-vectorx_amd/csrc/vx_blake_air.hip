@@ -151,9 +151,12 @@ __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const 
             for (int w = 0; w < 16; ++w) put_bits(tr, n, row, OUT(w), v0[w]);
         } else if (r == 13) {
             for (int w = 0; w < 8; ++w) {
-                put_bits(tr, n, row, GB(w % 4, w / 4, 0), h[w] ^ vfin[w]);
-                put_bits(tr, n, row, GB(w % 4, 2 + w / 4, 0), vfin[8 + w]);
+                put_bits(tr, n, row, FT(w, 0), h[w] ^ vfin[w]);
+                put_bits(tr, n, row, FV(w, 0), vfin[8 + w]);
+                put_bits(tr, n, row, FH(w, 0), h[w]);
             }
+        } else if (r == 14) {
+            for (int w = 0; w < 8; ++w) put_bits(tr, n, row, FT(w, 0), h_out[w]);
         }
     }
     // ---- message schedule + range check of natural word r
@@ -167,8 +170,9 @@ __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const 
     tr[(size_t)CNT * n + row] = d.inc < (uint32_t)(8 * (r + 1)) ? d.inc : (uint32_t)(8 * (r + 1));
     // ---- H register
     for (int w = 0; w < 8; ++w) {
-        uint64_t hv = r <= 13 ? h[w] : (r == 14 ? h_out[w] : (d.fin ? (w == 0 ? IV[0] ^ 0x01010020ULL : IV[w]) : h_out[w]));
-        put_bits(tr, n, row, H(w, 0), hv);
+        const uint64_t hv = r <= 13 ? h[w] : (r == 14 ? h_out[w] : (d.fin ? (w == 0 ? IV[0] ^ 0x01010020ULL : IV[w]) : h_out[w]));
+        tr[(size_t)HL(w, 0) * n + row] = hv & 0xFFFFFFFFULL;
+        tr[(size_t)HL(w, 1) * n + row] = hv >> 32;
     }
     // ---- digest register, flags, counters
     const bool cap = d.act && d.fin;

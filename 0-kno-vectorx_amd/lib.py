@@ -28,7 +28,7 @@ SYMBOLS = [
 ]
 
 VX_AIR_FIBONACCI, VX_AIR_MIX, VX_AIR_BLAKE_CHAIN = 1, 2, 3
-VX_BLAKE_AIR_COLS = 4833
+VX_BLAKE_AIR_COLS = 4337
 VX_AIR_SHA_CHAIN, VX_SHA_AIR_COLS = 4, 1444
 
 

@@ -35,7 +35,7 @@ PROFILE = "P15k"
 # 30,720 compressions x 16 rows -> 2^19 rows, 4822 columns), measured on a 1024-column slab.
 NTT_LOG_N = 19
 NTT_COLS = 1024
-BLAKE_COLS = 4833
+BLAKE_COLS = 4337
 
 
 class Workload:

@@ -184,13 +184,13 @@ int32_t vx_sha256_pairs(vx_ctx* ctx, const uint8_t* pairs64, size_t n, uint8_t* 
 /* ---- K8: BlakeChainAir trace generation (the Blake2b witness behind hash_encoded_header,
  * circuits/builder/header.rs:14-19, and the parent-hash links of
  * circuits/builder/subchain_verification.rs:163-177).  headers as for vx_verify_subchain (stride a
- * multiple of 128).  Writes the column-major trace (4833 columns x 2^log_n rows, 16 rows per
+ * multiple of 128).  Writes the column-major trace (4337 columns x 2^log_n rows, 16 rows per
  * compression, padded with inactive blocks) into trace_out, the 18 public inputs (trusted hash,
  * target hash as 32-bit little-endian limbs, first and last block number) and optionally the
  * digests (host).  The AIR also proves that header i carries block number first_block_number + i
  * as a 4-byte SCALE compact int (numbers in [2^14, 2^30); decoder.rs:64-66, subchain_verification.rs:166-168).
  * Prove it with vx_stark_prove(ctx, VX_AIR_BLAKE_CHAIN, ...). */
-enum { VX_AIR_BLAKE_CHAIN = 3, VX_BLAKE_AIR_COLS = 4833 };
+enum { VX_AIR_BLAKE_CHAIN = 3, VX_BLAKE_AIR_COLS = 4337 };
 int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_headers,
                              const uint8_t trusted_hash[32], uint32_t first_block_number, int log_n, vx_buf* trace_out,
                              uint64_t public_inputs_out[18], uint8_t* digests_out);

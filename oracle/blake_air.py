@@ -13,9 +13,10 @@ not claimed -- parity here is GPU trace/proof == this restatement, digests == ha
 Layout: 16 rows per compression ("block"), r = row mod 16:
   r = 0      INIT  : the out-state columns hold the initial work vector v
   r = 1..12  ROUND : row r holds the 8 G evaluations of round r-1 (column step then diagonal)
-  r = 13     FIN1  : T = H ^ v[0..8), V' = v[8..16)        (in free G columns)
-  r = 14     FIN2  : H = T ^ V' = h_out
+  r = 13     FIN1  : T = H ^ v[0..8), V' = v[8..16), HB = bits of H   (in free G columns)
+  r = 14     FIN2  : HO = T ^ V' = h_out bits (free G columns), H limbs = h_out
   r = 15     PAD   : H = next block's h_in (IV^param after a final block), D updated
+The chaining value H is carried as 16 limb columns; its bits exist only where an XOR needs them.
 Also enforced: zero padding of the final chunk beyond `inc` bytes (mask columns MK, counter CNT)
 and sequential SCALE block numbers.  Not covered: state & data roots (future AIRs).
 """
@@ -30,14 +31,14 @@ W_A1, W_D1, W_C1, W_B1, W_A2, W_D2, W_C2, W_B2 = range(8)
 CAR0 = 4096  # CAR(k, j)
 MS0 = 4160  # MS(s, h)
 MB0 = 4192
-H0 = 4256
-D0 = 4768
-ACT, FIN, FIRST, CAP, T, INC = 4776, 4777, 4778, 4779, 4780, 4781
-TB0 = 4782
-IB0 = 4814
-NUM, FA = 4822, 4823  # block number of the current header; FA = FIRST * ACT
-MK0, CNT = 4824, 4832  # MK[b]: byte 8r+b of the chunk lies below `inc`; CNT: running count of such bytes
-COLS = 4833
+HL0 = 4256  # chaining value H as 16 x 32-bit limbs: HL(w, h); its bits appear only in free G cells of rows 13/14
+D0 = 4272
+ACT, FIN, FIRST, CAP, T, INC = 4280, 4281, 4282, 4283, 4284, 4285
+TB0 = 4286
+IB0 = 4318
+NUM, FA = 4326, 4327  # block number of the current header; FA = FIRST * ACT
+MK0, CNT = 4328, 4336  # MK[b]: byte 8r+b of the chunk lies below `inc`; CNT: running count of such bytes
+COLS = 4337
 PUB = 18
 PERIODIC = 16
 PERIOD_LOG = 4
@@ -68,8 +69,20 @@ def MS(s, h):
     return MS0 + 2 * s + h
 
 
-def H(w, i):
-    return H0 + 64 * w + i
+def HL(w, h):
+    return HL0 + 2 * w + h
+
+
+def FT(w, i):  # row 13: T = H ^ v_lo;  row 14: HO = h_out bits
+    return GB(w % 4, w // 4, i)
+
+
+def FV(w, i):  # row 13: V' = v_hi
+    return GB(w % 4, 2 + w // 4, i)
+
+
+def FH(w, i):  # row 13: HB = bits of h_in
+    return GB(w % 4, 4 + w // 4, i)
 
 
 def out_word(w):
@@ -209,7 +222,7 @@ def gen_trace(messages, log_n, trusted_hash, first_number=None):
                 tr[D0 + j, row] = dl[j]
             hv = blk["h"] if r <= 13 else (h_out if r == 14 else h_next)
             for w in range(8):
-                put_bits(row, H(w, 0), hv[w])
+                tr[HL(w, 0), row], tr[HL(w, 1), row] = hv[w] & 0xFFFFFFFF, hv[w] >> 32
             # message schedule + range check of natural word r
             order = ms_order(r)
             for s in range(16):
@@ -246,8 +259,12 @@ def gen_trace(messages, log_n, trusted_hash, first_number=None):
             elif r == 13:
                 vfin = recs[11]["v"]
                 for w in range(8):
-                    put_bits(row, GB(w % 4, w // 4, 0), blk["h"][w] ^ vfin[w])
-                    put_bits(row, GB(w % 4, 2 + w // 4, 0), vfin[8 + w])
+                    put_bits(row, FT(w, 0), blk["h"][w] ^ vfin[w])
+                    put_bits(row, FV(w, 0), vfin[8 + w])
+                    put_bits(row, FH(w, 0), blk["h"][w])
+            elif r == 14:
+                for w in range(8):
+                    put_bits(row, FT(w, 0), h_out[w])
     lt, lg = [int.from_bytes(trusted_hash[4 * j: 4 * j + 4], "little") for j in range(8)], [int.from_bytes(target[4 * j: 4 * j + 4], "little") for j in range(8)]
     return tr, lt + lg + [first_number, last_number], target
 
@@ -278,7 +295,7 @@ class BlakeChainAir:
         # ---- 1. booleans
         for col in range(0, 4096):
             c.constraint(loc[col] * (loc[col] - 1))
-        for col in list(range(MB0, MB0 + 64)) + list(range(H0, H0 + 512)) + list(range(TB0, TB0 + 32)) + list(range(IB0, IB0 + 8)) + [ACT, FIN, FIRST, CAP, FA]:
+        for col in list(range(MB0, MB0 + 64)) + list(range(TB0, TB0 + 32)) + list(range(IB0, IB0 + 8)) + [ACT, FIN, FIRST, CAP, FA]:
             c.constraint(loc[col] * (loc[col] - 1))
         # ---- 2. carries
         for k in range(8):
@@ -327,18 +344,19 @@ class BlakeChainAir:
         # ---- 4. INIT row: out-state = (H, IV[0..4), IV4 ^ t, IV5, IV6 ^ f, IV7)
         for wd in range(16):
             k, slot = out_word(wd)
+            if wd < 8:  # v[0..8) = h_in: compared limb-wise with the H register
+                for h in range(2):
+                    c.constraint(sel[0] * (limb(loc, GB(k, slot, 0), h) - loc[HL(wd, h)]))
+                continue
             for i in range(64):
                 cell = loc[GB(k, slot, i)]
-                if wd < 8:
-                    want = loc[H(wd, i)]
+                bit = (IV[wd - 8] >> i) & 1
+                if wd == 12 and i < 32:
+                    want = loc[TB0 + i] if bit == 0 else 1 - loc[TB0 + i]
+                elif wd == 14:
+                    want = loc[FIN] if bit == 0 else 1 - loc[FIN]
                 else:
-                    bit = (IV[wd - 8] >> i) & 1
-                    if wd == 12 and i < 32:
-                        want = loc[TB0 + i] if bit == 0 else 1 - loc[TB0 + i]
-                    elif wd == 14:
-                        want = loc[FIN] if bit == 0 else 1 - loc[FIN]
-                    else:
-                        want = bit
+                    want = bit
                 c.constraint(sel[0] * (cell - want))
         # ---- 5. finalisation: FIN1 (T = H ^ vlo, V' = vhi), FIN2 (H' = T ^ V'), PAD (H' = f ? IVP : H)
         keep_h = sel[15]
@@ -348,12 +366,15 @@ class BlakeChainAir:
             klo, slo = out_word(wd)
             khi, shi = out_word(8 + wd)
             for i in range(64):
-                c.constraint(sel[12] * (nxt[GB(wd % 4, wd // 4, i)] - xor(loc[H(wd, i)], loc[GB(klo, slo, i)])))
-                c.constraint(sel[12] * (nxt[GB(wd % 4, 2 + wd // 4, i)] - loc[GB(khi, shi, i)]))
-                c.constraint(sel[13] * (nxt[H(wd, i)] - xor(loc[GB(wd % 4, wd // 4, i)], loc[GB(wd % 4, 2 + wd // 4, i)])))
-                ivp = (IVP[wd] >> i) & 1
-                c.constraint(sel[14] * (nxt[H(wd, i)] - (loc[FIN] * ivp + (1 - loc[FIN]) * loc[H(wd, i)])))
-                c.constraint(keep_h * (nxt[H(wd, i)] - loc[H(wd, i)]))
+                c.constraint(sel[12] * (nxt[FT(wd, i)] - xor(nxt[FH(wd, i)], loc[GB(klo, slo, i)])))
+                c.constraint(sel[12] * (nxt[FV(wd, i)] - loc[GB(khi, shi, i)]))
+                c.constraint(sel[13] * (nxt[FT(wd, i)] - xor(loc[FT(wd, i)], loc[FV(wd, i)])))
+            for h in range(2):
+                ivp = (IVP[wd] >> (32 * h)) & 0xFFFFFFFF
+                c.constraint(sel[13] * (loc[HL(wd, h)] - limb(loc, FH(wd, 0), h)))
+                c.constraint(sel[14] * (loc[HL(wd, h)] - limb(loc, FT(wd, 0), h)))
+                c.constraint(sel[14] * (nxt[HL(wd, h)] - (loc[FIN] * ivp + (1 - loc[FIN]) * loc[HL(wd, h)])))
+                c.constraint(keep_h * (nxt[HL(wd, h)] - loc[HL(wd, h)]))
         # ---- 6. message schedule, range check, link to the previous digest
         for s in range(16):
             for h in range(2):
@@ -414,7 +435,7 @@ class BlakeChainAir:
         # ---- 8. digest register D: captured at FIN2 -> PAD of an active final block
         for j in range(8):
             c.transition((1 - sel[14]) * (nxt[D0 + j] - loc[D0 + j]))
-            c.constraint(sel[14] * (nxt[D0 + j] - (loc[CAP] * limb(loc, H(j // 2, 0), j % 2) + (1 - loc[CAP]) * loc[D0 + j])))
+            c.constraint(sel[14] * (nxt[D0 + j] - (loc[CAP] * loc[HL(j // 2, j % 2)] + (1 - loc[CAP]) * loc[D0 + j])))
         # ---- 9. boundary: chain starts at the trusted hash, ends at the target hash with a final block
         for j in range(8):
             c.first_row(loc[D0 + j] - pub[j])

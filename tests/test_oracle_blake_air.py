@@ -25,7 +25,7 @@ def test_trace_satisfies_constraints_and_detects_corruption(oracle):
     tr, pub, tgt = B.gen_trace(msgs, 7, trusted)
     assert tgt == target
     assert B.first_violation(tr, pub) is None
-    for col, row in ((B.GB(5, 3, 17), 20), (B.CAR(2, 0), 37), (B.MS(3, 1), 5), (B.D0 + 2, 40), (B.H(3, 3), 30), (B.FIN, 70), (B.T, 17), (B.MB0 + 9, 3)):
+    for col, row in ((B.GB(5, 3, 17), 20), (B.CAR(2, 0), 37), (B.MS(3, 1), 5), (B.D0 + 2, 40), (B.HL(3, 1), 30), (B.FH(2, 9), 29), (B.FT(1, 4), 30), (B.FIN, 70), (B.T, 17), (B.MB0 + 9, 3)):
         bad = tr.copy()
         bad[col, row] ^= np.uint64(1)
         assert B.first_violation(bad, pub, rows=range(max(0, row - 1), row + 1)) is not None, (col, row)
