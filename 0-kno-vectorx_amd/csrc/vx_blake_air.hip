@@ -333,7 +333,7 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
         if (memcmp(tgt, out96, 32) != 0) rc = vx_fail(ctx, VX_ERR_STATEMENT, "header_range: chain digest differs from the subchain target hash");
     }
     if (rc == VX_OK)
-        rc = vx_stark_prove(ctx, VX_AIR_BLAKE_CHAIN, cfg, trace, log_n, pub, 18, room ? proof_out + VX_HR_HDR : nullptr, room ? proof_cap - VX_HR_HDR : 0, &len1);
+        rc = vx_stark_prove_impl(ctx, VX_AIR_BLAKE_CHAIN, cfg, trace->d, trace->n, /*consume_trace=*/1, log_n, pub, 18, room ? proof_out + VX_HR_HDR : nullptr, room ? proof_cap - VX_HR_HDR : 0, &len1);
     (void)vx_free(ctx, trace);
     // 3. authority-set commitment STARK (compute_authority_set_commitment, justification.rs:127-162)
     if ((rc == VX_OK || rc == VX_ERR_BUFSZ) && just) {
@@ -348,7 +348,7 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
         if (rc == VX_OK) {
             const size_t off = VX_HR_HDR + len1;
             const bool room2 = rc1 == VX_OK && proof_out && proof_cap > off;
-            rc = vx_stark_prove(ctx, VX_AIR_SHA_CHAIN, cfg, st, sl, spub, 8, room2 ? proof_out + off : nullptr, room2 ? proof_cap - off : 0, &len2);
+            rc = vx_stark_prove_impl(ctx, VX_AIR_SHA_CHAIN, cfg, st->d, st->n, /*consume_trace=*/1, sl, spub, 8, room2 ? proof_out + off : nullptr, room2 ? proof_cap - off : 0, &len2);
             if (rc == VX_OK && rc1 != VX_OK) rc = rc1;
         }
         (void)vx_free(ctx, st);

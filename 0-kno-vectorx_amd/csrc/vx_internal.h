@@ -118,3 +118,7 @@ struct Tw2 {
     int lo_bits;
 };
 int32_t vx_get_tw2(vx_ctx* ctx, int log_s, int inverse, Tw2* out);
+int32_t vx_lde_consume_dev(vx_ctx* ctx, uint64_t* values, int log_n, size_t n_cols, int rate_bits, uint64_t shift, uint64_t* dst);
+int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg, uint64_t* trace_d, size_t trace_len, int consume_trace,
+                            int log_n, const uint64_t* public_inputs, size_t n_public, uint64_t* proof_out, size_t proof_cap,
+                            size_t* proof_len);

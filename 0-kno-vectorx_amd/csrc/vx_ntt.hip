@@ -551,6 +551,21 @@ int32_t vx_lde_dev(vx_ctx* ctx, const uint64_t* src, int log_n, size_t n_cols, i
     return ntt_dit(ctx, co, n, dst, N, log_n + rate_bits, n_cols, 0, rate_bits, st.d);
 }
 
+// Same as vx_lde_dev(VX_LDE_SRC_VALUES) but the inverse transform runs IN PLACE on `values`
+// (which is left holding the coefficients in bit-reversed positions): no n*c scratch copy, so a
+// trace of t bytes needs t + 2^r t instead of 2t + 2^r t -- what lets the MAX_HEADER_SIZE case fit in HBM.
+int32_t vx_lde_consume_dev(vx_ctx* ctx, uint64_t* values, int log_n, size_t n_cols, int rate_bits, uint64_t shift, uint64_t* dst) {
+    const size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    PowTab st{nullptr};
+    if (shift > 1) VX_TRY(vx_get_shift_tab(ctx, shift, &st));
+    if (log_n > 0) VX_TRY(ntt_dif(ctx, values, n, values, n, log_n, n_cols, 1, glh::inv((uint64_t)n % glh::P)));
+    if (log_n + rate_bits == 0) {
+        VX_HIP(hipMemcpyAsync(dst, values, n_cols * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return VX_OK;
+    }
+    return ntt_dit(ctx, values, n, dst, N, log_n + rate_bits, n_cols, 0, rate_bits, st.d);
+}
+
 int32_t vx_gather_rows_dev(vx_ctx* ctx, const uint64_t* lde, int log_N, size_t n_cols, const uint64_t* leaf_idx, size_t n_idx,
                            uint64_t* out) {
     if (n_idx == 0) return VX_OK;

@@ -145,30 +145,32 @@ __global__ __launch_bounds__(256) void k_quotient(QuotArgs a) {
     a.q_out[N + i] = gl_mul(c.acc[1].v, a.zh_inv[k]);
 }
 
-// barycentric weights over the trace domain H: w0[i] = w^i / (zeta - w^i), w1[i] = w^i / (w*zeta - w^i)
-__global__ __launch_bounds__(256) void k_bary_weights(int log_n, gl2 zeta, gl2 zeta_next, const uint64_t* tw, uint64_t* w0,
+// Openings from the committed LDE: the n points x_i = g * w_n^i (LDE indices i << r) determine a polynomial
+// of degree < n,  P(z) = (z^n - g^n) / (n g^n) * sum_i v_i * x_i / (z - x_i).
+// w0[i] = x_i / (zeta - x_i), w1[i] = x_i / (w*zeta - x_i)
+__global__ __launch_bounds__(256) void k_bary_weights(int log_n, uint64_t shift, gl2 zeta, gl2 zeta_next, const uint64_t* tw, uint64_t* w0,
                                                       uint64_t* w1) {
     size_t n = (size_t)1 << log_n;
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint64_t wi = root_pow_f(tw, i, log_n);
-    gl2 d0 = gl2_inv({gl_sub(zeta.a, wi), zeta.b});
-    gl2 d1 = gl2_inv({gl_sub(zeta_next.a, wi), zeta_next.b});
-    d0 = gl2_scale(d0, wi);
-    d1 = gl2_scale(d1, wi);
+    uint64_t xi = gl_mul(shift, root_pow_f(tw, i, log_n));
+    gl2 d0 = gl2_inv({gl_sub(zeta.a, xi), zeta.b});
+    gl2 d1 = gl2_inv({gl_sub(zeta_next.a, xi), zeta_next.b});
+    d0 = gl2_scale(d0, xi);
+    d1 = gl2_scale(d1, xi);
     w0[2 * i] = d0.a;
     w0[2 * i + 1] = d0.b;
     w1[2 * i] = d1.a;
     w1[2 * i + 1] = d1.b;
 }
-// out[col] = (sum_i T[col][i] * w0[i], sum_i T[col][i] * w1[i]); one block per column
-__global__ __launch_bounds__(256) void k_bary_dot(const uint64_t* vals, size_t n, const uint64_t* w0, const uint64_t* w1,
-                                                  uint64_t* out) {
+// out[col] = (sum_i V[col][i << log_step] * w0[i], sum_i V[col][i << log_step] * w1[i]); one block per column
+__global__ __launch_bounds__(256) void k_bary_dot(const uint64_t* vals, size_t col_stride, int log_step, size_t n, const uint64_t* w0,
+                                                  const uint64_t* w1, uint64_t* out) {
     __shared__ uint64_t red[256 * 4];
-    const uint64_t* col = vals + blockIdx.x * n;
+    const uint64_t* col = vals + blockIdx.x * col_stride;
     gl2 s0{0, 0}, s1{0, 0};
     for (size_t i = threadIdx.x; i < n; i += 256) {
-        uint64_t v = col[i];
+        uint64_t v = col[i << log_step];
         s0 = gl2_add(s0, gl2_scale({w0[2 * i], w0[2 * i + 1]}, v));
         s1 = gl2_add(s1, gl2_scale({w1[2 * i], w1[2 * i + 1]}, v));
     }
@@ -351,6 +353,16 @@ int32_t vx_stark_prove(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_in, c
                        const uint64_t* public_inputs, size_t n_public, uint64_t* proof_out, size_t proof_cap,
                        size_t* proof_len) {
     if (!ctx || !cfg_in || !trace || !proof_len) return VX_ERR_ARG;
+    return vx_stark_prove_impl(ctx, air_id, cfg_in, trace->d, trace->n, 0, log_n, public_inputs, n_public, proof_out, proof_cap, proof_len);
+}
+}  // extern "C"
+
+// consume_trace != 0: the trace buffer is overwritten (it ends up holding the bit-reversed coefficients);
+// saves the n*c coefficient scratch -- the caller must own the buffer.
+int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_in, uint64_t* trace_d, size_t trace_len, int consume_trace,
+                            int log_n, const uint64_t* public_inputs, size_t n_public, uint64_t* proof_out, size_t proof_cap,
+                            size_t* proof_len) {
+    if (!ctx || !cfg_in || !trace_d || !proof_len) return VX_ERR_ARG;
     const AirDesc* air = find_air(air_id);
     VX_CHECK(air, "stark prove: unknown AIR id %d", air_id);
     const vx_stark_config cfg = *cfg_in;
@@ -362,7 +374,7 @@ int32_t vx_stark_prove(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_in, c
     VX_CHECK(cfg.cap_height >= 0 && cfg.cap_height <= LN, "stark prove: cap_height %d > log2(lde size) %d", cfg.cap_height, LN);
     VX_CHECK((int)n_public == air->pub && (n_public == 0 || public_inputs), "stark prove: AIR %d takes %d public inputs", air_id, air->pub);
     const size_t n = (size_t)1 << L, N = (size_t)1 << LN, c = air->cols;
-    VX_CHECK(trace->n >= n * c, "stark prove: trace holds %zu < %zu elements", trace->n, n * c);
+    VX_CHECK(trace_len >= n * c, "stark prove: trace holds %zu < %zu elements", trace_len, n * c);
     for (size_t i = 0; i < n_public; ++i) VX_CHECK(public_inputs[i] < glh::P, "stark prove: public input %zu not canonical", i);
     const int Q = 2, nq = 2 * Q;  // quotient_degree_factor 2 (constraint degree 3), 2 challenges
     const uint64_t g = 7;         // F::coset_shift()
@@ -372,7 +384,8 @@ int32_t vx_stark_prove(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_in, c
     // ---- 1. trace commitment: PolynomialBatch::from_values
     uint64_t* trace_lde = mem.alloc(N * c);
     VX_CHECK(trace_lde, "stark prove: out of device memory (trace LDE)");
-    VX_TRY(vx_lde_dev(ctx, trace->d, L, c, r, g, VX_LDE_SRC_VALUES, trace_lde, nullptr));
+    if (consume_trace) VX_TRY(vx_lde_consume_dev(ctx, trace_d, L, c, r, g, trace_lde));
+    else VX_TRY(vx_lde_dev(ctx, trace_d, L, c, r, g, VX_LDE_SRC_VALUES, trace_lde, nullptr));
     vx_tree* t_trace = nullptr;
     VX_TRY(vx_merkle_build_dev(ctx, trace_lde, N, c, VX_LEAVES_COLS_BITREV, cfg.cap_height, &t_trace));
     mem.trees.push_back(t_trace);
@@ -458,25 +471,25 @@ int32_t vx_stark_prove(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_in, c
         VX_CHECK(!(zn.a == 1 && zn.b == 0), "stark prove: zeta landed in the trace subgroup");
     }
 
-    // ---- 3. openings (StarkOpeningSet::new): barycentric dot products over the trace domain
-    VX_TRY(vx_ntt_dev(ctx, qv, L, nq, n, 0, 0, VX_ORDER_NATURAL));  // quotient chunk values on H
+    // ---- 3. openings (StarkOpeningSet::new): barycentric dot products over the committed LDE values at the
+    // coset points g * w_n^i (every 2^r-th LDE point) -- neither the trace values nor coefficients are needed
     uint64_t* w0 = mem.alloc(2 * n);
     uint64_t* w1 = mem.alloc(2 * n);
     uint64_t* d_open = mem.alloc(4 * (c + nq));
     VX_CHECK(w0 && w1 && d_open, "stark prove: out of device memory (openings)");
-    hipLaunchKernelGGL(k_bary_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, L, gl2{zeta.a, zeta.b},
+    hipLaunchKernelGGL(k_bary_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, L, g, gl2{zeta.a, zeta.b},
                        gl2{zeta_next.a, zeta_next.b}, (const uint64_t*)ctx->tw_fwd.d, w0, w1);
-    hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)c), dim3(256), 0, ctx->stream, (const uint64_t*)trace->d, n, (const uint64_t*)w0,
+    hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)c), dim3(256), 0, ctx->stream, (const uint64_t*)trace_lde, N, r, n, (const uint64_t*)w0,
                        (const uint64_t*)w1, d_open);
-    hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)nq), dim3(256), 0, ctx->stream, (const uint64_t*)qv, n, (const uint64_t*)w0,
+    hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)nq), dim3(256), 0, ctx->stream, (const uint64_t*)quot_lde, N, r, n, (const uint64_t*)w0,
                        (const uint64_t*)w1, d_open + 4 * c);
     VX_HIP(hipGetLastError());
     std::vector<uint64_t> h_open(4 * (c + nq));
     VX_HIP(hipMemcpyAsync(h_open.data(), d_open, h_open.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     VX_HIP(hipStreamSynchronize(ctx->stream));
-    const uint64_t ninv = glh::inv(n % glh::P);
-    const Ext f0 = e_scale(e_sub(e_pow(zeta, n), Ext{1, 0}), ninv);       // (zeta^n - 1)/n
-    const Ext f1 = e_scale(e_sub(e_pow(zeta_next, n), Ext{1, 0}), ninv);  // ((w zeta)^n - 1)/n
+    const uint64_t gn_ = glh::pow(g, n), fsc = glh::inv(glh::mul(n % glh::P, gn_));
+    const Ext f0 = e_scale(e_sub(e_pow(zeta, n), Ext{gn_, 0}), fsc);       // (zeta^n - g^n) / (n g^n)
+    const Ext f1 = e_scale(e_sub(e_pow(zeta_next, n), Ext{gn_, 0}), fsc);  // ((w zeta)^n - g^n) / (n g^n)
     std::vector<Ext> o_local(c), o_next(c), o_quot(nq);
     for (size_t j = 0; j < c; ++j) {
         o_local[j] = e_mul(f0, Ext{h_open[4 * j], h_open[4 * j + 1]});
@@ -635,4 +648,3 @@ int32_t vx_stark_prove(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_in, c
     memcpy(proof_out, proof.data(), proof.size() * 8);
     return VX_OK;
 }
-}  // extern "C"

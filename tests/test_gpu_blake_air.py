@@ -139,7 +139,7 @@ def test_product_verifier_on_gpu_proofs(ctx, vx):
         vx.lib.stark_verify(ctx.stark_prove(air.ID, ctx.from_host(trace), log_n, pub), expect_air=air.ID, expect_public=pub)
 
 
-@pytest.mark.parametrize("n_headers,profile", [(256, "P15k"), (512, "P15k")])
+@pytest.mark.parametrize("n_headers,profile", [(256, "P15k"), (512, "P15k"), (256, "Pmax")])
 def test_full_size_header_range(ctx, vx, n_headers, profile):
     """BASELINE.json configs[1] and [2] at full size: too big for the python prover, so the checks are
     size-independent properties -- outputs equal the hashlib mirror, the product's host verifier accepts
