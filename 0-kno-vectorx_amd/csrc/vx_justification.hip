@@ -69,7 +69,7 @@ __device__ U256 fe_add(const U256& a, const U256& b) {
 __device__ U256 fe_sub(const U256& a, const U256& b) {
     U256 bb = b;
     fe_canon(bb);
-    U256 r, np;  // a + (p - b), p - b in (0, p]
+    U256 np;  // a + (p - b), p - b in (0, p]
     u256_sub(np.w, FE_P, bb.w);
     return fe_add(a, np);
 }

@@ -1,0 +1,252 @@
+// RotateCircuit (circuits/rotate.rs:80-109; builder/rotate.rs:74-323): the epoch-end header is hashed
+// (Blake2b STARK over its compressions), justified by > 2/3 of the CURRENT authority set (Ed25519 batch on
+// the GPU + authority-set commitment STARK), checked to carry the ScheduledChange log that encodes the NEW
+// authority set (k_epoch_end_check, one lane per validator), and the new set's commitment is proved
+// (second SHA-256 chain STARK) and returned as the 32 output bytes.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "vx_internal.h"
+
+namespace {
+
+constexpr uint32_t MAX_HEADER_SIZE = 35840;  // consts.rs:16
+constexpr uint32_t VALIDATOR_LENGTH = 40, PUBKEY_LENGTH = 32, DELAY_LENGTH = 4, MAX_PREFIX_LENGTH = 17;
+
+// failure codes written by k_epoch_end_check (smallest wins); low 16 bits carry the validator index
+enum : uint32_t { EE_OK = 0xffffffffu, EE_RANGE = 1, EE_FLAG, EE_ENGINE, EE_COMPACT, EE_SCHED, EE_COUNT, EE_PUBKEY, EE_WEIGHT, EE_DELAY };
+
+__device__ bool ee_compact(const uint8_t* b, uint32_t* val, uint32_t* len) {  // decoder.rs:39-103
+    const uint32_t m = b[0] & 3;
+    bool ok = true;
+    switch (m) {
+        case 0: *val = b[0] >> 2; *len = 1; break;
+        case 1: *val = ((uint32_t)b[0] | ((uint32_t)b[1] << 8)) >> 2; *len = 2; break;
+        case 2: *val = ((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24)) >> 2; *len = 4; break;
+        default:
+            *val = (uint32_t)b[1] | ((uint32_t)b[2] << 8) | ((uint32_t)b[3] << 16) | ((uint32_t)b[4] << 24);
+            *len = 5;
+            ok = (b[0] >> 2) == 0;
+    }
+    return ok;
+}
+
+// lane t < max_authorities: validator t (pubkey, weight; delay when t is the last one).  Every lane parses
+// the 17-byte prefix itself (rotate.rs:74-174) -- cheaper than a second launch.
+__global__ __launch_bounds__(64) void k_epoch_end_check(const uint8_t* __restrict__ header, uint32_t num_authorities, uint32_t start_position,
+                                                        const uint8_t* __restrict__ new_pubkeys, uint32_t max_authorities,
+                                                        uint32_t* __restrict__ result) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= max_authorities) return;
+    auto fail = [&](uint32_t code, uint32_t idx) { atomicMin(result, (code << 16) | (idx & 0xffff)); };
+    if ((uint64_t)start_position + MAX_PREFIX_LENGTH > MAX_HEADER_SIZE) return fail(EE_RANGE, 0);
+    const uint8_t* p = header + start_position;
+    if (p[1] != 4) return fail(EE_FLAG, 0);                                                // :84-86
+    if (p[2] != 70 || p[3] != 82 || p[4] != 78 || p[5] != 75) return fail(EE_ENGINE, 0);  // :90-95 "FRNK"
+    uint32_t val, len;
+    if (!ee_compact(p + 6, &val, &len)) return fail(EE_COMPACT, 0);                        // :113-121, value unused
+    uint32_t cursor = 6 + len;
+    if (p[cursor] != 1) return fail(EE_SCHED, 0);                                          // :133-137
+    ++cursor;                                                                              // <= 12, so cursor + 5 <= 17 always
+    if (!ee_compact(p + cursor, &val, &len)) return fail(EE_COMPACT, 1);
+    if (val != num_authorities) return fail(EE_COUNT, 0);                                  // :161-165
+    const uint64_t base = (uint64_t)start_position + cursor + len;                         // :224
+    if (base + (uint64_t)max_authorities * VALIDATOR_LENGTH + DELAY_LENGTH > MAX_HEADER_SIZE) return fail(EE_RANGE, 1);  // :236-240
+    if (t >= num_authorities) return;  // validator_disabled
+    const uint8_t* v = header + base + (uint64_t)t * VALIDATOR_LENGTH;
+    const uint8_t* pk = new_pubkeys + (size_t)t * PUBKEY_LENGTH;
+    bool same = true;
+    for (int j = 0; j < 32; ++j) same &= v[j] == pk[j];
+    if (!same) return fail(EE_PUBKEY, t);                                                  // :251-255
+    bool w = v[32] == 1;
+    for (int j = 33; j < 40; ++j) w &= v[j] == 0;
+    if (!w) return fail(EE_WEIGHT, t);                                                     // :259-265
+    if (t + 1 == num_authorities && (v[40] | v[41] | v[42] | v[43]) != 0) return fail(EE_DELAY, t);  // :267-274
+}
+
+const uint64_t VX_ROT_MAGIC = 0x3154415458525856ULL;  // "VXRXTAT1"
+constexpr size_t VX_ROT_HDR = 24;  // magic, set id, block, n_new, header hash (4), set hash (4), new set hash (4), 3 proof lengths, 0, parent hash (4)
+
+int sha_rows_log(size_t n_keys) {
+    int log_n = 6;
+    while (((size_t)1 << log_n) < 64 * (2 * n_keys - 1)) ++log_n;
+    return log_n;
+}
+int blake_rows_log(size_t chunks) {
+    int log_n = 4;
+    while (((size_t)1 << log_n) < 16 * chunks) ++log_n;
+    return log_n;
+}
+
+void be_limbs(const uint8_t h[32], uint64_t out[8]) {
+    for (int j = 0; j < 8; ++j)
+        out[j] = ((uint64_t)h[4 * j] << 24) | ((uint64_t)h[4 * j + 1] << 16) | ((uint64_t)h[4 * j + 2] << 8) | h[4 * j + 3];
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t vx_verify_epoch_end_header(vx_ctx* ctx, const vx_buf* header, uint32_t num_authorities, uint32_t start_position,
+                                   const uint8_t* new_pubkeys, uint32_t max_authorities) {
+    if (!ctx || !header || !new_pubkeys) return VX_ERR_ARG;
+    VX_CHECK(header->n * 8 >= MAX_HEADER_SIZE, "rotate: header buffer holds %zu bytes, need MAX_HEADER_SIZE = %u", header->n * 8, MAX_HEADER_SIZE);
+    VX_CHECK(max_authorities >= 1 && max_authorities <= 4096, "rotate: max_authorities %u out of range", max_authorities);
+    if (num_authorities == 0) return vx_fail(ctx, VX_ERR_STATEMENT, "rotate: no authorities");                       // rotate.rs:190-192
+    if (num_authorities > max_authorities)                                                                            // circuits/rotate.rs:43-45
+        return vx_fail(ctx, VX_ERR_STATEMENT, "rotate: %u authorities exceed the maximum authority set size %u", num_authorities, max_authorities);
+    const size_t key_words = ((size_t)num_authorities * 32 + 7) / 8;
+    uint64_t* sc;
+    VX_TRY(vx_scratch(ctx, key_words + 1, &sc));
+    uint32_t init = EE_OK;
+    VX_HIP(hipMemcpyAsync(sc, new_pubkeys, (size_t)num_authorities * 32, hipMemcpyHostToDevice, ctx->stream));
+    VX_HIP(hipMemcpyAsync(sc + key_words, &init, 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_epoch_end_check, dim3((max_authorities + 63) / 64), dim3(64), 0, ctx->stream, (const uint8_t*)header->d,
+                       num_authorities, start_position, (const uint8_t*)sc, max_authorities, (uint32_t*)(sc + key_words));
+    VX_HIP(hipGetLastError());
+    uint32_t res = 0;
+    VX_HIP(hipMemcpyAsync(&res, sc + key_words, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipStreamSynchronize(ctx->stream));
+    if (res == EE_OK) return VX_OK;
+    static const char* WHY[] = {"", "subarray out of the header buffer", "consensus flag", "engine id", "compact int", "scheduled change flag",
+                                "authority count", "pubkey", "weight", "delay"};
+    const uint32_t code = res >> 16, idx = res & 0xffff;
+    return vx_fail(ctx, VX_ERR_STATEMENT, "rotate: epoch end header rejected: %s (%u)", code < 10 ? WHY[code] : "?", idx);
+}
+
+int32_t vx_rotate_proof_bound(const vx_stark_config* cfg, size_t n_chunks, size_t n_cur_authorities, size_t n_new_authorities, size_t* n_words) {
+    if (!cfg || !n_words || n_chunks == 0 || n_cur_authorities == 0 || n_new_authorities == 0) return VX_ERR_ARG;
+    size_t w1 = 0, w2 = 0, w3 = 0;
+    int32_t rc = vx_stark_proof_bound(VX_AIR_BLAKE_CHAIN, cfg, blake_rows_log(n_chunks), &w1);
+    if (rc == VX_OK) rc = vx_stark_proof_bound(VX_AIR_SHA_CHAIN, cfg, sha_rows_log(n_cur_authorities), &w2);
+    if (rc == VX_OK) rc = vx_stark_proof_bound(VX_AIR_SHA_CHAIN, cfg, sha_rows_log(n_new_authorities), &w3);
+    *n_words = VX_ROT_HDR + w1 + w2 + w3;
+    return rc;
+}
+
+int32_t vx_rotate_prove(vx_ctx* ctx, const vx_buf* header, uint32_t header_size, uint32_t epoch_end_block_number, uint32_t num_authorities,
+                        uint32_t start_position, const uint8_t* new_pubkeys, const vx_justification* just, const vx_stark_config* cfg,
+                        uint8_t out32[32], uint64_t* proof_out, size_t proof_cap, size_t* proof_len) {
+    if (!ctx || !header || !new_pubkeys || !just || !cfg || !out32 || !proof_len) return VX_ERR_ARG;
+    VX_CHECK(header->n * 8 >= MAX_HEADER_SIZE, "rotate: header buffer holds %zu bytes, need MAX_HEADER_SIZE = %u", header->n * 8, MAX_HEADER_SIZE);
+    if (header_size > MAX_HEADER_SIZE)  // input/mod.rs:851-856
+        return vx_fail(ctx, VX_ERR_STATEMENT, "rotate: header size %u is greater than MAX_HEADER_SIZE %u", header_size, MAX_HEADER_SIZE);
+    VX_CHECK(header_size >= 36, "rotate: header of %u bytes cannot hold a parent hash and a block number", header_size);
+    // 1. header hash = Blake2b-256 of the first header_size bytes (rotate.rs:293); the trace of its compressions
+    //    is the witness of the hash STARK (one-header chain anchored at the header's own parent hash)
+    uint8_t head[40], header_hash[32];
+    const uint8_t* parent = head;
+    VX_HIP(hipMemcpyAsync(head, header->d, 40, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipStreamSynchronize(ctx->stream));
+    {
+        // The hash AIR pins the header's own SCALE number (4-byte compact at bytes 32..36) to its public input.  The
+        // reference binds number and hash only through the signed precommit; for any header GRANDPA finalised the
+        // two coincide, so a header numbered differently from epoch_end_block_number is refused here.
+        const uint32_t enc = (epoch_end_block_number << 2) | 2;
+        uint32_t got;
+        memcpy(&got, head + 32, 4);
+        if (got != enc)
+            return vx_fail(ctx, VX_ERR_STATEMENT, "rotate: header does not carry block number %u as a 4-byte SCALE compact", epoch_end_block_number);
+    }
+    const size_t chunks = (header_size + 127) / 128;
+    const int bl = blake_rows_log(chunks);
+    vx_buf* trace = nullptr;
+    VX_TRY(vx_alloc(ctx, ((size_t)VX_BLAKE_AIR_COLS) << bl, &trace));
+    uint64_t pub[18];
+    int32_t rc = vx_blake_chain_trace(ctx, header, MAX_HEADER_SIZE, &header_size, 1, parent, epoch_end_block_number, bl, trace, pub, header_hash);
+    // 2. justification by the current set over (epoch_end_block_number, header hash) (rotate.rs:297-302)
+    if (rc == VX_OK)
+        rc = vx_verify_simple_justification(ctx, epoch_end_block_number, header_hash, just->authority_set_id, just->authority_set_hash,
+                                            just->precommit, just->pubkeys, just->signatures, just->validator_signed, just->num_authorities,
+                                            just->max_authorities);
+    // 3. the header encodes the new authority set (rotate.rs:306-312)
+    if (rc == VX_OK) rc = vx_verify_epoch_end_header(ctx, header, num_authorities, start_position, new_pubkeys, just->max_authorities);
+    size_t len[3] = {0, 0, 0};
+    int32_t rc_room = VX_OK;
+    auto room = [&](size_t off) { return rc_room == VX_OK && proof_out && proof_cap > off; };
+    if (rc == VX_OK) {
+        rc = vx_stark_prove_impl(ctx, VX_AIR_BLAKE_CHAIN, cfg, trace->d, trace->n, 1, bl, pub, 18, room(VX_ROT_HDR) ? proof_out + VX_ROT_HDR : nullptr,
+                                 room(VX_ROT_HDR) ? proof_cap - VX_ROT_HDR : 0, &len[0]);
+        if (rc == VX_ERR_BUFSZ) rc_room = rc, rc = VX_OK;
+    }
+    (void)vx_free(ctx, trace);
+    // 4. commitments of the current set (binds the EVM input hash) and of the new set (the output, rotate.rs:317-320)
+    uint8_t commit[2][32];
+    for (int k = 0; k < 2 && rc == VX_OK; ++k) {
+        const uint8_t* keys = k == 0 ? just->pubkeys : new_pubkeys;
+        const size_t nk = k == 0 ? just->num_authorities : num_authorities;
+        const int sl = sha_rows_log(nk);
+        vx_buf* st = nullptr;
+        rc = vx_alloc(ctx, ((size_t)VX_SHA_AIR_COLS) << sl, &st);
+        if (rc != VX_OK) break;
+        uint64_t spub[8];
+        rc = vx_sha_chain_trace(ctx, keys, nk, sl, st, spub, commit[k]);
+        if (rc == VX_OK && k == 0 && memcmp(commit[0], just->authority_set_hash, 32) != 0)
+            rc = vx_fail(ctx, VX_ERR_STATEMENT, "rotate: authority-set commitment mismatch");
+        if (rc == VX_OK) {
+            const size_t off = VX_ROT_HDR + len[0] + (k ? len[1] : 0);
+            rc = vx_stark_prove_impl(ctx, VX_AIR_SHA_CHAIN, cfg, st->d, st->n, 1, sl, spub, 8, room(off) ? proof_out + off : nullptr,
+                                     room(off) ? proof_cap - off : 0, &len[1 + k]);
+            if (rc == VX_ERR_BUFSZ) rc_room = rc, rc = VX_OK;
+        }
+        (void)vx_free(ctx, st);
+    }
+    if (rc != VX_OK) return rc;
+    *proof_len = VX_ROT_HDR + len[0] + len[1] + len[2];
+    memcpy(out32, commit[1], 32);
+    if (rc_room != VX_OK || !proof_out || proof_cap < *proof_len)
+        return vx_fail(ctx, VX_ERR_BUFSZ, "rotate: proof needs %zu words, buffer has %zu", *proof_len, proof_cap);
+    proof_out[0] = VX_ROT_MAGIC;
+    proof_out[1] = just->authority_set_id;
+    proof_out[2] = epoch_end_block_number;
+    proof_out[3] = num_authorities;
+    memcpy(proof_out + 4, header_hash, 32);
+    memcpy(proof_out + 8, just->authority_set_hash, 32);
+    memcpy(proof_out + 12, commit[1], 32);
+    proof_out[16] = len[0];
+    proof_out[17] = len[1];
+    proof_out[18] = len[2];
+    proof_out[19] = 0;
+    memcpy(proof_out + 20, parent, 32);
+    return VX_OK;
+}
+
+// RotateCircuit verify: the blob must be for this (authority_set_id, authority_set_hash) request and claim out32;
+// then the three STARKs are verified against the public inputs those values imply.
+int32_t vx_rotate_verify(const vx_stark_config* cfg, const uint64_t* blob, size_t len, uint64_t authority_set_id,
+                         const uint8_t authority_set_hash[32], const uint8_t out32[32], char* err, size_t errlen) {
+    if (!cfg || !blob || !authority_set_hash || !out32) return VX_ERR_ARG;
+    auto bad = [&](const char* why) {
+        if (err && errlen) snprintf(err, errlen, "%s", why);
+        return (int32_t)VX_ERR_STATEMENT;
+    };
+    if (len <= VX_ROT_HDR || blob[0] != VX_ROT_MAGIC) return bad("bad rotate blob");
+    if (blob[1] != authority_set_id || memcmp(blob + 8, authority_set_hash, 32) != 0) return bad("blob is for a different request");
+    if (memcmp(blob + 12, out32, 32) != 0) return bad("public output differs from the blob");
+    const size_t l0 = blob[16], l1 = blob[17], l2 = blob[18];
+    if (l0 > len || l1 > len || l2 > len || VX_ROT_HDR + l0 + l1 + l2 != len) return bad("blob lengths are inconsistent");
+    if (blob[2] >> 32) return bad("block number out of range");
+    // Blake proof: a chain of exactly one header, numbered epoch_end_block, hashing to the blob's header hash.  The
+    // anchor (first 8 public inputs) is the parent hash the header itself carries -- free in this statement.
+    const uint64_t* p0 = blob + VX_ROT_HDR;
+    uint64_t pub[18];
+    for (int j = 0; j < 8; ++j) {
+        uint32_t a, b;
+        memcpy(&a, (const uint8_t*)(blob + 20) + 4 * j, 4);
+        memcpy(&b, (const uint8_t*)(blob + 4) + 4 * j, 4);
+        pub[j] = a;
+        pub[8 + j] = b;
+    }
+    pub[16] = pub[17] = blob[2];
+    int32_t rc = vx_stark_verify(cfg, p0, l0, VX_AIR_BLAKE_CHAIN, pub, 18, err, errlen);
+    if (rc != VX_OK) return rc;
+    uint64_t spub[8];
+    be_limbs(authority_set_hash, spub);
+    rc = vx_stark_verify(cfg, p0 + l0, l1, VX_AIR_SHA_CHAIN, spub, 8, err, errlen);
+    if (rc != VX_OK) return rc;
+    be_limbs(out32, spub);
+    return vx_stark_verify(cfg, p0 + l0 + l1, l2, VX_AIR_SHA_CHAIN, spub, 8, err, errlen);
+}
+
+}  // extern "C"

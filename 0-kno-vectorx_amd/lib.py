@@ -25,6 +25,7 @@ SYMBOLS = [
     "vx_stark_default_config", "vx_stark_proof_bound", "vx_stark_prove", "vx_stark_verify", "vx_header_range_proof_bound", "vx_header_range_prove", "vx_header_range_verify",
     "vx_blake2b_256_batch", "vx_sha256_pairs", "vx_verify_subchain", "vx_blake_chain_trace",
     "vx_ed25519_verify_batch", "vx_verify_simple_justification", "vx_sha_chain_trace",
+    "vx_verify_epoch_end_header", "vx_rotate_proof_bound", "vx_rotate_prove", "vx_rotate_verify",
 ]
 
 VX_AIR_FIBONACCI, VX_AIR_MIX, VX_AIR_BLAKE_CHAIN = 1, 2, 3
@@ -115,6 +116,10 @@ def load_library():
         "vx_ed25519_verify_batch": [vp, vp, vp, vp, C.c_uint32, vp, sz, vp],
         "vx_sha_chain_trace": [vp, vp, sz, C.c_int, vp, vp, vp],
         "vx_verify_simple_justification": [vp, C.c_uint32, vp, u64, vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32],
+        "vx_verify_epoch_end_header": [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32],
+        "vx_rotate_proof_bound": [C.POINTER(StarkConfig), sz, sz, sz, C.POINTER(sz)],
+        "vx_rotate_prove": [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.POINTER(JustificationStruct), C.POINTER(StarkConfig), vp, vp, sz, C.POINTER(sz)],
+        "vx_rotate_verify": [C.POINTER(StarkConfig), vp, sz, u64, vp, vp, C.c_char_p, sz],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -172,6 +177,24 @@ def header_range_verify(blob, max_headers, trusted_block, trusted_hash, target_b
                                   _ptr(o), err, 256)
     if rc != 0:
         raise VxError(rc, err.value.decode())
+
+
+def rotate_verify(blob, authority_set_id, authority_set_hash, out32, cfg=None):
+    L = load_library()
+    cfg = cfg or default_stark_config()
+    b = np.ascontiguousarray(blob, dtype=np.uint64)
+    ah = np.frombuffer(bytes(authority_set_hash), dtype=np.uint8).copy()
+    o = np.frombuffer(bytes(out32), dtype=np.uint8).copy()
+    err = C.create_string_buffer(256)
+    rc = L.vx_rotate_verify(C.byref(cfg), _ptr(b), b.size, authority_set_id, _ptr(ah), _ptr(o), err, 256)
+    if rc != 0:
+        raise VxError(rc, err.value.decode())
+
+
+def split_rotate_blob(blob):
+    """-> (header-hash proof, current-set commitment proof, new-set commitment proof) of a vx_rotate_prove blob."""
+    l0, l1, l2 = int(blob[16]), int(blob[17]), int(blob[18])
+    return blob[24:24 + l0], blob[24 + l0:24 + l0 + l1], blob[24 + l0 + l1:24 + l0 + l1 + l2]
 
 
 class Buffer:
@@ -369,6 +392,23 @@ class Context:
                                               target_block, C.byref(just.struct) if just is not None else None, C.byref(cfg), _ptr(out96),
                                               _ptr(out), out.size, C.byref(need)))
         return out96.tobytes(), out[: need.value]
+
+    def verify_epoch_end_header(self, header_buf, num_authorities, start_position, new_pubkeys, max_authorities=300):
+        pk = np.ascontiguousarray(np.frombuffer(b"".join(new_pubkeys), dtype=np.uint8)) if new_pubkeys else np.zeros(32, dtype=np.uint8)
+        self._ck(self.L.vx_verify_epoch_end_header(self.h, header_buf.h, num_authorities, start_position, _ptr(pk), max_authorities))
+
+    def rotate_prove(self, header_buf, header_size, epoch_end_block_number, num_authorities, start_position, new_pubkeys, just, cfg=None, out=None):
+        """RotateCircuit::prove -> (32-byte new authority set hash, proof blob words)."""
+        cfg = cfg or self.stark_config()
+        pk = np.ascontiguousarray(np.frombuffer(b"".join(new_pubkeys), dtype=np.uint8))
+        need = C.c_size_t(0)
+        self._ck(self.L.vx_rotate_proof_bound(C.byref(cfg), max(1, (header_size + 127) // 128), max(1, just.struct.num_authorities), max(1, num_authorities), C.byref(need)))
+        if out is None or out.size < need.value:
+            out = np.empty(need.value, dtype=np.uint64)
+        out32 = np.zeros(32, dtype=np.uint8)
+        self._ck(self.L.vx_rotate_prove(self.h, header_buf.h, header_size, epoch_end_block_number, num_authorities, start_position, _ptr(pk),
+                                        C.byref(just.struct), C.byref(cfg), _ptr(out32), _ptr(out), out.size, C.byref(need)))
+        return out32.tobytes(), out[: need.value]
 
     # K8 / statement
     def blake2b_256_batch(self, msgs_buf, stride, sizes):

@@ -25,6 +25,7 @@ import numpy as np
 from . import ed25519
 
 CHAIN_SEED = 0x5645435458  # "VECTX"
+ROTATE_SEED = 0x524F54  # "ROT"
 JUST_SEED = 0x4A555354  # "JUST"
 MAX_HEADER_SIZE = 280 * 128  # consts.rs:9-16
 MAX_AUTHORITY_SET_SIZE = 300  # consts.rs:52
@@ -131,6 +132,50 @@ class Justification:
         for pk in self.pubkeys:
             h = hashlib.sha256(h + pk).digest()
         self.authority_set_hash = h
+
+
+class EpochEndHeader:
+    """Synthetic epoch-end header (input/mod.rs:835-968 describes what the RPC one looks like): parent hash,
+    Compact(number), state root, extrinsics root, digest = Compact(n_logs) ++ [PreRuntime("BABE"), ...,
+    Consensus("FRNK", ScheduledChange{authorities x (pubkey, weight 1), delay 0}), Seal("BABE")], extension filler.
+    `start_position` is computed the way get_header_rotate does (:878-882, :924-927): the offset just after
+    extrinsics_root plus the encoded length of every log before the GRANDPA one -- i.e. ONE BYTE BEFORE the
+    log's variant byte (rotate.rs:80 "Skip 1 byte")."""
+
+    def __init__(self, number, n_new, size=None, seed=ROTATE_SEED, logs_before=1, parent_hash=None):
+        secrets = [rand_bytes(seed + 1009 * i, 32) for i in range(n_new)]
+        self.new_pubkeys = [ed25519.public_key(s) for s in secrets]
+        self.num_authorities = n_new
+        self.number = number
+        value = b"\x01" + compact_u32(n_new) + b"".join(pk + (1).to_bytes(8, "little") for pk in self.new_pubkeys) + bytes(4)
+        grandpa = b"\x04" + b"FRNK" + compact_u32(len(value)) + value          # DigestItem::Consensus = variant 4
+        before = []
+        for k in range(logs_before):
+            body = rand_bytes(seed ^ (0xBABE + k), 33 + 7 * k)
+            before.append(b"\x06" + b"BABE" + compact_u32(len(body)) + body)    # DigestItem::PreRuntime = variant 6
+        seal = b"\x05" + b"BABE" + compact_u32(64) + rand_bytes(seed ^ 0x5EA1, 64)
+        logs = before + [grandpa, seal]
+        parent_hash = parent_hash or rand_bytes(seed ^ 0x9A7E, 32)
+        fixed = parent_hash + compact_u32(number) + rand_bytes(seed ^ 1, 32) + rand_bytes(seed ^ 2, 32)
+        self.start_position = len(fixed) + sum(len(x) for x in before)
+        h = fixed + compact_u32(len(logs)) + b"".join(logs)
+        size = size or (len(h) + 300)
+        assert size >= len(h) + 32 and size <= MAX_HEADER_SIZE
+        h += rand_bytes(seed ^ 3, size - len(h))                                # header extension (ends with the data root)
+        self.size = size
+        self.bytes = h
+        self.padded = np.zeros(MAX_HEADER_SIZE, dtype=np.uint8)
+        self.padded[:size] = np.frombuffer(h, dtype=np.uint8)
+        self.hash = hashlib.blake2b(h, digest_size=32).digest()
+        hh = b""
+        for pk in self.new_pubkeys:
+            hh = hashlib.sha256(hh + pk).digest()
+        self.new_authority_set_hash = hh
+
+
+def pack_rotate_input(set_id, set_hash):
+    """40-byte EVM-packed rotate input (dummy_rotate.rs:11-14; rotate.rs:90-91)."""
+    return set_id.to_bytes(8, "big") + set_hash
 
 
 def pack_input(trusted_block, trusted_hash, set_id, set_hash, target_block):

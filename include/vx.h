@@ -260,6 +260,27 @@ int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob,
                                uint32_t trusted_block, const uint8_t trusted_hash[32], const uint8_t* authority_set_hash /* 32 B or NULL */,
                                uint32_t target_block, const uint8_t out96[96], char* err, size_t errlen);
 
+/* ---- RotateCircuit: circuits/rotate.rs:80-109, circuits/builder/rotate.rs:74-323 ----
+ * EVM input = u64 authority_set_id || bytes32 authority_set_hash (40 B, dummy_rotate.rs:11-14);
+ * output = bytes32 new authority set hash.  The RotateHint witness (rotate.rs:29-63, vars.rs RotateStruct)
+ * is passed flat: the epoch-end header (device buffer of >= MAX_HEADER_SIZE bytes, zero padded past
+ * header_size, as get_header_rotate builds it, input/mod.rs:848-858), its size, the epoch-end block number,
+ * target_header_num_authorities, next_authority_set_start_position and the new pubkeys (host, n x 32). */
+/* verify_epoch_end_header (builder/rotate.rs:176-276) on the GPU, one lane per validator slot. */
+int32_t vx_verify_epoch_end_header(vx_ctx* ctx, const vx_buf* header, uint32_t num_authorities, uint32_t start_position,
+                                   const uint8_t* new_pubkeys, uint32_t max_authorities);
+int32_t vx_rotate_proof_bound(const vx_stark_config* cfg, size_t n_chunks, size_t n_cur_authorities, size_t n_new_authorities,
+                              size_t* n_words);
+/* RotateMethods::rotate (builder/rotate.rs:278-323) + Circuit::prove: header hash STARK, justification by the
+ * current set (`just`, required), epoch-end header checks, both authority-set commitment STARKs.
+ * VX_ERR_STATEMENT where the reference circuit's assertions (or the hint's panics) would fail. */
+int32_t vx_rotate_prove(vx_ctx* ctx, const vx_buf* header, uint32_t header_size, uint32_t epoch_end_block_number,
+                        uint32_t num_authorities, uint32_t start_position, const uint8_t* new_pubkeys,
+                        const vx_justification* just, const vx_stark_config* cfg, uint8_t out32[32], uint64_t* proof_out,
+                        size_t proof_cap, size_t* proof_len);
+int32_t vx_rotate_verify(const vx_stark_config* cfg, const uint64_t* blob, size_t blob_len, uint64_t authority_set_id,
+                         const uint8_t authority_set_hash[32], const uint8_t out32[32], char* err, size_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,131 @@
+"""RotateCircuit on the GPU: vx_verify_epoch_end_header agrees with the oracle's restatement of
+builder/rotate.rs:74-276 on accepts and on every rejection class; vx_rotate_prove returns the oracle's new
+authority-set hash, its three STARKs are accepted by the python reference verifier and by the product's host
+verifier, and a wrong statement never reaches the prover."""
+import numpy as np
+import pytest
+
+from oracle import blake_air as B
+from oracle import rotate_ref as R
+from oracle import sha_air as A
+from oracle import stark_ref as S
+
+pytestmark = pytest.mark.gpu
+S.register_air(B.BlakeChainAir)
+S.register_air(A.ShaChainAir)
+
+
+def gpu_reason(ctx, vx, hb, n, pos, keys):
+    try:
+        ctx.verify_epoch_end_header(ctx.from_host(np.frombuffer(bytes(hb), dtype=np.uint8)), n, pos, keys)
+        return None
+    except vx.VxError as e:
+        assert e.code == -5
+        return str(e)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 300])
+def test_epoch_end_header_accepts(ctx, vx, n):
+    e = vx.synth.EpochEndHeader(120000 + n, n)
+    assert R.verify_epoch_end_header(e.padded.tobytes(), n, e.start_position, e.new_pubkeys) is None
+    assert gpu_reason(ctx, vx, e.padded.tobytes(), n, e.start_position, e.new_pubkeys) is None
+
+
+def test_epoch_end_header_rejections_match_oracle(ctx, vx):
+    n = 9
+    e = vx.synth.EpochEndHeader(131072, n)
+    h, sp = bytearray(e.padded.tobytes()), e.start_position
+    base = sp + 10
+    cases = [(h, n, sp, e.new_pubkeys, None), (h, 0, sp, e.new_pubkeys, "no authorities"), (h, 301, sp, e.new_pubkeys, "exceed"),
+             (h, n + 1, sp, e.new_pubkeys, "authority count"), (h, n, R.MAX_HEADER_SIZE - 16, e.new_pubkeys, "subarray"),
+             (h, n, sp - 1, e.new_pubkeys, None if False else "consensus flag")]
+    for off, word in [(sp + 1, "consensus flag"), (sp + 3, "engine id"), (sp + 8, "scheduled change flag"), (base + 40 * 4 + 5, "pubkey (4)"),
+                      (base + 40 * 8 + 32, "weight (8)"), (base + 40 * 2 + 39, "weight (2)"), (base + 40 * n + 2, "delay"), (base + 40 * n + 4 + 11, None)]:
+        c = bytearray(h)
+        c[off] ^= 1
+        cases.append((c, n, sp, e.new_pubkeys, word))
+    c = bytearray(h)
+    c[sp + 6] = 0x07
+    cases.append((c, n, sp, e.new_pubkeys, "compact int"))
+    keys = list(e.new_pubkeys)
+    keys[0] = bytes(32)
+    cases.append((h, n, sp, keys, "pubkey (0)"))
+    for hb, na, pos, ks, word in cases:
+        want = R.verify_epoch_end_header(bytes(hb), na, pos, ks)
+        got = gpu_reason(ctx, vx, hb, na, pos, ks)
+        assert (want is None) == (got is None), (want, got)
+        if word:
+            assert word in got, (word, got)
+    # range rule for the 12,004-byte validator subarray
+    big = vx.synth.EpochEndHeader(131072, 9, size=30000, logs_before=0)
+    moved = bytearray(R.MAX_HEADER_SIZE)
+    pos = R.MAX_HEADER_SIZE - 12004 - 9
+    moved[pos:pos + 400] = big.bytes[big.start_position:big.start_position + 400]
+    assert "subarray" in gpu_reason(ctx, vx, moved, 9, pos, big.new_pubkeys)
+    assert gpu_reason(ctx, vx, moved[1:] + b"\0", 9, pos - 1, big.new_pubkeys) is None
+
+
+def test_rotate_prove_small(ctx, vx):
+    cfg = ctx.stark_config(num_queries=12)
+    pcfg = dict(S.DEFAULT_CFG, num_queries=12)
+    e = vx.synth.EpochEndHeader(140000, 5)
+    sj = vx.synth.Justification(140000, e.hash, n_auth=7, n_signed=5, set_id=3)
+    just = vx.lib.PackedJustification(sj, 12)
+    hb = ctx.from_host(e.padded)
+    out32, blob = ctx.rotate_prove(hb, e.size, 140000, 5, e.start_position, e.new_pubkeys, just, cfg)
+    why, want = R.rotate(e.padded.tobytes(), e.size, 140000, 5, e.start_position, e.new_pubkeys, 3, sj.authority_set_hash, sj, max_authorities=12)
+    assert why is None and out32 == want == e.new_authority_set_hash
+    assert blob[4:8].tobytes() == e.hash and blob[8:12].tobytes() == sj.authority_set_hash and blob[12:16].tobytes() == out32
+    p0, p1, p2 = vx.lib.split_rotate_blob(blob)
+    limbs = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "little") for j in range(8)]  # noqa: E731
+    info = S.verify(p0, pcfg, expect_air=B.ID)
+    assert info["public_inputs"] == limbs(e.bytes[:32]) + limbs(e.hash) + [140000, 140000]
+    be = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "big") for j in range(8)]  # noqa: E731
+    assert S.verify(p1, pcfg, expect_air=A.ID)["public_inputs"] == be(sj.authority_set_hash)
+    assert S.verify(p2, pcfg, expect_air=A.ID)["public_inputs"] == be(out32)
+    # product verifier: accepts, and is bound to the request and the claimed output
+    vx.lib.rotate_verify(blob, 3, sj.authority_set_hash, out32, cfg)
+    for args in ((4, sj.authority_set_hash, out32), (3, bytes(32), out32), (3, sj.authority_set_hash, bytes(32))):
+        with pytest.raises(vx.VxError):
+            vx.lib.rotate_verify(blob, *args, cfg)
+    for word in (5, 21, 24 + int(blob[16]) // 2, 24 + int(blob[16]) + 40, len(blob) - 7):
+        bad = blob.copy()
+        bad[word] ^= np.uint64(1)
+        with pytest.raises(vx.VxError):
+            vx.lib.rotate_verify(bad, 3, sj.authority_set_hash, out32, cfg)
+    # statements the circuit would refuse never reach the prover
+    weak = vx.lib.PackedJustification(vx.synth.Justification(140000, e.hash, n_auth=7, n_signed=4, set_id=3), 12)
+    other = vx.lib.PackedJustification(vx.synth.Justification(140000, bytes(32), n_auth=7, set_id=3), 12)
+    keys = list(e.new_pubkeys)
+    keys[2] = keys[1]
+    for args in ((e.size, 140000, 5, e.start_position, e.new_pubkeys, weak), (e.size, 140000, 5, e.start_position, e.new_pubkeys, other),
+                 (e.size, 140000, 4, e.start_position, e.new_pubkeys[:4], just), (e.size, 140000, 5, e.start_position + 1, e.new_pubkeys, just),
+                 (e.size, 140000, 5, e.start_position, keys, just), (e.size - 1, 140000, 5, e.start_position, e.new_pubkeys, just),
+                 (e.size, 140001, 5, e.start_position, e.new_pubkeys, just)):  # header numbered 140000
+        with pytest.raises(vx.VxError) as ei:
+            ctx.rotate_prove(hb, *args, cfg)
+        assert ei.value.code == -5, str(ei.value)
+    with pytest.raises(vx.VxError) as ei:
+        ctx.rotate_prove(hb, R.MAX_HEADER_SIZE + 1, 140000, 5, e.start_position, e.new_pubkeys, just, cfg)
+    assert ei.value.code == -5
+    hb.free()
+
+
+def test_rotate_full_size(ctx, vx):
+    """BASELINE configs[3]-shaped case: MAX_AUTHORITY_SET_SIZE = 300 current and 300 new authorities, 201 signers
+    (201*3 > 300*2), a 15,360-byte epoch-end header; default StarkConfig.  Determinism: two runs, same bytes."""
+    e = vx.synth.EpochEndHeader(397859, 300, size=15360)
+    sj = vx.synth.Justification(397859, e.hash, n_auth=300, n_signed=201, set_id=117)
+    just = vx.lib.PackedJustification(sj, 300)
+    hb = ctx.from_host(e.padded)
+    out32, blob = ctx.rotate_prove(hb, e.size, 397859, 300, e.start_position, e.new_pubkeys, just)
+    assert out32 == e.new_authority_set_hash
+    first = blob.copy()
+    vx.lib.rotate_verify(first, 117, sj.authority_set_hash, out32)
+    _, again = ctx.rotate_prove(hb, e.size, 397859, 300, e.start_position, e.new_pubkeys, just)
+    assert (again == first).all()
+    bad = first.copy()
+    bad[len(bad) // 2] ^= np.uint64(1)
+    with pytest.raises(vx.VxError):
+        vx.lib.rotate_verify(bad, 117, sj.authority_set_hash, out32)
+    hb.free()
