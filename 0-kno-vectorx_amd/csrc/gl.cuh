@@ -43,19 +43,72 @@ __device__ __forceinline__ uint64_t gl_add_nc(uint64_t a, uint64_t b) {
 __device__ __forceinline__ uint64_t gl_neg(uint64_t a) { return a ? GL_P - a : 0; }
 __device__ __forceinline__ uint64_t gl_dbl(uint64_t a) { return gl_add(a, a); }
 
-// (hi, lo) 128-bit -> [0, 2^64), NOT necessarily canonical (may be in [p, 2^64))
+// (hi, lo) 128-bit -> [0, 2^64), NOT necessarily canonical (may be in [p, 2^64)).
+// value = lo + hl*2^64 + hh*2^96 = lo - hh + hl*(2^32-1)  (mod p).
+#ifndef GL_REDUCE_C
+// Hand-scheduled: 8 vector instructions instead of the 12 the compiler needs for the two conditional +-eps
+// corrections (tools/isa_rate.hip: v_mad_u64_u32 issues at nearly the rate of any VOP3 add, so instruction COUNT
+// is what the integer kernels pay for).  A = lo - hh wraps with borrow b; T = A + hl*eps wraps with carry c
+// (the mad's own carry-out); V = T + (c-b)*2^64, and 2^64 = eps, so R = T + d*eps with d = c-b in {-1,0,1},
+// applied as T - d (v_mad_i64_i32 by -1) and d added to the high word.  |d| = 1 cannot wrap again: c=1,b=0
+// means T <= 2^64 - 2^33; c=0,b=1 means T >= 2^64 - 2^32 + 1.  gfx90a+ needs 2 wait states between a VALU
+// write of VCC / an SGPR and a VALU read of it; inside an asm block that is ours to honour (s_nop 1).
+__device__ __forceinline__ uint64_t gl_reduce128_nc(uint64_t hi, uint64_t lo) {
+    const uint32_t hh = (uint32_t)(hi >> 32), hl = (uint32_t)hi;
+    uint32_t al, ah, mb, mc;
+    asm("v_sub_co_u32 %0, vcc, %3, %5\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 %1, vcc, 0, %4, vcc\n\t"
+        "s_nop 1\n\t"
+        "v_subb_co_u32 %2, vcc, %3, %3, vcc"
+        : "=&v"(al), "=&v"(ah), "=&v"(mb)
+        : "v"((uint32_t)lo), "v"((uint32_t)(lo >> 32)), "v"(hh)
+        : "vcc");
+    const uint64_t a = ((uint64_t)ah << 32) | al;
+    uint64_t t, sc;
+    asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e64 %2, 0, -1, %1"
+        : "=&v"(t), "=&s"(sc), "=&v"(mc)
+        : "v"(hl), "v"(a));
+    const uint32_t d = mb - mc;  // c - b
+    uint64_t r;
+    asm("v_mad_i64_i32 %0, vcc, %1, -1, %2" : "=v"(r) : "v"(d), "v"(t) : "vcc");
+    return r + ((uint64_t)d << 32);
+}
+#else
 __device__ __forceinline__ uint64_t gl_reduce128_nc(uint64_t hi, uint64_t lo) {
     const uint32_t hh = (uint32_t)(hi >> 32), hl = (uint32_t)hi;
     uint64_t t0 = lo - hh;
     if (lo < hh) t0 -= GL_EPS;                    // borrow: + p (mod 2^64)
-    const uint64_t t1 = ((uint64_t)hl << 32) - hl;  // hl * (2^32 - 1)
+    const uint64_t t1 = ((uint64_t)hl << 32) - hl;  // hl * (2^32 - 1); LLVM emits it as a v_mad_u64_u32 by -1
     uint64_t t2 = t0 + t1;
     if (t2 < t1) t2 += GL_EPS;                    // carry: - p (mod 2^64)
     return t2;
 }
+#endif
 __device__ __forceinline__ uint64_t gl_reduce128(uint64_t hi, uint64_t lo) { return gl_canon(gl_reduce128_nc(hi, lo)); }
 // 64 x 64 -> 128 from four 32 x 32 + 64 multiply-adds (v_mad_u64_u32); the compiler's own
 // expansion of a * b and __umul64hi(a, b) computes the partial products twice.
+#ifndef GL_MUL_C
+// rows: t0 = a0 b0; t1 = a0 b1 + hi(t0) (cannot overflow); t2 = a1 b0 + t1 with the mad's carry-out k (65 bits);
+// lo = (lo(t0), lo(t2)); hi = a1 b1 + hi(t2) + k 2^32.  Taking k from the instruction saves the extra
+// 64-bit add and two register-pair moves of the C form below.
+__device__ __forceinline__ void gl_mul128(uint64_t a, uint64_t b, uint64_t& hi, uint64_t& lo) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const uint64_t t0 = (uint64_t)a0 * b0;
+    const uint64_t t1 = (uint64_t)a0 * b1 + (t0 >> 32);
+    uint64_t t2, sk;
+    uint32_t k;
+    asm("v_mad_u64_u32 %0, %1, %3, %4, %5\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e64 %2, 0, 1, %1"
+        : "=&v"(t2), "=&s"(sk), "=&v"(k)
+        : "v"(a1), "v"(b0), "v"(t1));
+    hi = (uint64_t)a1 * b1 + (((uint64_t)k << 32) | (t2 >> 32));
+    lo = (t2 << 32) | (uint32_t)t0;
+}
+#else
 __device__ __forceinline__ void gl_mul128(uint64_t a, uint64_t b, uint64_t& hi, uint64_t& lo) {
     const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
     const uint64_t t0 = (uint64_t)a0 * b0;
@@ -64,6 +117,7 @@ __device__ __forceinline__ void gl_mul128(uint64_t a, uint64_t b, uint64_t& hi, 
     hi = (uint64_t)a1 * b1 + (t1 >> 32) + (t2 >> 32);
     lo = (t2 << 32) | (uint32_t)t0;
 }
+#endif
 // inputs: any 64-bit representatives; output in [0, 2^64) (non-canonical)
 __device__ __forceinline__ uint64_t gl_mul_nc(uint64_t a, uint64_t b) {
     uint64_t hi, lo;

@@ -74,7 +74,15 @@ __device__ __forceinline__ void poseidon_mds_half(const uint32_t* x, int64_t* y)
     }
 }
 
-__device__ __forceinline__ void poseidon_mds(uint64_t* s) {
+// MDS layer + the NEXT round's constant add.  Each output is al + ah 2^32 with al, ah < 2^43 (row sums of the
+// 32-bit halves, plus the constant's halves when RC):  ah 2^32 = hi(ah) 2^64 + lo(ah) 2^32, and 2^64 = eps, so
+//   w = hi(ah) * eps + al          one v_mad_u64_u32, < 2^44, cannot wrap
+//   y = w + lo(ah) 2^32            a 32-bit add into the high word; its carry is worth 2^64 = eps
+// The result is left NON-canonical (any value in [0, 2^64)): the s-box multiplier and the next MDS split accept
+// that; poseidon_permute canonicalises once at the end.  (v_mad_u64_u32 issues at the rate of any other VOP3
+// instruction on gfx950, tools/isa_rate.hip, so a mad that replaces an add + compare + select is a clear win.)
+template <bool RC>
+__device__ __forceinline__ void poseidon_mds(uint64_t* s, int rc_next) {
     uint32_t lo[12], hi[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
@@ -88,39 +96,47 @@ __device__ __forceinline__ void poseidon_mds(uint64_t* s) {
     yh[0] += (int64_t)hi[0] * VX_POSEIDON_MDS_DIAG0;
 #pragma unroll
     for (int r = 0; r < 12; ++r) {
-        // al + ah * 2^32 with al, ah < 2^42:  ah*2^32 = (ah>>32)*2^64 + (ah & eps) << 32.  The sum is left
-        // NON-canonical (any value in [0, 2^64)): the round-constant add, the s-box multiplier and the
-        // next MDS split all accept that; poseidon_permute canonicalises once at the end.
-        const uint64_t al = (uint64_t)yl[r], ah = (uint64_t)yh[r];
-        const uint64_t t = gl_add_nc((ah & GL_EPS) << 32, al);  // al < 2^42 is canonical
-        s[r] = gl_add_nc(t, (ah >> 32) * GL_EPS);               // (ah >> 32) * eps < 2^42 is canonical
+        uint64_t al = (uint64_t)yl[r], ah = (uint64_t)yh[r];
+        if (RC) {
+            const uint64_t c = POSEIDON_RC[rc_next + r];
+            al += c & GL_EPS;
+            ah += c >> 32;
+        }
+        const uint64_t w = (uint64_t)(uint32_t)(ah >> 32) * GL_EPS + al;
+        uint32_t yhi;
+        const bool carry = __builtin_add_overflow((uint32_t)(w >> 32), (uint32_t)ah, &yhi);
+        const uint64_t y = ((uint64_t)yhi << 32) | (uint32_t)w;
+        s[r] = y + (carry ? (uint64_t)GL_EPS : 0);  // y wrapped to < 2^44: no second carry
     }
 }
 
 __device__ __forceinline__ void poseidon_permute(uint64_t* s) {
-    int rc = 0;
+    int rc = 12;  // constants of round k+1 are added by the MDS layer of round k
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = gl_add_nc(s[i], POSEIDON_RC[i]);
 #pragma unroll 1
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox(gl_add_nc(s[i], POSEIDON_RC[rc + i]));
+        for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox(s[i]);
+        poseidon_mds<true>(s, rc);
         rc += 12;
-        poseidon_mds(s);
     }
 #pragma unroll 1
     for (int r = 0; r < 22; ++r) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) s[i] = gl_add_nc(s[i], POSEIDON_RC[rc + i]);
-        rc += 12;
         s[0] = poseidon_sbox(s[0]);
-        poseidon_mds(s);
+        poseidon_mds<true>(s, rc);
+        rc += 12;
     }
 #pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < 3; ++r) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox(gl_add_nc(s[i], POSEIDON_RC[rc + i]));
+        for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox(s[i]);
+        poseidon_mds<true>(s, rc);
         rc += 12;
-        poseidon_mds(s);
     }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox(s[i]);
+    poseidon_mds<false>(s, 0);
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = gl_canon(s[i]);
 }

@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvxprove.so")
+LIB_PATH = os.environ.get("VX_LIB_PATH") or os.path.join(_HERE, "libvxprove.so")  # VX_LIB_PATH: A/B builds of the same library (tools/ab_kernels.py)
 P = 2**64 - 2**32 + 1
 
 VX_ORDER_NATURAL, VX_ORDER_BITREV = 0, 1

@@ -139,6 +139,21 @@ def test_product_verifier_on_gpu_proofs(ctx, vx):
         vx.lib.stark_verify(ctx.stark_prove(air.ID, ctx.from_host(trace), log_n, pub), expect_air=air.ID, expect_public=pub)
 
 
+def test_partial_ragged_range(ctx, vx):
+    """target = trusted + N - 37 with header sizes uniform in [512, 35840]: disabled leaves / batches on
+    the statement side (subchain_verification.rs:137-142, 198-199), a ragged chain on the trace side."""
+    n, N = 256 - 37, 256
+    ch = vx.synth.Chain(n, profile="Pmix")
+    hb = ctx.from_host(ch.headers)
+    cfg = ctx.stark_config()
+    out96, blob = ctx.header_range_prove(hb, ch.stride, ch.sizes, N, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
+    assert out96 == ch.expected_outputs(N)
+    vx.lib.header_range_verify(blob, N, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg)
+    with pytest.raises(vx.VxError):  # the same blob is not a proof for the full range
+        vx.lib.header_range_verify(blob, N, ch.trusted_block, ch.trusted_hash, ch.target_block + 37, out96, cfg)
+    hb.free()
+
+
 @pytest.mark.parametrize("n_headers,profile", [(256, "P15k"), (512, "P15k"), (256, "Pmax")])
 def test_full_size_header_range(ctx, vx, n_headers, profile):
     """BASELINE.json configs[1] and [2] at full size: too big for the python prover, so the checks are
