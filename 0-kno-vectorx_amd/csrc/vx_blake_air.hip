@@ -96,9 +96,35 @@ __device__ __forceinline__ void put_bits(uint64_t* tr, size_t n, size_t row, int
     for (int i = 0; i < nbits; ++i) tr[(size_t)(col0 + i) * n + row] = (val >> i) & 1;
 }
 
+// The 4096 bit columns of the G area and the 64 of MB0 are not stored bit by bit from the row lane: a lane would
+// walk 4337 columns 8n bytes apart, one 512-byte store each, and the address translation of that walk -- not the
+// bytes -- set the kernel's time (22 ms for 18 GB).  k_blake_trace writes the 65 WORDS per row instead
+// (words[wc * n + row]) and k_expand_bits turns each word column into its 64 bit columns, a block writing 16 KB
+// runs of 64 columns only.
+constexpr int N_WORD_COLS = 65, EXP_RPL = 8;
+__global__ __launch_bounds__(256) void k_expand_bits(const uint64_t* __restrict__ words, uint64_t* __restrict__ tr, size_t n) {
+    const int wc = blockIdx.y;
+    const size_t col0 = wc < 64 ? (size_t)wc * 64 : (size_t)blk::MB0;
+    const size_t row0 = (size_t)blockIdx.x * (256 * EXP_RPL) + threadIdx.x;
+    uint64_t w[EXP_RPL];
+#pragma unroll
+    for (int rr = 0; rr < EXP_RPL; ++rr) {
+        const size_t row = row0 + 256 * (size_t)rr;
+        w[rr] = row < n ? words[(size_t)wc * n + row] : 0;
+    }
+    for (int i = 0; i < 64; ++i) {
+        uint64_t* c = tr + (col0 + i) * n;
+#pragma unroll
+        for (int rr = 0; rr < EXP_RPL; ++rr) {
+            const size_t row = row0 + 256 * (size_t)rr;
+            if (row < n) c[row] = (w[rr] >> i) & 1;
+        }
+    }
+}
+
 // one lane per trace row
 __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const BlockDesc* descs, const uint64_t* hchain, size_t n_real,
-                                                     uint64_t* tr, size_t n) {
+                                                     uint64_t* tr, uint64_t* __restrict__ words, size_t n) {
     using namespace blk;
     const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (row >= n) return;
@@ -140,23 +166,25 @@ __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const 
     uint64_t h_out[8];
     if (r >= 13)
         for (int k = 0; k < 8; ++k) h_out[k] = h[k] ^ vfin[k] ^ vfin[k + 8];
+    auto put_word = [&](int bit_col0, uint64_t val) { words[(size_t)(bit_col0 >> 6) * n + row] = val; };  // G-area cells are word aligned
     if (have_rec) {
         for (int k = 0; k < 8; ++k) {
-            for (int w = 0; w < 8; ++w) put_bits(tr, n, row, GB(k, w, 0), rec[k].w[w]);
+            for (int w = 0; w < 8; ++w) put_word(GB(k, w, 0), rec[k].w[w]);
             for (int j = 0; j < 8; ++j) tr[(size_t)CAR(k, j) * n + row] = rec[k].car[j];
         }
     } else {
-        for (int col = 0; col < 4160; ++col) tr[(size_t)col * n + row] = 0;
-        if (r == 0) {
-            for (int w = 0; w < 16; ++w) put_bits(tr, n, row, OUT(w), v0[w]);
+        for (int wc = 0; wc < 64; ++wc) words[(size_t)wc * n + row] = 0;
+        for (int col = 4096; col < 4160; ++col) tr[(size_t)col * n + row] = 0;
+        if (r == 0) {  // (a lane's later store to the same address wins)
+            for (int w = 0; w < 16; ++w) put_word(OUT(w), v0[w]);
         } else if (r == 13) {
             for (int w = 0; w < 8; ++w) {
-                put_bits(tr, n, row, FT(w, 0), h[w] ^ vfin[w]);
-                put_bits(tr, n, row, FV(w, 0), vfin[8 + w]);
-                put_bits(tr, n, row, FH(w, 0), h[w]);
+                put_word(FT(w, 0), h[w] ^ vfin[w]);
+                put_word(FV(w, 0), vfin[8 + w]);
+                put_word(FH(w, 0), h[w]);
             }
         } else if (r == 14) {
-            for (int w = 0; w < 8; ++w) put_bits(tr, n, row, FT(w, 0), h_out[w]);
+            for (int w = 0; w < 8; ++w) put_word(FT(w, 0), h_out[w]);
         }
     }
     // ---- message schedule + range check of natural word r
@@ -165,7 +193,7 @@ __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const 
         tr[(size_t)MS(s, 0) * n + row] = w & 0xFFFFFFFFULL;
         tr[(size_t)MS(s, 1) * n + row] = w >> 32;
     }
-    put_bits(tr, n, row, MB0, m[r]);
+    words[(size_t)64 * n + row] = m[r];  // MB0 .. MB0+63
     for (int b = 0; b < 8; ++b) tr[(size_t)(MK0 + b) * n + row] = (uint32_t)(8 * r + b) < d.inc ? 1 : 0;
     tr[(size_t)CNT * n + row] = d.inc < (uint32_t)(8 * (r + 1)) ? d.inc : (uint32_t)(8 * (r + 1));
     // ---- H register
@@ -217,13 +245,15 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
     // device scratch: sizes | block_base | digests | hchain | descs
     const size_t w_sizes = (n_headers * 4 + 7) / 8, w_dig = n_headers * 4, w_hc = n_real * 8;
     const size_t w_desc = (n_blocks * sizeof(BlockDesc) + 7) / 8;
+    const size_t w_words = (size_t)N_WORD_COLS * n;
     uint64_t* sc;
-    VX_TRY(vx_scratch(ctx, 2 * w_sizes + w_dig + w_hc + w_desc, &sc));
+    VX_TRY(vx_scratch(ctx, 2 * w_sizes + w_dig + w_hc + w_desc + w_words, &sc));
     uint32_t* d_sizes = (uint32_t*)sc;
     uint32_t* d_base = (uint32_t*)(sc + w_sizes);
     uint8_t* d_dig = (uint8_t*)(sc + 2 * w_sizes);
     uint64_t* d_hc = sc + 2 * w_sizes + w_dig;
     BlockDesc* d_desc = (BlockDesc*)(d_hc + w_hc);
+    uint64_t* d_words = d_hc + w_hc + w_desc;
     VX_HIP(hipMemcpyAsync(d_sizes, sizes, n_headers * 4, hipMemcpyHostToDevice, ctx->stream));
     VX_HIP(hipMemcpyAsync(d_base, base.data(), n_headers * 4, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_blake_chain, dim3((unsigned)((n_headers + 63) / 64)), dim3(64), 0, ctx->stream, (const uint8_t*)headers->d,
@@ -265,7 +295,10 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
     }
     VX_HIP(hipMemcpyAsync(d_desc, descs.data(), n_blocks * sizeof(BlockDesc), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_blake_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t*)headers->d,
-                       (const BlockDesc*)d_desc, (const uint64_t*)d_hc, n_real, trace_out->d, n);
+                       (const BlockDesc*)d_desc, (const uint64_t*)d_hc, n_real, trace_out->d, d_words, n);
+    VX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_expand_bits, dim3((unsigned)((n + 256 * EXP_RPL - 1) / (256 * EXP_RPL)), N_WORD_COLS), dim3(256), 0, ctx->stream,
+                       (const uint64_t*)d_words, trace_out->d, n);
     VX_HIP(hipGetLastError());
     VX_HIP(hipStreamSynchronize(ctx->stream));  // descs must outlive the kernel
     for (int j = 0; j < 8; ++j) {
