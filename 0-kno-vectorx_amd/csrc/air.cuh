@@ -17,17 +17,49 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "gl.cuh"
 
 #define VX_HD __host__ __device__ __forceinline__
 
-struct Fp {  // device base-field element
-    uint64_t v;
-    __device__ __forceinline__ Fp operator+(Fp o) const { return {gl_add(v, o.v)}; }
-    __device__ __forceinline__ Fp operator-(Fp o) const { return {gl_sub(v, o.v)}; }
-    __device__ __forceinline__ Fp operator*(Fp o) const { return {gl_mul(v, o.v)}; }
-    __device__ __forceinline__ static Fp from(uint64_t x) { return {x}; }
+// Device base-field element, R LDE points per lane (rows i, i + 256, ... of the block's tile).  R > 1 gives every
+// load R independent streams per lane (the kernel is bound by load latency -- each column lives in its own pages --
+// not by bytes) and makes a block touch R x 2 KB of a column per visit.
+template <int R>
+struct FpN {
+    static constexpr int LANES = R;
+    uint64_t v[R];
+    __device__ __forceinline__ FpN operator+(const FpN& o) const {
+        FpN r;
+#pragma unroll
+        for (int j = 0; j < R; ++j) r.v[j] = gl_add(v[j], o.v[j]);
+        return r;
+    }
+    __device__ __forceinline__ FpN operator-(const FpN& o) const {
+        FpN r;
+#pragma unroll
+        for (int j = 0; j < R; ++j) r.v[j] = gl_sub(v[j], o.v[j]);
+        return r;
+    }
+    __device__ __forceinline__ FpN operator*(const FpN& o) const {
+        FpN r;
+#pragma unroll
+        for (int j = 0; j < R; ++j) r.v[j] = gl_mul(v[j], o.v[j]);
+        return r;
+    }
+    __device__ __forceinline__ static FpN from(uint64_t x) {
+        FpN r;
+#pragma unroll
+        for (int j = 0; j < R; ++j) r.v[j] = x;
+        return r;
+    }
 };
+using Fp = FpN<1>;
+template <class F>
+struct is_device_field : std::false_type {};
+template <int R>
+struct is_device_field<FpN<R>> : std::true_type {};
 
 // host-side extension-field element (verifier: constraints evaluated at zeta)
 struct Fx {
@@ -51,8 +83,15 @@ struct HostRow {
     Fx operator[](int col) const { return v[col]; }
 };
 
+// Gates: a run of constraints that share one factor g (a row selector) may be pushed as
+//   auto G = c.open(g); ... c.gated(G, e) ... ; c.close(G);
+// which stands for c.constraint(g * e) at each position (several gates may be open at once, interleaved with plain
+// constraints).  The generic consumer does exactly that; the device consumer factors g out of the run.
 template <class F>
 struct Consumer {
+    struct Gate {
+        F g;
+    };
     F acc[2], alpha[2], z_last, l_first, l_last;
     VX_HD void constraint(F c) {
         acc[0] = acc[0] * alpha[0] + c;
@@ -61,18 +100,104 @@ struct Consumer {
     VX_HD void transition(F c) { constraint(c * z_last); }
     VX_HD void first_row(F c) { constraint(c * l_first); }
     VX_HD void last_row(F c) { constraint(c * l_last); }
+    VX_HD Gate open(F g) { return Gate{g}; }
+    VX_HD void gated(Gate& G, F e) { constraint(G.g * e); }
+    VX_HD void close(Gate&) {}
 };
 
-struct RowView {  // column-major LDE, one row
+// Device consumer: the Horner recurrence acc = acc alpha + c_k over K constraints equals sum_k c_k alpha^(K-1-k),
+// so with the powers tabulated (apow[2k + j] = alpha_j^(K-1-k), uniform loads) each constraint costs two
+// multiply-accumulates into 160-bit integers (gl_mac) and nothing is reduced until the end.  A gate has its own
+// pair of accumulators: sum over the run of alpha^(..) g e_k = g * sum alpha^(..) e_k, one extra product per run.
+// The result is the same field element the generic consumer computes -- proofs stay byte-identical.
+template <int R>
+struct Consumer<FpN<R>> {
+    using F = FpN<R>;
+    struct Gate {
+        gl_acc a0[R], a1[R];
+        F g;
+    };
+    gl_acc acc0[R], acc1[R];
+    const uint64_t* apow;
+    int k;
+    F z_last, l_first, l_last;
+    __device__ __forceinline__ void init(const uint64_t* apow_) {
+        apow = apow_, k = 0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) gl_acc_zero(acc0[j]), gl_acc_zero(acc1[j]);
+    }
+    __device__ __forceinline__ void push(gl_acc* a0, gl_acc* a1, const F& c) {
+        const int ku = __builtin_amdgcn_readfirstlane(k);  // the constraint index is wave-uniform by construction
+        const uint64_t p0 = apow[2 * ku], p1 = apow[2 * ku + 1];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            gl_mac(a0[j], c.v[j], p0);
+            gl_mac(a1[j], c.v[j], p1);
+        }
+        k = ku + 1;
+    }
+    __device__ __forceinline__ void constraint(const F& c) { push(acc0, acc1, c); }
+    __device__ __forceinline__ void transition(const F& c) { constraint(c * z_last); }
+    __device__ __forceinline__ void first_row(const F& c) { constraint(c * l_first); }
+    __device__ __forceinline__ void last_row(const F& c) { constraint(c * l_last); }
+    __device__ __forceinline__ Gate open(const F& g) {
+        Gate G;
+        G.g = g;
+#pragma unroll
+        for (int j = 0; j < R; ++j) gl_acc_zero(G.a0[j]), gl_acc_zero(G.a1[j]);
+        return G;
+    }
+    __device__ __forceinline__ void gated(Gate& G, const F& e) { push(G.a0, G.a1, e); }
+    __device__ __forceinline__ void close(Gate& G) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            gl_mac(acc0[j], G.g.v[j], gl_acc_reduce(G.a0[j]));
+            gl_mac(acc1[j], G.g.v[j], gl_acc_reduce(G.a1[j]));
+        }
+    }
+    __device__ __forceinline__ uint64_t result(int challenge, int j) const { return gl_acc_reduce(challenge ? acc1[j] : acc0[j]); }
+};
+
+// counts the constraints an AIR pushes (host, once per AIR): K of the power table
+struct CountF {
+    VX_HD CountF operator+(CountF) const { return {}; }
+    VX_HD CountF operator-(CountF) const { return {}; }
+    VX_HD CountF operator*(CountF) const { return {}; }
+    static CountF from(uint64_t) { return {}; }
+};
+template <>
+struct Consumer<CountF> {
+    struct Gate {};
+    int k = 0;
+    void constraint(CountF) { ++k; }
+    void transition(CountF) { ++k; }
+    void first_row(CountF) { ++k; }
+    void last_row(CountF) { ++k; }
+    Gate open(CountF) { return {}; }
+    void gated(Gate&, CountF) { ++k; }
+    void close(Gate&) {}
+};
+struct CountRow {
+    CountF operator[](int) const { return {}; }
+};
+
+template <int R>
+struct RowViewN {  // column-major LDE, rows i[0..R) of it
     const uint64_t* base;
-    size_t stride, i;
-    __device__ __forceinline__ Fp operator[](int col) const { return {base[(size_t)col * stride + i]}; }
+    size_t stride, i[R];
+    __device__ __forceinline__ FpN<R> operator[](int col) const {
+        const uint64_t* c = base + (size_t)col * stride;
+        FpN<R> r;
+#pragma unroll
+        for (int j = 0; j < R; ++j) r.v[j] = c[i[j]];
+        return r;
+    }
 };
 
 // ---- AIR 1: Fibonacci (the canonical starky example; used to pin the generic prover) ----
 // columns (x0, x1); public inputs (x0[0], x1[0], x1[n-1]); next.x0 = x1, next.x1 = x0 + x1.
 struct FibAir {
-    static constexpr int ID = 1, COLS = 2, PUB = 3, PERIODIC = 0, PERIOD_LOG = 0;
+    static constexpr int ID = 1, COLS = 2, PUB = 3, PERIODIC = 0, PERIOD_LOG = 0, QUOT_ROWS_PER_LANE = 1;
     template <class F, class Row, class C>
     VX_HD static void eval(const Row& loc, const Row& nxt, const F*, const F* pub, C& c) {
         c.first_row(loc[0] - pub[0]);
@@ -89,7 +214,7 @@ struct FibAir {
 //   rows with s = 1: next.a = d         (re-seed; s = (0,0,0,1) so the wrap-around pair re-seeds)
 //   next.b = a + b, next.c = c*c + d    (transition: degree 2 * z_last = 3), d boolean
 struct MixAir {
-    static constexpr int ID = 2, COLS = 4, PUB = 2, PERIODIC = 2, PERIOD_LOG = 2;
+    static constexpr int ID = 2, COLS = 4, PUB = 2, PERIODIC = 2, PERIOD_LOG = 2, QUOT_ROWS_PER_LANE = 2;
     template <class F, class Row, class C>
     VX_HD static void eval(const Row& loc, const Row& nxt, const F* per, const F* pub, C& c) {
         F a = loc[0], b = loc[1], cc = loc[2], d = loc[3];

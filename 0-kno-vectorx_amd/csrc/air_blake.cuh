@@ -12,6 +12,8 @@
 // zero-padding mask (8 mask bits + running count per row).
 // Constraint ORDER is protocol: oracle/blake_air.py restates it independently.
 #pragma once
+#include <type_traits>
+
 #include "air.cuh"
 #include "blake_tables.h"
 
@@ -57,7 +59,7 @@ VX_HD int rc_slot(int r) { return RC_SLOT_H[r]; }
 }  // namespace blk
 
 struct BlakeAir {
-    static constexpr int ID = 3, COLS = blk::COLS, PUB = 18, PERIODIC = 16, PERIOD_LOG = 4;
+    static constexpr int ID = 3, COLS = blk::COLS, PUB = 18, PERIODIC = 16, PERIOD_LOG = 4, QUOT_ROWS_PER_LANE = 1;  // 2 rows per lane: 266 VGPRs, 53 ms instead of 41
 
     template <class F, class Row, class C>
     __host__ __device__ static void eval(const Row& loc, const Row& nxt, const F* sel, const F* pub, C& c) {
@@ -67,18 +69,43 @@ struct BlakeAir {
         for (int r = 1; r < 12; ++r) g_on = g_on + sel[r];
         auto at = [&](int which, int col) -> F { return which ? nxt[col] : loc[col]; };
         auto xorf = [&](F x, F y) -> F { return x + y - two * (x * y); };
-        auto limb = [&](int which, int col0, int h) -> F {
-            F acc = at(which, col0 + 32 * h + 31);
-#pragma unroll 1
-            for (int i = 30; i >= 0; --i) acc = acc + acc + at(which, col0 + 32 * h + i);
-            return acc;
+        auto limb = [&](int which, int col0, int h) -> F {  // sum_i 2^i x_i over the 32 cells of one limb
+            if constexpr (is_device_field<F>::value) {
+                // device: the low and high halves of the 32 cells accumulate as plain integers (each sum < 2^64),
+                // one multiply-add by 2^i per half; a single reduction at the end
+                uint64_t lo[F::LANES], hi[F::LANES];
+#pragma unroll
+                for (int j = 0; j < F::LANES; ++j) lo[j] = hi[j] = 0;
+#pragma unroll 8
+                for (int i = 0; i < 32; ++i) {
+                    const F x = at(which, col0 + 32 * h + i);
+#pragma unroll
+                    for (int j = 0; j < F::LANES; ++j) {
+                        lo[j] += (uint64_t)(uint32_t)x.v[j] * (uint32_t)(1u << i);
+                        hi[j] += (x.v[j] >> 32) * (uint32_t)(1u << i);
+                    }
+                }
+                // lo + hi 2^32 = (lo + (hi << 32) mod 2^64) + ((hi >> 32) + carry) 2^64
+                F r;
+#pragma unroll
+                for (int j = 0; j < F::LANES; ++j) {
+                    uint64_t low;
+                    const bool cy = __builtin_add_overflow(lo[j], hi[j] << 32, &low);
+                    r.v[j] = gl_reduce128((hi[j] >> 32) + (cy ? 1 : 0), low);
+                }
+                return r;
+            } else {
+                F acc = at(which, col0 + 32 * h + 31);
+                for (int i = 30; i >= 0; --i) acc = acc + acc + at(which, col0 + 32 * h + i);
+                return acc;
+            }
         };
         auto boolean = [&](int col) {
             F x = loc[col];
             c.constraint(x * (x - one));
         };
         // ---- 1. booleans
-#pragma unroll 1
+#pragma unroll 4
         for (int col = 0; col < 4096; ++col) boolean(col);
 #pragma unroll 1
         for (int col = MB0; col < MB0 + 64; ++col) boolean(col);
@@ -100,7 +127,8 @@ struct BlakeAir {
                 if ((j & 2) == 0) c.constraint(x * (x - one) * (x - two));
                 else c.constraint(x * (x - one));
             }
-        // ---- 3. the eight G functions of the round held in the next row
+        // ---- 3. the eight G functions of the round held in the next row (every constraint gated by g_on)
+        auto GON = c.open(g_on);
 #pragma unroll 1
         for (int k = 0; k < 8; ++k) {
             int wa, ca, wb, cb, wc, cc, wd, cd, xs, ys;  // (row selector, first bit column) of the inputs
@@ -122,15 +150,15 @@ struct BlakeAir {
                     if (msg_slot >= 0) lhs = lhs + nxt[MS(msg_slot, h)];
                     if (h) lhs = lhs + cin;
                     F car = nxt[CAR(k, car_j + h)];
-                    c.constraint(g_on * (lhs - limb(1, GB(k, res_slot, 0), h) - two32 * car));
+                    c.gated(GON, lhs - limb(1, GB(k, res_slot, 0), h) - two32 * car);
                     cin = car;
                 }
             };
             auto xorrot = [&](int w1, int c1, int w2, int c2, int res_slot, int rot) {
-#pragma unroll 1
+#pragma unroll 4
                 for (int i = 0; i < 64; ++i) {
                     const int s = (i + rot) & 63;
-                    c.constraint(g_on * (nxt[GB(k, res_slot, i)] - xorf(at(w1, c1 + s), at(w2, c2 + s))));
+                    c.gated(GON, nxt[GB(k, res_slot, i)] - xorf(at(w1, c1 + s), at(w2, c2 + s)));
                 }
             };
             add3(wa, ca, wb, cb, xs, W_A1, 0);
@@ -142,14 +170,16 @@ struct BlakeAir {
             add3(1, GB(k, W_C1, 0), 1, GB(k, W_D2, 0), -1, W_C2, 6);
             xorrot(1, GB(k, W_B1, 0), 1, GB(k, W_C2, 0), W_B2, 63);
         }
-        // ---- 4. INIT row
+        c.close(GON);
+        // ---- 4. INIT row (gated by sel[0])
         const F fin = loc[FIN];
+        auto S0 = c.open(sel[0]);
 #pragma unroll 1
         for (int wd = 0; wd < 16; ++wd) {
             const int col0 = OUT(wd);
             if (wd < 8) {  // v[0..8) = h_in: compared limb-wise with the H register
 #pragma unroll 1
-                for (int h = 0; h < 2; ++h) c.constraint(sel[0] * (limb(0, col0, h) - loc[HL(wd, h)]));
+                for (int h = 0; h < 2; ++h) c.gated(S0, limb(0, col0, h) - loc[HL(wd, h)]);
                 continue;
             }
 #pragma unroll 1
@@ -159,32 +189,37 @@ struct BlakeAir {
                 if (wd == 12 && i < 32) want = bit ? one - loc[TB0 + i] : loc[TB0 + i];
                 else if (wd == 14) want = bit ? one - fin : fin;
                 else want = F::from((uint64_t)bit);
-                c.constraint(sel[0] * (cell - want));
+                c.gated(S0, cell - want);
             }
         }
+        c.close(S0);
         // ---- 5. finalisation
         F keep_h = sel[15];
         for (int r = 0; r < 13; ++r) keep_h = keep_h + sel[r];
+        auto S12 = c.open(sel[12]);
+        auto S13 = c.open(sel[13]);
 #pragma unroll 1
         for (int wd = 0; wd < 8; ++wd) {
             const int lo0 = OUT(wd), hi0 = OUT(8 + wd);
             const uint64_t ivp = wd == 0 ? (iv(0) ^ 0x01010020ULL) : iv(wd);
 #pragma unroll 1
             for (int i = 0; i < 64; ++i) {
-                c.constraint(sel[12] * (nxt[FT(wd, i)] - xorf(nxt[FH(wd, i)], loc[lo0 + i])));
-                c.constraint(sel[12] * (nxt[FV(wd, i)] - loc[hi0 + i]));
-                c.constraint(sel[13] * (nxt[FT(wd, i)] - xorf(loc[FT(wd, i)], loc[FV(wd, i)])));
+                c.gated(S12, nxt[FT(wd, i)] - xorf(nxt[FH(wd, i)], loc[lo0 + i]));
+                c.gated(S12, nxt[FV(wd, i)] - loc[hi0 + i]);
+                c.gated(S13, nxt[FT(wd, i)] - xorf(loc[FT(wd, i)], loc[FV(wd, i)]));
             }
 #pragma unroll 1
             for (int h = 0; h < 2; ++h) {
                 const F hl = loc[HL(wd, h)], hn = nxt[HL(wd, h)];
                 const F ivl = F::from((ivp >> (32 * h)) & 0xFFFFFFFFULL);
-                c.constraint(sel[13] * (hl - limb(0, FH(wd, 0), h)));
+                c.gated(S13, hl - limb(0, FH(wd, 0), h));
                 c.constraint(sel[14] * (hl - limb(0, FT(wd, 0), h)));
                 c.constraint(sel[14] * (hn - (fin * ivl + (one - fin) * hl)));
                 c.constraint(keep_h * (hn - hl));
             }
         }
+        c.close(S12);
+        c.close(S13);
         // ---- 6. message schedule, range check, link
 #pragma unroll 1
         for (int s = 0; s < 16; ++s)

@@ -39,7 +39,7 @@ VX_HD constexpr uint32_t pad64(int j) { return j == 0 ? 0x80000000u : (j == 15 ?
 }  // namespace shc
 
 struct ShaAir {
-    static constexpr int ID = 4, COLS = shc::COLS, PUB = 8, PERIODIC = 4, PERIOD_LOG = 6;
+    static constexpr int ID = 4, COLS = shc::COLS, PUB = 8, PERIODIC = 4, PERIOD_LOG = 6, QUOT_ROWS_PER_LANE = 1;
 
     template <class F, class Row, class C>
     __host__ __device__ static void eval(const Row& loc, const Row& nxt, const F* per, const F* pub, C& c) {

@@ -118,6 +118,30 @@ __device__ __forceinline__ void gl_mul128(uint64_t a, uint64_t b, uint64_t& hi, 
     lo = (t2 << 32) | (uint32_t)t0;
 }
 #endif
+// ---- lazy dot products: sum_k c_k * p_k kept as a 160-bit integer, reduced once --------------------------------
+// (the random-linear-combination accumulators of the quotient kernel: one 64x64 multiply + a 5-word carry chain
+// per term instead of multiply + reduce + modular add)
+struct gl_acc {
+    uint64_t lo, hi;
+    uint32_t top;
+};
+__device__ __forceinline__ void gl_acc_zero(gl_acc& a) { a.lo = a.hi = 0, a.top = 0; }
+// a += c * p (any 64-bit representatives); at most 2^32 terms
+__device__ __forceinline__ void gl_mac(gl_acc& a, uint64_t c, uint64_t p) {
+    uint64_t ph, pl;
+    gl_mul128(c, p, ph, pl);
+    const bool c1 = __builtin_add_overflow(a.lo, pl, &a.lo);
+    const bool c2 = __builtin_add_overflow(a.hi, ph, &a.hi);
+    const bool c3 = __builtin_add_overflow(a.hi, (uint64_t)c1, &a.hi);
+    a.top += (uint32_t)c2 + (uint32_t)c3;
+}
+// lo + hi 2^64 + top 2^128 (mod p), canonical.  2^128 = eps^2 = 2^64 - 2^33 + 1 = -2^32 (mod p).
+__device__ __forceinline__ uint64_t gl_reduce128(uint64_t hi, uint64_t lo);
+__device__ __forceinline__ uint64_t gl_acc_reduce(const gl_acc& a) {
+    const uint64_t r = gl_reduce128(a.hi, a.lo);
+    return gl_sub(r, (uint64_t)a.top << 32);  // top < 2^31: top 2^32 < p
+}
+
 // inputs: any 64-bit representatives; output in [0, 2^64) (non-canonical)
 __device__ __forceinline__ uint64_t gl_mul_nc(uint64_t a, uint64_t b) {
     uint64_t hi, lo;

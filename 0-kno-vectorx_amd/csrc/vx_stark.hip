@@ -115,34 +115,45 @@ struct QuotArgs {
     const uint64_t* periodic;  // [PERIODIC][(1<<PERIOD_LOG) << rate_bits] on the LDE coset
     const uint64_t* pub;       // [PUB] (device)
     const uint64_t* tw;        // forward w_{2^32} power table
+    const uint64_t* apow;      // [2K]: apow[2k + j] = alpha_j^(K-1-k), K = the AIR's constraint count (device)
 };
 
-template <class Air>
-__global__ __launch_bounds__(256) void k_quotient(QuotArgs a) {
+// one block = a tile of 256 * R consecutive LDE points, lane t holding points t, t + 256, ... of the tile
+template <class Air, int R>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_quotient(QuotArgs a) {
+    using F = FpN<R>;
     const size_t N = (size_t)1 << a.log_N;
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const uint64_t x = gl_mul(a.shift, root_pow_f(a.tw, i, a.log_N));
-    const int k = (int)(i & (((size_t)1 << a.rate_bits) - 1));
-    Consumer<Fp> c;
-    c.acc[0] = c.acc[1] = {0};
-    c.alpha[0] = {a.alpha[0]};
-    c.alpha[1] = {a.alpha[1]};
-    c.z_last = {gl_sub(x, a.last)};
-    // L_first = Z_H(x) / (n (x - 1)),  L_last = last * Z_H(x) / (n (x - last))
-    const uint64_t zh_n = gl_mul(a.zh[k], a.n_inv);
-    c.l_first = {gl_mul(zh_n, gl_inv(gl_sub(x, 1)))};
-    c.l_last = {gl_mul(gl_mul(zh_n, a.last), gl_inv(gl_sub(x, a.last)))};
-    RowView loc{a.lde, N, i}, nxt{a.lde, N, (i + ((size_t)1 << a.rate_bits)) & (N - 1)};
-    Fp per[Air::PERIODIC > 0 ? Air::PERIODIC : 1], pub[Air::PUB > 0 ? Air::PUB : 1];
-    const size_t plen = (size_t)1 << (Air::PERIOD_LOG + a.rate_bits);
+    const size_t i0 = blockIdx.x * (size_t)(256 * R) + threadIdx.x;
+    const size_t step = (size_t)1 << a.rate_bits, plen = (size_t)1 << (Air::PERIOD_LOG + a.rate_bits);
+    Consumer<F> c;
+    c.init(a.apow);
+    RowViewN<R> loc{a.lde, N, {}}, nxt{a.lde, N, {}};
+    F per[Air::PERIODIC > 0 ? Air::PERIODIC : 1], pub[Air::PUB > 0 ? Air::PUB : 1];
+    uint64_t zinv[R];
 #pragma unroll
-    for (int j = 0; j < Air::PERIODIC; ++j) per[j] = {a.periodic[j * plen + (i & (plen - 1))]};
+    for (int j = 0; j < R; ++j) {
+        const size_t i = (i0 + 256 * (size_t)j) & (N - 1);  // N >= 256 * R is checked by the launcher
+        const uint64_t x = gl_mul(a.shift, root_pow_f(a.tw, i, a.log_N));
+        const int k = (int)(i & (step - 1));
+        c.z_last.v[j] = gl_sub(x, a.last);
+        // L_first = Z_H(x) / (n (x - 1)),  L_last = last * Z_H(x) / (n (x - last))
+        const uint64_t zh_n = gl_mul(a.zh[k], a.n_inv);
+        c.l_first.v[j] = gl_mul(zh_n, gl_inv(gl_sub(x, 1)));
+        c.l_last.v[j] = gl_mul(gl_mul(zh_n, a.last), gl_inv(gl_sub(x, a.last)));
+        zinv[j] = a.zh_inv[k];
+        loc.i[j] = i;
+        nxt.i[j] = (i + step) & (N - 1);
 #pragma unroll
-    for (int j = 0; j < Air::PUB; ++j) pub[j] = {a.pub[j]};
-    Air::template eval<Fp>(loc, nxt, per, pub, c);
-    a.q_out[i] = gl_mul(c.acc[0].v, a.zh_inv[k]);
-    a.q_out[N + i] = gl_mul(c.acc[1].v, a.zh_inv[k]);
+        for (int q = 0; q < Air::PERIODIC; ++q) per[q].v[j] = a.periodic[q * plen + (i & (plen - 1))];
+    }
+#pragma unroll
+    for (int q = 0; q < Air::PUB; ++q) pub[q] = F::from(a.pub[q]);
+    Air::template eval<F>(loc, nxt, per, pub, c);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        a.q_out[loc.i[j]] = gl_mul(c.result(0, j), zinv[j]);
+        a.q_out[N + loc.i[j]] = gl_mul(c.result(1, j), zinv[j]);
+    }
 }
 
 // Openings from the committed LDE: the n points x_i = g * w_n^i (LDE indices i << r) determine a polynomial
@@ -226,11 +237,25 @@ struct AirDesc {
     int id, cols, pub, periodic, period_log;
     void (*periodic_values)(std::vector<uint64_t>&);  // [periodic][1 << period_log] values on the trace rows
     void (*launch)(QuotArgs&, hipStream_t);
+    int (*count)();  // number of constraints eval pushes
 };
 template <class Air>
+static int count_q() {
+    static const int k = [] {
+        Consumer<CountF> c;
+        CountRow r;
+        CountF per[Air::PERIODIC > 0 ? Air::PERIODIC : 1], pub[Air::PUB > 0 ? Air::PUB : 1];
+        Air::template eval<CountF>(r, r, per, pub, c);
+        return c.k;
+    }();
+    return k;
+}
+template <class Air>
 static void launch_q(QuotArgs& a, hipStream_t s) {
-    size_t N = (size_t)1 << a.log_N;
-    hipLaunchKernelGGL(k_quotient<Air>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, a);
+    constexpr int R = Air::QUOT_ROWS_PER_LANE;
+    const size_t N = (size_t)1 << a.log_N;
+    if (R > 1 && N >= 256 * (size_t)R) hipLaunchKernelGGL((k_quotient<Air, R>), dim3((unsigned)(N / (256 * R))), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_quotient<Air, 1>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, a);
 }
 static void no_periodic(std::vector<uint64_t>& v) { v.clear(); }
 static void mix_periodic(std::vector<uint64_t>& v) { v = {0, 0, 0, 1, 3, 5, 7, 11}; }
@@ -246,10 +271,10 @@ static void sha_periodic(std::vector<uint64_t>& v) {
     for (int r = 0; r < 64; ++r) v[192 + r] = shc::K_H[r];
 }
 static const AirDesc AIRS[] = {
-    {ShaAir::ID, ShaAir::COLS, ShaAir::PUB, ShaAir::PERIODIC, ShaAir::PERIOD_LOG, sha_periodic, launch_q<ShaAir>},
-    {BlakeAir::ID, BlakeAir::COLS, BlakeAir::PUB, BlakeAir::PERIODIC, BlakeAir::PERIOD_LOG, blake_periodic, launch_q<BlakeAir>},
-    {FibAir::ID, FibAir::COLS, FibAir::PUB, FibAir::PERIODIC, FibAir::PERIOD_LOG, no_periodic, launch_q<FibAir>},
-    {MixAir::ID, MixAir::COLS, MixAir::PUB, MixAir::PERIODIC, MixAir::PERIOD_LOG, mix_periodic, launch_q<MixAir>},
+    {ShaAir::ID, ShaAir::COLS, ShaAir::PUB, ShaAir::PERIODIC, ShaAir::PERIOD_LOG, sha_periodic, launch_q<ShaAir>, count_q<ShaAir>},
+    {BlakeAir::ID, BlakeAir::COLS, BlakeAir::PUB, BlakeAir::PERIODIC, BlakeAir::PERIOD_LOG, blake_periodic, launch_q<BlakeAir>, count_q<BlakeAir>},
+    {FibAir::ID, FibAir::COLS, FibAir::PUB, FibAir::PERIODIC, FibAir::PERIOD_LOG, no_periodic, launch_q<FibAir>, count_q<FibAir>},
+    {MixAir::ID, MixAir::COLS, MixAir::PUB, MixAir::PERIODIC, MixAir::PERIOD_LOG, mix_periodic, launch_q<MixAir>, count_q<MixAir>},
 };
 static const AirDesc* find_air(int id) {
     for (const AirDesc& d : AIRS)
@@ -449,7 +474,21 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
         qa.periodic = d_per;
         qa.pub = d_pub;
         qa.tw = ctx->tw_fwd.d;
+        // powers of the two alphas for the K constraints (the Horner recurrence as a dot product, air.cuh)
+        const int K = air->count();
+        std::vector<uint64_t> apow(2 * (size_t)K);
+        uint64_t pw[2] = {1, 1};
+        for (int kk = K - 1; kk >= 0; --kk)
+            for (int j = 0; j < 2; ++j) {
+                apow[2 * (size_t)kk + j] = pw[j];
+                pw[j] = glh::mul(pw[j], alphas[j]);
+            }
+        uint64_t* d_apow_q = mem.alloc(apow.size());
+        VX_CHECK(d_apow_q, "stark prove: out of device memory (alpha powers)");
+        VX_HIP(hipMemcpyAsync(d_apow_q, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        qa.apow = d_apow_q;
         air->launch(qa, ctx->stream);
+        VX_HIP(hipStreamSynchronize(ctx->stream));  // apow (host vector) must outlive the copy
         VX_HIP(hipGetLastError());
     }
     // values on the coset -> coefficients (coset_ifft), split into Q chunks of n, commit (from_coeffs)
