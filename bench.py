@@ -246,7 +246,7 @@ def main():
                            "two ShaChainAir witnesses + STARKs: current and new authority-set commitments (2^16 x 1444 each)"],
                 "missing": ["epoch-end header parsing and EdDSA inside a STARK", "recursive aggregation into one proof"],
             }
-        elif not args.no_cpu_baseline:
+        elif not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline(vx)
         print(json.dumps(line), flush=True)
     ctx.close()
