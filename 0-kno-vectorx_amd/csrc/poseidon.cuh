@@ -13,7 +13,8 @@
 #include "gl.cuh"
 #include "poseidon_constants.h"
 
-static __constant__ uint64_t POSEIDON_RC[360] = VX_POSEIDON_RC_INIT;
+// folded form: partial rounds (4..25) carry a single constant, for element 0 (poseidon_constants.h)
+static __constant__ uint64_t POSEIDON_RC[360] = VX_POSEIDON_RC_FOLDED_INIT;
 
 // x^7; intermediate products stay non-canonical (the multiplier and the MDS split accept any
 // 64-bit representative), so no compare/select is spent between the four multiplications
@@ -85,7 +86,8 @@ __device__ __forceinline__ void poseidon_mds_part(const TIn* x, T* y) {
 // that; poseidon_permute canonicalises once at the end.  (v_mad_u64_u32 issues at the rate of any other VOP3
 // instruction on gfx950 and plain 32-bit add/sub/shift at almost twice that rate, tools/isa_rate.hip: the
 // 52/12 split puts half of the layer on the cheap instructions and needs no zero-extension moves.)
-template <bool RC>
+// RC: 0 = no constants, 1 = the next round's constant for element 0 only (a partial round follows), 12 = all twelve
+template <int RC>
 __device__ __forceinline__ void poseidon_mds(uint64_t* s, int rc_next) {
     constexpr uint64_t M52 = (1ULL << 52) - 1;
     uint64_t xl[12];
@@ -105,7 +107,7 @@ __device__ __forceinline__ void poseidon_mds(uint64_t* s, int rc_next) {
     for (int r = 0; r < 12; ++r) {
         uint64_t al = (uint64_t)yl[r];
         uint32_t ah = (uint32_t)yh[r];
-        if (RC) {
+        if (RC == 12 || (RC == 1 && r == 0)) {
             const uint64_t c = POSEIDON_RC[rc_next + r];
             al += c & M52;
             ah += (uint32_t)(c >> 52);
@@ -123,28 +125,35 @@ __device__ __forceinline__ void poseidon_permute(uint64_t* s) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = gl_add_nc(s[i], POSEIDON_RC[i]);
 #pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox(s[i]);
-        poseidon_mds<true>(s, rc);
-        rc += 12;
-    }
-#pragma unroll 1
-    for (int r = 0; r < 22; ++r) {
-        s[0] = poseidon_sbox(s[0]);
-        poseidon_mds<true>(s, rc);
-        rc += 12;
-    }
-#pragma unroll 1
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox(s[i]);
-        poseidon_mds<true>(s, rc);
+        poseidon_mds<12>(s, rc);
         rc += 12;
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox(s[i]);
-    poseidon_mds<false>(s, 0);
+    poseidon_mds<1>(s, rc);  // round 4 is partial
+    rc += 12;
+#pragma unroll 1
+    for (int r = 0; r < 21; ++r) {
+        s[0] = poseidon_sbox(s[0]);
+        poseidon_mds<1>(s, rc);
+        rc += 12;
+    }
+    s[0] = poseidon_sbox(s[0]);
+    poseidon_mds<12>(s, rc);  // round 26 is full again (its constants absorbed what the partial rounds pushed forward)
+    rc += 12;
+#pragma unroll 1
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox(s[i]);
+        poseidon_mds<12>(s, rc);
+        rc += 12;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox(s[i]);
+    poseidon_mds<0>(s, 0);
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = gl_canon(s[i]);
 }

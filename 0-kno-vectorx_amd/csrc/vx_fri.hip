@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256) void k_fri_pow(const uint64_t* state12, int po
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (; t < count; t += stride) {
         uint64_t cand = base + t;
-        if (cand >= *best) return;  // a smaller hit exists already
+        // a smaller hit exists already (the load must not be hoisted out of the loop: it is how late waves stop)
+        if (cand >= __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
         uint64_t s[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) s[k] = state12[k];
@@ -281,10 +282,12 @@ int32_t vx_fri_pow(vx_ctx* ctx, const uint64_t state[12], int pos, int bits, uin
     unsigned long long init = ~0ULL, h = ~0ULL;
     VX_HIP(hipMemcpyAsync(sc, state, 12 * 8, hipMemcpyHostToDevice, ctx->stream));
     VX_HIP(hipMemcpyAsync(best, &init, 8, hipMemcpyHostToDevice, ctx->stream));
-    const uint64_t chunk = 1ULL << 22;
+    // first launch: 2^(bits+2) candidates (misses with probability e^-4), later ones 2^22; the smallest nonce wins
     const uint64_t limit = 1ULL << (bits + 12 > 62 ? 62 : bits + 12);  // far beyond the expected 2^bits tries
-    for (uint64_t base = 0; base < limit; base += chunk) {
-        hipLaunchKernelGGL(k_fri_pow, dim3(2048), dim3(256), 0, ctx->stream, sc, pos, bits, base, chunk, best);
+    uint64_t chunk = 1ULL << (bits + 2 < 16 ? 16 : (bits + 2 > 22 ? 22 : bits + 2));
+    for (uint64_t base = 0; base < limit; base += chunk, chunk = 1ULL << 22) {
+        const unsigned blocks = (unsigned)(chunk / 256 < 2048 ? chunk / 256 : 2048);
+        hipLaunchKernelGGL(k_fri_pow, dim3(blocks), dim3(256), 0, ctx->stream, sc, pos, bits, base, chunk, best);
         VX_HIP(hipGetLastError());
         VX_HIP(hipMemcpyAsync(&h, best, 8, hipMemcpyDeviceToHost, ctx->stream));
         VX_HIP(hipStreamSynchronize(ctx->stream));

@@ -151,6 +151,27 @@ __device__ Pt pt_scalar_mul(const Pt& p, const uint32_t* k) {  // variable time,
     }
     return acc;
 }
+// a*P + b*Q in one pass (Shamir): one doubling and ONE addition per bit, the addend (identity, P, Q or P+Q) picked by
+// data selects so that the lanes of a wave never diverge -- with a branch per bit every wave would execute all cases.
+// The addition law is complete on this curve, so adding the identity is fine.
+__device__ Pt pt_double_scalar_mul(const Pt& p, const uint32_t* a, const Pt& q, const uint32_t* b) {
+    const Pt pq = pt_add(p, q), id = pt_identity();
+    Pt acc = id;
+    for (int bit = 255; bit >= 0; --bit) {
+        acc = pt_add(acc, acc);
+        const bool ba = (a[bit >> 5] >> (bit & 31)) & 1, bb = (b[bit >> 5] >> (bit & 31)) & 1;
+        Pt t;
+        const U256* src[4][4] = {{&id.X, &id.Y, &id.Z, &id.T}, {&p.X, &p.Y, &p.Z, &p.T}, {&q.X, &q.Y, &q.Z, &q.T}, {&pq.X, &pq.Y, &pq.Z, &pq.T}};
+        U256* dst[4] = {&t.X, &t.Y, &t.Z, &t.T};
+        for (int c = 0; c < 4; ++c)
+            for (int w = 0; w < 8; ++w) {
+                const uint32_t lo = ba ? src[1][c]->w[w] : src[0][c]->w[w], hi = ba ? src[3][c]->w[w] : src[2][c]->w[w];
+                dst[c]->w[w] = bb ? hi : lo;
+            }
+        acc = pt_add(acc, t);
+    }
+    return acc;
+}
 // RFC 8032 5.1.3 decoding; false when the encoding is not a curve point
 __device__ bool pt_decode(const uint8_t* s, Pt* out) {
     U256 y;
@@ -278,7 +299,7 @@ __global__ __launch_bounds__(64) void k_ed25519_verify(const uint8_t* pubkeys, c
     for (int j = 0; j < 8; ++j) one.w[j] = j == 0;
     const U256 bx = fe_from(ED_BX), by = fe_from(ED_BY);
     const Pt B = {bx, by, one, fe_mul(bx, by)};
-    const Pt R = pt_add(pt_scalar_mul(B, s), pt_scalar_mul(nA, k));
+    const Pt R = pt_double_scalar_mul(B, s, nA, k);
     uint8_t enc[32];
     pt_encode(R, enc);
     bool eq = true;

@@ -179,16 +179,19 @@ __global__ __launch_bounds__(256) void k_bary_dot(const uint64_t* vals, size_t c
                                                   const uint64_t* w1, uint64_t* out) {
     __shared__ uint64_t red[256 * 4];
     const uint64_t* col = vals + blockIdx.x * col_stride;
-    gl2 s0{0, 0}, s1{0, 0};
+    gl_acc acc[4];  // lazy sums (160-bit integers), reduced once per lane
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gl_acc_zero(acc[e]);
+#pragma unroll 2
     for (size_t i = threadIdx.x; i < n; i += 256) {
-        uint64_t v = col[i << log_step];
-        s0 = gl2_add(s0, gl2_scale({w0[2 * i], w0[2 * i + 1]}, v));
-        s1 = gl2_add(s1, gl2_scale({w1[2 * i], w1[2 * i + 1]}, v));
+        const uint64_t v = col[i << log_step];
+        gl_mac(acc[0], v, w0[2 * i]);
+        gl_mac(acc[1], v, w0[2 * i + 1]);
+        gl_mac(acc[2], v, w1[2 * i]);
+        gl_mac(acc[3], v, w1[2 * i + 1]);
     }
-    red[4 * threadIdx.x] = s0.a;
-    red[4 * threadIdx.x + 1] = s0.b;
-    red[4 * threadIdx.x + 2] = s1.a;
-    red[4 * threadIdx.x + 3] = s1.b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[4 * threadIdx.x + e] = gl_acc_reduce(acc[e]);
     __syncthreads();
     for (int h = 128; h > 0; h >>= 1) {
         if ((int)threadIdx.x < h)
@@ -212,24 +215,48 @@ struct CombineArgs {
 };
 // final_poly(x) = alpha^c * (S0(x) - y0) / (x - zeta) + (S1(x) - y1) / (x - w zeta)
 // (PolynomialBatch::prove_openings: batch 0 = trace ++ quotient at zeta, batch 1 = trace at w*zeta)
+// One block = 256 * R consecutive LDE points, lane t holding points t, t + 256, ...: R independent loads per column
+// and R x 2 KB of each column per visit (the walk over thousands of columns is bound by load latency / address
+// translation otherwise).  The alpha-power sums are 160-bit integer multiply-accumulates reduced once (gl_mac).
+template <int R>
 __global__ __launch_bounds__(256) void k_fri_combine(CombineArgs a) {
     const size_t N = (size_t)1 << a.log_N;
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    gl2 s1{0, 0};
-    for (int j = 0; j < a.n_cols; ++j)
-        s1 = gl2_add(s1, gl2_scale({a.alpha_pow[2 * j], a.alpha_pow[2 * j + 1]}, a.trace_lde[(size_t)j * N + i]));
-    gl2 s0 = s1;
-    for (int j = 0; j < a.n_q; ++j) {
-        int k = a.n_cols + j;
-        s0 = gl2_add(s0, gl2_scale({a.alpha_pow[2 * k], a.alpha_pow[2 * k + 1]}, a.quot_lde[(size_t)j * N + i]));
+    const size_t i0 = blockIdx.x * (size_t)(256 * R) + threadIdx.x;
+    size_t idx[R];
+    gl_acc sa[R], sb[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        idx[r] = (i0 + 256 * (size_t)r) & (N - 1);  // R > 1 only when N >= 256 R (launcher); duplicates write equal values
+        gl_acc_zero(sa[r]);
+        gl_acc_zero(sb[r]);
     }
-    const uint64_t x = gl_mul(a.shift, root_pow_f(a.tw, i, a.log_N));
-    gl2 t0 = gl2_mul(gl2_sub(s0, a.y0), gl2_inv({gl_sub(x, a.zeta.a), gl_neg(a.zeta.b)}));
-    gl2 t1 = gl2_mul(gl2_sub(s1, a.y1), gl2_inv({gl_sub(x, a.zeta_next.a), gl_neg(a.zeta_next.b)}));
-    gl2 f = gl2_add(gl2_mul(a.alpha_c, t0), t1);
-    a.out[2 * i] = f.a;
-    a.out[2 * i + 1] = f.b;
+#pragma unroll 2
+    for (int j = 0; j < a.n_cols; ++j) {
+        const uint64_t pa = a.alpha_pow[2 * j], pb = a.alpha_pow[2 * j + 1];
+        const uint64_t* col = a.trace_lde + (size_t)j * N;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint64_t v = col[idx[r]];
+            gl_mac(sa[r], v, pa);
+            gl_mac(sb[r], v, pb);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const size_t i = idx[r];
+        const gl2 s1{gl_acc_reduce(sa[r]), gl_acc_reduce(sb[r])};
+        gl2 s0 = s1;
+        for (int j = 0; j < a.n_q; ++j) {
+            const int k = a.n_cols + j;
+            s0 = gl2_add(s0, gl2_scale({a.alpha_pow[2 * k], a.alpha_pow[2 * k + 1]}, a.quot_lde[(size_t)j * N + i]));
+        }
+        const uint64_t x = gl_mul(a.shift, root_pow_f(a.tw, i, a.log_N));
+        gl2 t0 = gl2_mul(gl2_sub(s0, a.y0), gl2_inv({gl_sub(x, a.zeta.a), gl_neg(a.zeta.b)}));
+        gl2 t1 = gl2_mul(gl2_sub(s1, a.y1), gl2_inv({gl_sub(x, a.zeta_next.a), gl_neg(a.zeta_next.b)}));
+        gl2 f = gl2_add(gl2_mul(a.alpha_c, t0), t1);
+        a.out[2 * i] = f.a;
+        a.out[2 * i + 1] = f.b;
+    }
 }
 
 // ------------------------------------------------------------------ AIR registry
@@ -578,7 +605,8 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
         ca.shift = g;
         ca.tw = ctx->tw_fwd.d;
         ca.out = layers[0];
-        hipLaunchKernelGGL(k_fri_combine, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, ca);
+        if (N >= 1024) hipLaunchKernelGGL(k_fri_combine<4>, dim3((unsigned)(N / 1024)), dim3(256), 0, ctx->stream, ca);
+        else hipLaunchKernelGGL(k_fri_combine<1>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, ca);
         VX_HIP(hipGetLastError());
     }
 

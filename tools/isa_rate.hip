@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_mds(uint64_t* out, uint32_t seed) {
     uint64_t s[12];
     for (int j = 0; j < 12; ++j) s[j] = 0x9E3779B97F4A7C15ULL * (threadIdx.x + seed + j) | 1;
 #pragma unroll 1
-    for (int i = 0; i < PITER * 30; ++i) poseidon_mds<true>(s, (i % 29) * 12);
+    for (int i = 0; i < PITER * 30; ++i) poseidon_mds<12>(s, (i % 29) * 12);
     uint64_t x = 0;
     for (int j = 0; j < 12; ++j) x ^= s[j];
     out[blockIdx.x * 256 + threadIdx.x] = x;
