@@ -174,31 +174,70 @@ __global__ __launch_bounds__(256) void k_bary_weights(int log_n, uint64_t shift,
     w1[2 * i] = d1.a;
     w1[2 * i + 1] = d1.b;
 }
-// out[col] = (sum_i V[col][i << log_step] * w0[i], sum_i V[col][i << log_step] * w1[i]); one block per column
-__global__ __launch_bounds__(256) void k_bary_dot(const uint64_t* vals, size_t col_stride, int log_step, size_t n, const uint64_t* w0,
-                                                  const uint64_t* w1, uint64_t* out) {
+// Consume mode: after the in-place inverse NTT the trace buffer holds coefficient k at position brev(k), so
+// P(zeta) = sum_j buf[j] * zeta^brev(j): w0[j] = zeta^brev(j), w1[j] = (w zeta)^brev(j) from the tables of
+// squarings zp[b] = z^(2^b) -- the same dot-product kernel then reads the n coefficients (half the bytes of
+// every second LDE point).
+struct PowBrevArgs {
+    gl2 z0[32], z1[32];  // zeta^(2^b), (w zeta)^(2^b)
+    int log_n;
+};
+__global__ __launch_bounds__(256) void k_pow_brev_weights(PowBrevArgs a, uint64_t* w0, uint64_t* w1) {
+    const size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (j >= ((size_t)1 << a.log_n)) return;
+    const uint32_t e = brev32((uint32_t)j, a.log_n);
+    gl2 p0{1, 0}, p1{1, 0};
+    for (int b = 0; b < a.log_n; ++b)
+        if ((e >> b) & 1) {
+            p0 = gl2_mul(p0, a.z0[b]);
+            p1 = gl2_mul(p1, a.z1[b]);
+        }
+    w0[2 * j] = p0.a;
+    w0[2 * j + 1] = p0.b;
+    w1[2 * j] = p1.a;
+    w1[2 * j + 1] = p1.b;
+}
+// out[col] = (sum_i V[col][i << log_step] * w0[i], sum_i V[col][i << log_step] * w1[i]).  One block per BARY_CPB
+// columns: the two ext weights of an index (32 bytes) are loaded once and used for BARY_CPB values (8 bytes each) --
+// with one column per block the weight stream, served by L2 / Infinity Cache, was 4x the data stream.
+constexpr int BARY_CPB = 4;
+__global__ __launch_bounds__(256) void k_bary_dot(const uint64_t* vals, size_t col_stride, int log_step, size_t n, size_t n_cols,
+                                                  const uint64_t* w0, const uint64_t* w1, uint64_t* out) {
     __shared__ uint64_t red[256 * 4];
-    const uint64_t* col = vals + blockIdx.x * col_stride;
-    gl_acc acc[4];  // lazy sums (160-bit integers), reduced once per lane
+    const uint64_t* col[BARY_CPB];
+    gl_acc acc[BARY_CPB][4];  // lazy sums (160-bit integers), reduced once per lane
 #pragma unroll
-    for (int e = 0; e < 4; ++e) gl_acc_zero(acc[e]);
-#pragma unroll 2
+    for (int q = 0; q < BARY_CPB; ++q) {
+        const size_t cidx = blockIdx.x * (size_t)BARY_CPB + q;
+        col[q] = vals + (cidx < n_cols ? cidx : n_cols - 1) * col_stride;  // tail block: recomputed, not written
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gl_acc_zero(acc[q][e]);
+    }
     for (size_t i = threadIdx.x; i < n; i += 256) {
-        const uint64_t v = col[i << log_step];
-        gl_mac(acc[0], v, w0[2 * i]);
-        gl_mac(acc[1], v, w0[2 * i + 1]);
-        gl_mac(acc[2], v, w1[2 * i]);
-        gl_mac(acc[3], v, w1[2 * i + 1]);
+        const uint64_t a0 = w0[2 * i], b0 = w0[2 * i + 1], a1 = w1[2 * i], b1 = w1[2 * i + 1];
+#pragma unroll
+        for (int q = 0; q < BARY_CPB; ++q) {
+            const uint64_t v = col[q][i << log_step];
+            gl_mac(acc[q][0], v, a0);
+            gl_mac(acc[q][1], v, b0);
+            gl_mac(acc[q][2], v, a1);
+            gl_mac(acc[q][3], v, b1);
+        }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[4 * threadIdx.x + e] = gl_acc_reduce(acc[e]);
-    __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) {
-        if ((int)threadIdx.x < h)
-            for (int e = 0; e < 4; ++e) red[4 * threadIdx.x + e] = gl_add(red[4 * threadIdx.x + e], red[4 * (threadIdx.x + h) + e]);
+    for (int q = 0; q < BARY_CPB; ++q) {
         __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[4 * threadIdx.x + e] = gl_acc_reduce(acc[q][e]);
+        __syncthreads();
+        for (int h = 128; h > 0; h >>= 1) {
+            if ((int)threadIdx.x < h)
+                for (int e = 0; e < 4; ++e) red[4 * threadIdx.x + e] = gl_add(red[4 * threadIdx.x + e], red[4 * (threadIdx.x + h) + e]);
+            __syncthreads();
+        }
+        const size_t cidx = blockIdx.x * (size_t)BARY_CPB + q;
+        if (threadIdx.x < 4 && cidx < n_cols) out[4 * cidx + threadIdx.x] = red[threadIdx.x];
     }
-    if (threadIdx.x < 4) out[4 * blockIdx.x + threadIdx.x] = red[threadIdx.x];
 }
 
 struct CombineArgs {
@@ -545,10 +584,26 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
     VX_CHECK(w0 && w1 && d_open, "stark prove: out of device memory (openings)");
     hipLaunchKernelGGL(k_bary_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, L, g, gl2{zeta.a, zeta.b},
                        gl2{zeta_next.a, zeta_next.b}, (const uint64_t*)ctx->tw_fwd.d, w0, w1);
-    hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)c), dim3(256), 0, ctx->stream, (const uint64_t*)trace_lde, N, r, n, (const uint64_t*)w0,
-                       (const uint64_t*)w1, d_open);
-    hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)nq), dim3(256), 0, ctx->stream, (const uint64_t*)quot_lde, N, r, n, (const uint64_t*)w0,
+    hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)((nq + BARY_CPB - 1) / BARY_CPB)), dim3(256), 0, ctx->stream, (const uint64_t*)quot_lde, N, r, n, (size_t)nq, (const uint64_t*)w0,
                        (const uint64_t*)w1, d_open + 4 * c);
+    if (consume_trace) {
+        // the trace buffer holds the coefficients (bit-reversed positions): plain evaluation, no barycentric factor
+        PowBrevArgs pa{};
+        pa.log_n = L;
+        Ext z0 = zeta, z1 = zeta_next;
+        for (int b = 0; b < L; ++b) {
+            pa.z0[b] = {z0.a, z0.b};
+            pa.z1[b] = {z1.a, z1.b};
+            z0 = e_mul(z0, z0);
+            z1 = e_mul(z1, z1);
+        }
+        hipLaunchKernelGGL(k_pow_brev_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, pa, w0, w1);
+        hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)((c + BARY_CPB - 1) / BARY_CPB)), dim3(256), 0, ctx->stream, (const uint64_t*)trace_d, n, 0, n, c, (const uint64_t*)w0,
+                           (const uint64_t*)w1, d_open);
+    } else {
+        hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)((c + BARY_CPB - 1) / BARY_CPB)), dim3(256), 0, ctx->stream, (const uint64_t*)trace_lde, N, r, n, c, (const uint64_t*)w0,
+                           (const uint64_t*)w1, d_open);
+    }
     VX_HIP(hipGetLastError());
     std::vector<uint64_t> h_open(4 * (c + nq));
     VX_HIP(hipMemcpyAsync(h_open.data(), d_open, h_open.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -557,9 +612,11 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
     const Ext f0 = e_scale(e_sub(e_pow(zeta, n), Ext{gn_, 0}), fsc);       // (zeta^n - g^n) / (n g^n)
     const Ext f1 = e_scale(e_sub(e_pow(zeta_next, n), Ext{gn_, 0}), fsc);  // ((w zeta)^n - g^n) / (n g^n)
     std::vector<Ext> o_local(c), o_next(c), o_quot(nq);
+    const Ext one_{1, 0};
+    const Ext t0 = consume_trace ? one_ : f0, t1 = consume_trace ? one_ : f1;  // coefficient sums need no factor
     for (size_t j = 0; j < c; ++j) {
-        o_local[j] = e_mul(f0, Ext{h_open[4 * j], h_open[4 * j + 1]});
-        o_next[j] = e_mul(f1, Ext{h_open[4 * j + 2], h_open[4 * j + 3]});
+        o_local[j] = e_mul(t0, Ext{h_open[4 * j], h_open[4 * j + 1]});
+        o_next[j] = e_mul(t1, Ext{h_open[4 * j + 2], h_open[4 * j + 3]});
     }
     for (int j = 0; j < nq; ++j) o_quot[j] = e_mul(f0, Ext{h_open[4 * (c + j)], h_open[4 * (c + j) + 1]});
     for (const Ext& e : o_local) proof.push_back(e.a), proof.push_back(e.b);
