@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_pow_brev_weights(PowBrevArgs a, uint64_
 // out[col] = (sum_i V[col][i << log_step] * w0[i], sum_i V[col][i << log_step] * w1[i]).  One block per BARY_CPB
 // columns: the two ext weights of an index (32 bytes) are loaded once and used for BARY_CPB values (8 bytes each) --
 // with one column per block the weight stream, served by L2 / Infinity Cache, was 4x the data stream.
-constexpr int BARY_CPB = 4;
+constexpr int BARY_CPB = 2;  // measured per proof: 1 -> 9.3 ms, 4 -> 12.7 ms
 __global__ __launch_bounds__(256) void k_bary_dot(const uint64_t* vals, size_t col_stride, int log_step, size_t n, size_t n_cols,
                                                   const uint64_t* w0, const uint64_t* w1, uint64_t* out) {
     __shared__ uint64_t red[256 * 4];
