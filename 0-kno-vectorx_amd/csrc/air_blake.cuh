@@ -105,7 +105,10 @@ struct BlakeAir {
             c.constraint(x * (x - one));
         };
         // ---- 1. booleans
-#pragma unroll 4
+#ifndef VX_Q_UNROLL
+#define VX_Q_UNROLL 4
+#endif
+#pragma unroll VX_Q_UNROLL
         for (int col = 0; col < 4096; ++col) boolean(col);
 #pragma unroll 1
         for (int col = MB0; col < MB0 + 64; ++col) boolean(col);
@@ -155,7 +158,7 @@ struct BlakeAir {
                 }
             };
             auto xorrot = [&](int w1, int c1, int w2, int c2, int res_slot, int rot) {
-#pragma unroll 4
+#pragma unroll VX_Q_UNROLL
                 for (int i = 0; i < 64; ++i) {
                     const int s = (i + rot) & 63;
                     c.gated(GON, nxt[GB(k, res_slot, i)] - xorf(at(w1, c1 + s), at(w2, c2 + s)));

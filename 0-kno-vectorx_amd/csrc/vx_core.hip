@@ -3,6 +3,8 @@
 #include <stdio.h>
 
 #include "gl.cuh"
+#include <dlfcn.h>
+
 #include "vx_internal.h"
 
 int32_t vx_fail(vx_ctx* ctx, int32_t code, const char* fmt, ...) {
@@ -324,6 +326,31 @@ int32_t vx_ext_batch_mul(vx_ctx* ctx, const vx_buf* a, const vx_buf* b, vx_buf* 
     if (n == 0) return VX_OK;
     hipLaunchKernelGGL(k_ext_mul, dim3(grid_for(n)), dim3(256), 0, ctx->stream, a->d, b->d, o->d, n);
     VX_HIP(hipGetLastError());
+    return VX_OK;
+}
+
+// One all-gather of fixed-size proof blobs.  RCCL is bound at call time (dlsym) from whatever copy is
+// already loaded in the process -- the one the caller's communicator was made by.
+int32_t vx_gather_proofs(vx_ctx* ctx, void* nccl_comm, int world, const uint64_t* mine, size_t n_words, uint64_t* out) {
+    if (!ctx || !nccl_comm || !mine || !out || world < 1) return VX_ERR_ARG;
+    typedef int (*all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+    static all_gather_fn all_gather = nullptr;
+    if (!all_gather) all_gather = (all_gather_fn)dlsym(RTLD_DEFAULT, "ncclAllGather");
+    if (!all_gather) {  // loaded with RTLD_LOCAL (a Python extension's dependency): find that copy by its soname
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            void* h = dlopen(name, RTLD_NOLOAD | RTLD_LAZY);
+            if (h && (all_gather = (all_gather_fn)dlsym(h, "ncclAllGather"))) break;
+        }
+    }
+    if (!all_gather) return vx_fail(ctx, VX_ERR_DEVICE, "gather: ncclAllGather is not loaded in this process");
+    if (n_words == 0) return VX_OK;
+    uint64_t* sc;
+    VX_TRY(vx_scratch(ctx, n_words * ((size_t)world + 1), &sc));
+    VX_HIP(hipMemcpyAsync(sc, mine, n_words * 8, hipMemcpyHostToDevice, ctx->stream));
+    const int rc = all_gather(sc, sc + n_words, n_words, /*ncclUint64=*/5, nccl_comm, ctx->stream);
+    if (rc != 0) return vx_fail(ctx, VX_ERR_DEVICE, "gather: ncclAllGather failed (%d)", rc);
+    VX_HIP(hipMemcpyAsync(out, sc + n_words, n_words * 8 * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipStreamSynchronize(ctx->stream));
     return VX_OK;
 }
 }

@@ -26,6 +26,7 @@ SYMBOLS = [
     "vx_blake2b_256_batch", "vx_sha256_pairs", "vx_verify_subchain", "vx_blake_chain_trace",
     "vx_ed25519_verify_batch", "vx_verify_simple_justification", "vx_sha_chain_trace",
     "vx_verify_epoch_end_header", "vx_rotate_proof_bound", "vx_rotate_prove", "vx_rotate_verify",
+    "vx_gather_proofs",
 ]
 
 VX_AIR_FIBONACCI, VX_AIR_MIX, VX_AIR_BLAKE_CHAIN = 1, 2, 3
@@ -120,6 +121,7 @@ def load_library():
         "vx_rotate_proof_bound": [C.POINTER(StarkConfig), sz, sz, sz, C.POINTER(sz)],
         "vx_rotate_prove": [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.POINTER(JustificationStruct), C.POINTER(StarkConfig), vp, vp, sz, C.POINTER(sz)],
         "vx_rotate_verify": [C.POINTER(StarkConfig), vp, sz, u64, vp, vp, C.c_char_p, sz],
+        "vx_gather_proofs": [vp, vp, C.c_int, vp, sz, vp],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -409,6 +411,13 @@ class Context:
         self._ck(self.L.vx_rotate_prove(self.h, header_buf.h, header_size, epoch_end_block_number, num_authorities, start_position, _ptr(pk),
                                         C.byref(just.struct), C.byref(cfg), _ptr(out32), _ptr(out), out.size, C.byref(need)))
         return out32.tobytes(), out[: need.value]
+
+    def gather_proofs(self, nccl_comm, world, blob_words):
+        """All-gather equal-length proof blobs over RCCL (nccl_comm: a raw ncclComm_t as an integer / c_void_p)."""
+        mine = np.ascontiguousarray(blob_words, dtype=np.uint64)
+        out = np.empty(world * mine.size, dtype=np.uint64)
+        self._ck(self.L.vx_gather_proofs(self.h, C.c_void_p(nccl_comm), world, _ptr(mine), mine.size, _ptr(out)))
+        return out.reshape(world, mine.size)
 
     # K8 / statement
     def blake2b_256_batch(self, msgs_buf, stride, sizes):

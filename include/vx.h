@@ -281,6 +281,14 @@ int32_t vx_rotate_prove(vx_ctx* ctx, const vx_buf* header, uint32_t header_size,
 int32_t vx_rotate_verify(const vx_stark_config* cfg, const uint64_t* blob, size_t blob_len, uint64_t authority_set_id,
                          const uint8_t authority_set_hash[32], const uint8_t out32[32], char* err, size_t errlen);
 
+/* ---- multi-GPU: proofs are independent, one per rank; the only exchange is this gather ----
+ * All-gathers `n_words` u64 words per rank over RCCL on the ctx stream: out (host, world * n_words words, rank
+ * order) is filled on EVERY rank; blobs must have the same length on all ranks (pad to the proof bound).
+ * `nccl_comm` is an ncclComm_t the caller created (ncclCommInitRank, one rank per GPU); the RCCL symbols are
+ * looked up in the process at call time, so the library has no link-time dependency on RCCL and uses the same
+ * copy the caller's communicator belongs to.  VX_ERR_DEVICE if RCCL is not loaded or the collective fails. */
+int32_t vx_gather_proofs(vx_ctx* ctx, void* nccl_comm, int world, const uint64_t* mine, size_t n_words, uint64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,6 @@
 """GPU parity for the witness-side hashing and verify_subchain (statement level)."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -59,3 +60,37 @@ def test_verify_subchain_rejects_bad_chains(ctx, vx):
     with pytest.raises(vx.VxError):
         run(ch.headers, trusted=bytes(32))
     assert run(ch.headers) == ch.expected_outputs(16)
+
+
+def test_gather_proofs_over_rccl_single_rank(ctx, vx):
+    """vx_gather_proofs with a real RCCL communicator (1 rank: what a one-GPU box can run; the N > 1 rank logic is
+    covered by tests/test_shard_gloo.py and bench.py's torch.distributed path).  RCCL comes from the copy PyTorch loads."""
+    import ctypes as C
+
+    import torch  # noqa: F401  (loads librccl)
+
+    rccl = None
+    for name in ("librccl.so.1", "librccl.so", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")):
+        try:
+            rccl = C.CDLL(name)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip("no RCCL library to make a communicator with")
+    uid = (C.c_char * 128)()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+
+    class Uid(C.Structure):
+        _fields_ = [("b", C.c_char * 128)]
+
+    u = Uid()
+    C.memmove(C.byref(u), uid, 128)
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, u, 0) == 0
+    words = np.arange(1, 4097, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    got = ctx.gather_proofs(comm.value, 1, words)
+    assert got.shape == (1, 4096) and (got[0] == words).all()
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
