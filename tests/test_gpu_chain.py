@@ -67,7 +67,10 @@ def test_gather_proofs_over_rccl_single_rank(ctx, vx):
     covered by tests/test_shard_gloo.py and bench.py's torch.distributed path).  RCCL comes from the copy PyTorch loads."""
     import ctypes as C
 
-    import torch  # noqa: F401  (loads librccl)
+    import torch  # loads librccl; RCCL needs the HIP runtime PyTorch ships to be initialised before a communicator is made
+
+    torch.cuda.init()
+    torch.cuda.set_device(0)
 
     rccl = None
     for name in ("librccl.so.1", "librccl.so", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")):
