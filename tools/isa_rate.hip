@@ -134,6 +134,20 @@ __global__ __launch_bounds__(256) void k_perm(uint64_t* out, uint32_t seed) {
     for (int j = 0; j < 12; ++j) x ^= s[j];
     out[blockIdx.x * 256 + threadIdx.x] = x;
 }
+template <class T, class TIn>
+__global__ __launch_bounds__(256) void k_mds_part(uint64_t* out, uint32_t seed) {
+    TIn x[12];
+    for (int j = 0; j < 12; ++j) x[j] = (TIn)((0x9E3779B97F4A7C15ULL * (threadIdx.x + seed + j)) & 0xFFF);
+#pragma unroll 1
+    for (int i = 0; i < PITER * 30; ++i) {
+        T y[12];
+        poseidon_mds_part<T>(x, y);
+        for (int j = 0; j < 12; ++j) x[j] = (TIn)(y[j] & 0xFFF) + (TIn)i;
+    }
+    uint64_t r = 0;
+    for (int j = 0; j < 12; ++j) r ^= (uint64_t)x[j];
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+}
 typedef void (*kern)(uint64_t*, uint32_t);
 int main() {
     uint64_t* d;
@@ -145,7 +159,7 @@ int main() {
     struct { const char* n; kern k; } ks[] = {{"v_mad_u64_u32", k_mad_u64_u32}, {"v_lshl_add_u64", k_lshl_add_u64}, {"v_lshlrev_b64", k_lshlrev_b64},
         {"v_add_u32", k_add_u32}, {"v_add_co_u32", k_add_co_u32}, {"v_addc_co_u32", k_addc_co_u32}, {"v_mul_lo_u32", k_mul_lo_u32},
         {"v_mul_hi_u32", k_mul_hi_u32}, {"v_mul_u32_u24", k_mul_u32_u24}, {"v_mad_u32_u24", k_mad_u32_u24}, {"v_mov_b32", k_mov_b32},
-        {"PERM: cycles per permutation /(ITER*64/PITER)", k_perm}, {"MDS30: cycles per 30 MDS layers /(ITER*64/PITER)", k_mds}, {"gl_mul_nc chain (x8 per modmul)", k_glmul}, {"sbox x^7 chain (x8 per sbox)", k_sbox}, {"gl_add chain (8 adds/iter; per add x8) compiler", k_gladd<0>}, {"gl_add chain e64 selects", k_gladd<1>}, {"v_cndmask_b32", k_cndmask}, {"v_cndmask_b32_e64 sgpr", k_cndmask_e64}, {"v_cndmask_b32_e64 0,-1,vcc", k_cndmask_imm}, {"v_cndmask_b32 fresh dst", k_cndmask_dst}, {"v_subb_co_u32 x,x,vcc (mask)", k_subb_mask}, {"v_sub_co_u32_e64 sgpr", k_sub_co_e64}, {"v_cmp_lt_u32", k_cmp_u32}, {"v_cmp_lt_u64", k_cmp_u64}, {"v_and_or_b32", k_and_or}, {"v_lshl_add_u32", k_lshl_add_u32}, {"v_sub_u32", k_sub_u32}, {"v_and_b32", k_and_b32}, {"v_lshrrev_b32", k_lshrrev_b32}, {"v_mov_b64", k_mov_b64}, {"v_pk_add_u16", k_pk_add_u16}, {"v_xor_b32", k_xor}, {"v_alignbit_b32", k_alignbit}, {"v_add3_u32", k_add3}};
+        {"PERM: cycles per permutation /(ITER*64/PITER)", k_perm}, {"MDSPART64x30 /(ITER*64/PITER)", k_mds_part<int64_t, uint64_t>}, {"MDSPART32x30 /(ITER*64/PITER)", k_mds_part<int32_t, uint32_t>}, {"MDS30: cycles per 30 MDS layers /(ITER*64/PITER)", k_mds}, {"gl_mul_nc chain (x8 per modmul)", k_glmul}, {"sbox x^7 chain (x8 per sbox)", k_sbox}, {"gl_add chain (8 adds/iter; per add x8) compiler", k_gladd<0>}, {"gl_add chain e64 selects", k_gladd<1>}, {"v_cndmask_b32", k_cndmask}, {"v_cndmask_b32_e64 sgpr", k_cndmask_e64}, {"v_cndmask_b32_e64 0,-1,vcc", k_cndmask_imm}, {"v_cndmask_b32 fresh dst", k_cndmask_dst}, {"v_subb_co_u32 x,x,vcc (mask)", k_subb_mask}, {"v_sub_co_u32_e64 sgpr", k_sub_co_e64}, {"v_cmp_lt_u32", k_cmp_u32}, {"v_cmp_lt_u64", k_cmp_u64}, {"v_and_or_b32", k_and_or}, {"v_lshl_add_u32", k_lshl_add_u32}, {"v_sub_u32", k_sub_u32}, {"v_and_b32", k_and_b32}, {"v_lshrrev_b32", k_lshrrev_b32}, {"v_mov_b64", k_mov_b64}, {"v_pk_add_u16", k_pk_add_u16}, {"v_xor_b32", k_xor}, {"v_alignbit_b32", k_alignbit}, {"v_add3_u32", k_add3}};
     printf("{\"clock_hz\": %.0f, \"cus\": %d, \"rates\": {", clk, cus);
     bool first = true;
     for (auto& e : ks) {
