@@ -62,38 +62,48 @@ def test_verify_subchain_rejects_bad_chains(ctx, vx):
     assert run(ch.headers) == ch.expected_outputs(16)
 
 
-def test_gather_proofs_over_rccl_single_rank(ctx, vx):
+GATHER_SCRIPT = r"""
+import ctypes as C, os, sys
+import numpy as np
+import torch                      # first: PyTorch brings the HIP runtime and the RCCL build that belong together
+torch.cuda.init(); torch.cuda.set_device(0)
+sys.path.insert(0, sys.argv[1])
+import vx_import
+vx = vx_import.load()
+ctx = vx.Context(0)
+rccl = None
+for name in ("librccl.so.1", "librccl.so", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")):
+    try:
+        rccl = C.CDLL(name); break
+    except OSError:
+        pass
+if rccl is None:
+    print("NO_RCCL"); sys.exit(0)
+class Uid(C.Structure):
+    _fields_ = [("b", C.c_char * 128)]
+u = Uid()
+assert rccl.ncclGetUniqueId(C.byref(u)) == 0
+comm = C.c_void_p()
+rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
+assert rccl.ncclCommInitRank(C.byref(comm), 1, u, 0) == 0, "ncclCommInitRank"
+words = np.arange(1, 4097, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+got = ctx.gather_proofs(comm.value, 1, words)
+assert got.shape == (1, 4096) and (got[0] == words).all()
+rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+rccl.ncclCommDestroy(comm)
+print("GATHER_OK")
+"""
+
+
+def test_gather_proofs_over_rccl_single_rank(vx):
     """vx_gather_proofs with a real RCCL communicator (1 rank: what a one-GPU box can run; the N > 1 rank logic is
-    covered by tests/test_shard_gloo.py and bench.py's torch.distributed path).  RCCL comes from the copy PyTorch loads."""
-    import ctypes as C
+    covered by tests/test_shard_gloo.py and bench.py's torch.distributed path).  Own process, PyTorch imported first,
+    as bench.py does: RCCL is the copy PyTorch ships and wants the HIP runtime it was built with."""
+    import subprocess
+    import sys
 
-    import torch  # loads librccl; RCCL needs the HIP runtime PyTorch ships to be initialised before a communicator is made
-
-    torch.cuda.init()
-    torch.cuda.set_device(0)
-
-    rccl = None
-    for name in ("librccl.so.1", "librccl.so", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")):
-        try:
-            rccl = C.CDLL(name)
-            break
-        except OSError:
-            continue
-    if rccl is None:
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", GATHER_SCRIPT, root], capture_output=True, text=True, timeout=300)
+    if "NO_RCCL" in r.stdout:
         pytest.skip("no RCCL library to make a communicator with")
-    uid = (C.c_char * 128)()
-    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
-
-    class Uid(C.Structure):
-        _fields_ = [("b", C.c_char * 128)]
-
-    u = Uid()
-    C.memmove(C.byref(u), uid, 128)
-    comm = C.c_void_p()
-    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
-    assert rccl.ncclCommInitRank(C.byref(comm), 1, u, 0) == 0
-    words = np.arange(1, 4097, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
-    got = ctx.gather_proofs(comm.value, 1, words)
-    assert got.shape == (1, 4096) and (got[0] == words).all()
-    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
-    rccl.ncclCommDestroy(comm)
+    assert r.returncode == 0 and "GATHER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
