@@ -10,6 +10,8 @@
 #include <string.h>
 
 #include "air_blake.cuh"
+#include <thread>
+
 #include "vx_internal.h"
 
 
@@ -341,22 +343,48 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
     if (!ctx || !cfg || !proof_len || !out96) return VX_ERR_ARG;
     // 1. statement + public outputs (map/reduce chain rules, Merkle roots)
     VX_TRY(vx_verify_subchain(ctx, headers, stride, sizes, n_fetched, max_headers, trusted_block, trusted_hash, target_block, out96));
-    // 1b. the target header is justified by > 2/3 of the committed authority set (header_range.rs:49-54)
-    if (just)
-        VX_TRY(vx_verify_simple_justification(ctx, target_block, out96, just->authority_set_id, just->authority_set_hash, just->precommit,
-                                              just->pubkeys, just->signatures, just->validator_signed, just->num_authorities,
-                                              just->max_authorities));
+    // 1b. the target header is justified by > 2/3 of the committed authority set (header_range.rs:49-54): checked on
+    //     the side context together with the commitment proof (below), while this context proves the hash chain
     const bool room = proof_out && proof_cap > VX_HR_HDR;
+    // 3. authority-set commitment STARK (compute_authority_set_commitment, justification.rs:127-162): independent of
+    //    the hash-chain proof and small, so it runs on the side context from a host thread while this one proves
+    std::vector<uint64_t> sha_proof;
+    size_t len1 = 0, len2 = 0;
+    int32_t rc_sha = VX_OK;
+    std::thread sha_thread;
+    vx_ctx* side = just ? vx_side_ctx(ctx) : nullptr;
+    auto prove_sha = [&](vx_ctx* c) -> int32_t {
+        (void)hipSetDevice(c->device);
+        int32_t rj = vx_verify_simple_justification(c, target_block, out96, just->authority_set_id, just->authority_set_hash, just->precommit,
+                                                    just->pubkeys, just->signatures, just->validator_signed, just->num_authorities,
+                                                    just->max_authorities);
+        if (rj != VX_OK) return rj;
+        const int sl = sha_log_n(just->num_authorities);
+        size_t bound = 0;
+        int32_t r = vx_stark_proof_bound(VX_AIR_SHA_CHAIN, cfg, sl, &bound);
+        if (r != VX_OK) return r;
+        sha_proof.resize(bound);
+        vx_buf* st = nullptr;
+        r = vx_alloc(c, ((size_t)VX_SHA_AIR_COLS) << sl, &st);
+        if (r != VX_OK) return r;
+        uint64_t spub[8];
+        uint8_t com[32];
+        r = vx_sha_chain_trace(c, just->pubkeys, just->num_authorities, sl, st, spub, com);
+        if (r == VX_OK && memcmp(com, just->authority_set_hash, 32) != 0) r = vx_fail(c, VX_ERR_STATEMENT, "header_range: authority-set commitment mismatch");
+        if (r == VX_OK) r = vx_stark_prove_impl(c, VX_AIR_SHA_CHAIN, cfg, st->d, st->n, /*consume_trace=*/1, sl, spub, 8, sha_proof.data(), sha_proof.size(), &len2);
+        (void)vx_free(c, st);
+        return r;
+    };
+    if (side) sha_thread = std::thread([&] { rc_sha = prove_sha(side); });
     // 2. Blake2b parent-hash-chain STARK over every compression of every header
     size_t chunks = 0;
     for (size_t i = 0; i < n_fetched; ++i) chunks += (sizes[i] + 127) / 128;
     int log_n = 4;
     while (((size_t)1 << log_n) < 16 * chunks) ++log_n;
     vx_buf* trace = nullptr;
-    VX_TRY(vx_alloc(ctx, ((size_t)blk::COLS) << log_n, &trace));
+    int32_t rc = vx_alloc(ctx, ((size_t)blk::COLS) << log_n, &trace);
     uint64_t pub[18];
-    int32_t rc = vx_blake_chain_trace(ctx, headers, stride, sizes, n_fetched, trusted_hash, trusted_block + 1, log_n, trace, pub, nullptr);
-    size_t len1 = 0, len2 = 0;
+    if (rc == VX_OK) rc = vx_blake_chain_trace(ctx, headers, stride, sizes, n_fetched, trusted_hash, trusted_block + 1, log_n, trace, pub, nullptr);
     if (rc == VX_OK) {
         uint8_t tgt[32];
         for (int j = 0; j < 8; ++j) {
@@ -367,24 +395,16 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
     }
     if (rc == VX_OK)
         rc = vx_stark_prove_impl(ctx, VX_AIR_BLAKE_CHAIN, cfg, trace->d, trace->n, /*consume_trace=*/1, log_n, pub, 18, room ? proof_out + VX_HR_HDR : nullptr, room ? proof_cap - VX_HR_HDR : 0, &len1);
-    (void)vx_free(ctx, trace);
-    // 3. authority-set commitment STARK (compute_authority_set_commitment, justification.rs:127-162)
-    if ((rc == VX_OK || rc == VX_ERR_BUFSZ) && just) {
-        const int32_t rc1 = rc;
-        const int sl = sha_log_n(just->num_authorities);
-        vx_buf* st = nullptr;
-        VX_TRY(vx_alloc(ctx, ((size_t)VX_SHA_AIR_COLS) << sl, &st));
-        uint64_t spub[8];
-        uint8_t com[32];
-        rc = vx_sha_chain_trace(ctx, just->pubkeys, just->num_authorities, sl, st, spub, com);
-        if (rc == VX_OK && memcmp(com, just->authority_set_hash, 32) != 0) rc = vx_fail(ctx, VX_ERR_STATEMENT, "header_range: authority-set commitment mismatch");
+    if (trace) (void)vx_free(ctx, trace);
+    if (sha_thread.joinable()) sha_thread.join();
+    else if (just) rc_sha = prove_sha(ctx);  // no side context: one after the other
+    if (just) {
+        if (rc_sha != VX_OK && side) (void)vx_fail(ctx, rc_sha, "%s", vx_last_error(side));
+        if ((rc == VX_OK || rc == VX_ERR_BUFSZ) && rc_sha != VX_OK) rc = rc_sha;
         if (rc == VX_OK) {
-            const size_t off = VX_HR_HDR + len1;
-            const bool room2 = rc1 == VX_OK && proof_out && proof_cap > off;
-            rc = vx_stark_prove_impl(ctx, VX_AIR_SHA_CHAIN, cfg, st->d, st->n, /*consume_trace=*/1, sl, spub, 8, room2 ? proof_out + off : nullptr, room2 ? proof_cap - off : 0, &len2);
-            if (rc == VX_OK && rc1 != VX_OK) rc = rc1;
+            if (proof_out && proof_cap >= VX_HR_HDR + len1 + len2) memcpy(proof_out + VX_HR_HDR + len1, sha_proof.data(), len2 * 8);
+            else rc = vx_fail(ctx, VX_ERR_BUFSZ, "header_range: proof needs %zu words, buffer has %zu", VX_HR_HDR + len1 + len2, proof_cap);
         }
-        (void)vx_free(ctx, st);
     }
     *proof_len = VX_HR_HDR + len1 + len2;
     if (rc != VX_OK) return rc;

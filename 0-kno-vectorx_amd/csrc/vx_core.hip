@@ -178,6 +178,10 @@ int32_t vx_ctx_create(int device, vx_ctx** out) {
 
 int32_t vx_ctx_destroy(vx_ctx* ctx) {
     if (!ctx) return VX_ERR_ARG;
+    if (ctx->side) {
+        vx_ctx_destroy(ctx->side);
+        ctx->side = nullptr;
+    }
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->shift_tabs) hipFree(kv.second.d);
@@ -353,4 +357,9 @@ int32_t vx_gather_proofs(vx_ctx* ctx, void* nccl_comm, int world, const uint64_t
     VX_HIP(hipStreamSynchronize(ctx->stream));
     return VX_OK;
 }
+}
+
+vx_ctx* vx_side_ctx(vx_ctx* ctx) {
+    if (!ctx->side && vx_ctx_create(ctx->device, &ctx->side) != VX_OK) ctx->side = nullptr;
+    return ctx->side;
 }

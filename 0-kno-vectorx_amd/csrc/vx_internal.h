@@ -65,7 +65,11 @@ struct vx_ctx {
     // All work is on ctx->stream, so a recycled block is safe to hand out again immediately.
     std::map<size_t, std::vector<void*>> pool_free;
     std::map<void*, size_t> pool_live;
+    // a second context on the same device (own stream, scratch and pool), made on first use: independent small proofs
+    // (the authority-set commitment STARKs) run on it from a host thread while this context proves the hash chain
+    vx_ctx* side = nullptr;
 };
+vx_ctx* vx_side_ctx(vx_ctx* ctx);  // nullptr if it cannot be created
 void* vx_pool_alloc(vx_ctx* ctx, size_t bytes);
 void vx_pool_free(vx_ctx* ctx, void* p);
 void vx_pool_trim(vx_ctx* ctx);

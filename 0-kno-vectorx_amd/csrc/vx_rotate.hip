@@ -5,6 +5,7 @@
 // (second SHA-256 chain STARK) and returned as the 32 output bytes.
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "vx_internal.h"
@@ -133,6 +134,38 @@ int32_t vx_rotate_prove(vx_ctx* ctx, const vx_buf* header, uint32_t header_size,
     if (header_size > MAX_HEADER_SIZE)  // input/mod.rs:851-856
         return vx_fail(ctx, VX_ERR_STATEMENT, "rotate: header size %u is greater than MAX_HEADER_SIZE %u", header_size, MAX_HEADER_SIZE);
     VX_CHECK(header_size >= 36, "rotate: header of %u bytes cannot hold a parent hash and a block number", header_size);
+    // 0. commitment of the CURRENT set (binds the EVM input hash): independent of everything below, so it is proven on
+    //    the side context from a host thread meanwhile
+    std::vector<uint64_t> cur_proof;
+    size_t cur_len = 0;
+    int32_t rc_cur = VX_OK;
+    uint8_t commit[2][32];
+    auto prove_set = [&](vx_ctx* c, const uint8_t* keys, size_t nk, uint8_t com[32], uint64_t* dst, size_t cap, size_t* len) -> int32_t {
+        (void)hipSetDevice(c->device);
+        const int sl = sha_rows_log(nk);
+        vx_buf* st = nullptr;
+        int32_t r = vx_alloc(c, ((size_t)VX_SHA_AIR_COLS) << sl, &st);
+        if (r != VX_OK) return r;
+        uint64_t spub[8];
+        r = vx_sha_chain_trace(c, keys, nk, sl, st, spub, com);
+        if (r == VX_OK) r = vx_stark_prove_impl(c, VX_AIR_SHA_CHAIN, cfg, st->d, st->n, 1, sl, spub, 8, dst, cap, len);
+        (void)vx_free(c, st);
+        return r;
+    };
+    {
+        size_t bound = 0;
+        VX_TRY(vx_stark_proof_bound(VX_AIR_SHA_CHAIN, cfg, sha_rows_log(just->num_authorities ? just->num_authorities : 1), &bound));
+        cur_proof.resize(bound);
+    }
+    vx_ctx* side = just->num_authorities ? vx_side_ctx(ctx) : nullptr;
+    std::thread cur_thread;
+    if (side) cur_thread = std::thread([&] { rc_cur = prove_set(side, just->pubkeys, just->num_authorities, commit[0], cur_proof.data(), cur_proof.size(), &cur_len); });
+    struct Joiner {  // every exit path waits for the thread
+        std::thread& t;
+        ~Joiner() {
+            if (t.joinable()) t.join();
+        }
+    } joiner{cur_thread};
     // 1. header hash = Blake2b-256 of the first header_size bytes (rotate.rs:293); the trace of its compressions
     //    is the witness of the hash STARK (one-header chain anchored at the header's own parent hash)
     uint8_t head[40], header_hash[32];
@@ -171,26 +204,23 @@ int32_t vx_rotate_prove(vx_ctx* ctx, const vx_buf* header, uint32_t header_size,
         if (rc == VX_ERR_BUFSZ) rc_room = rc, rc = VX_OK;
     }
     (void)vx_free(ctx, trace);
-    // 4. commitments of the current set (binds the EVM input hash) and of the new set (the output, rotate.rs:317-320)
-    uint8_t commit[2][32];
-    for (int k = 0; k < 2 && rc == VX_OK; ++k) {
-        const uint8_t* keys = k == 0 ? just->pubkeys : new_pubkeys;
-        const size_t nk = k == 0 ? just->num_authorities : num_authorities;
-        const int sl = sha_rows_log(nk);
-        vx_buf* st = nullptr;
-        rc = vx_alloc(ctx, ((size_t)VX_SHA_AIR_COLS) << sl, &st);
-        if (rc != VX_OK) break;
-        uint64_t spub[8];
-        rc = vx_sha_chain_trace(ctx, keys, nk, sl, st, spub, commit[k]);
-        if (rc == VX_OK && k == 0 && memcmp(commit[0], just->authority_set_hash, 32) != 0)
-            rc = vx_fail(ctx, VX_ERR_STATEMENT, "rotate: authority-set commitment mismatch");
-        if (rc == VX_OK) {
-            const size_t off = VX_ROT_HDR + len[0] + (k ? len[1] : 0);
-            rc = vx_stark_prove_impl(ctx, VX_AIR_SHA_CHAIN, cfg, st->d, st->n, 1, sl, spub, 8, room(off) ? proof_out + off : nullptr,
-                                     room(off) ? proof_cap - off : 0, &len[1 + k]);
-            if (rc == VX_ERR_BUFSZ) rc_room = rc, rc = VX_OK;
-        }
-        (void)vx_free(ctx, st);
+    // 4. commitment of the new set (the output, rotate.rs:317-320) on this context; then collect the current set's
+    std::vector<uint64_t> new_proof;
+    if (rc == VX_OK) {
+        size_t bound = 0;
+        rc = vx_stark_proof_bound(VX_AIR_SHA_CHAIN, cfg, sha_rows_log(num_authorities), &bound);
+        new_proof.resize(bound);
+        if (rc == VX_OK) rc = prove_set(ctx, new_pubkeys, num_authorities, commit[1], new_proof.data(), new_proof.size(), &len[2]);
+    }
+    if (cur_thread.joinable()) cur_thread.join();
+    else if (rc == VX_OK && just->num_authorities)
+        rc_cur = prove_set(ctx, just->pubkeys, just->num_authorities, commit[0], cur_proof.data(), cur_proof.size(), &cur_len);
+    if (rc == VX_OK && rc_cur != VX_OK) rc = side ? vx_fail(ctx, rc_cur, "%s", vx_last_error(side)) : rc_cur;
+    if (rc == VX_OK && memcmp(commit[0], just->authority_set_hash, 32) != 0) rc = vx_fail(ctx, VX_ERR_STATEMENT, "rotate: authority-set commitment mismatch");
+    len[1] = cur_len;
+    if (rc == VX_OK && rc_room == VX_OK && proof_out && proof_cap >= VX_ROT_HDR + len[0] + len[1] + len[2]) {
+        memcpy(proof_out + VX_ROT_HDR + len[0], cur_proof.data(), len[1] * 8);
+        memcpy(proof_out + VX_ROT_HDR + len[0] + len[1], new_proof.data(), len[2] * 8);
     }
     if (rc != VX_OK) return rc;
     *proof_len = VX_ROT_HDR + len[0] + len[1] + len[2];
