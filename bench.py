@@ -8,7 +8,9 @@ resident in HBM (a 256-header P15k chain + its STARK trace): see `config.stages`
 line for exactly which stages are inside the timed region -- `config.complete_proof` says
 whether they add up to a full proof yet.  Independent inputs shard one per rank (weak
 scaling, no data-path collective); the only collective is the final RCCL gather of the
-fixed-size result blobs, outside the per-step work but inside the timed region.
+fixed-size result blobs, outside the per-step work but inside the timed region.  By default two
+proofs are in flight per GPU (`--inflight`): K steps are K complete proofs, handed to two worker
+contexts from one queue, so one proof's small-kernel tail overlaps another's bulk kernels.
 
 The JSON line carries `roofline` (NTT kernel: algorithmic bytes 16*n*c per transform over
 its HIP-event time on the ctx stream) and `cpu_baseline` (the C oracle, kind "port", timed on
@@ -163,6 +165,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headers", type=int, default=256, choices=(256, 512),
                     help="256 = BASELINE.json configs[1] (the headline metric, default); 512 = configs[2]/[5]")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="proofs in flight per GPU (contexts + host threads; steps are handed out from one queue). Default: 2 "
+                         "(header_range_256, rotate), 1 for --headers 512 (two 2^20-row proofs would not fit 288 GB)")
     ap.add_argument("--circuit", default="header_range", choices=("header_range", "rotate"),
                     help="header_range = the headline metric (default); rotate = BASELINE.json configs[3]")
     args = ap.parse_args()
@@ -180,23 +185,56 @@ def main():
         dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist = dist_mod
     vx = vx_import.load()
-    ctx = vx.Context(local_rank)
-    wl = (RotateWorkload if args.circuit == "rotate" else Workload)(vx, ctx, seed_offset=rank)
+    inflight = args.inflight or (1 if (args.circuit == "header_range" and N_HEADERS == 512) else 2)
+    inflight = max(1, min(inflight, args.steps))
+    # `inflight` proofs are proven concurrently on this GPU: each worker thread owns a context (stream, pool) and an
+    # input resident in HBM and takes the next step from a shared counter, so the tail of one proof (FRI layers, host
+    # transcript, queries -- small kernels and syncs) overlaps the bulk kernels of another.  K steps are still K proofs.
+    import threading
+
+    ctxs = [vx.Context(local_rank) for _ in range(inflight)]
+    ctx = ctxs[0]
+    wls = [(RotateWorkload if args.circuit == "rotate" else Workload)(vx, c, seed_offset=rank) for c in ctxs]
+    wl = wls[0]
 
     def barrier():
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         if dist:
             import torch
 
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        res = wl.step()
+    def run_steps(n_steps):
+        lock, nxt, last, errs = threading.Lock(), [0], [None] * inflight, []
+
+        def worker(i):
+            try:
+                while True:
+                    with lock:
+                        if nxt[0] >= n_steps:
+                            return
+                        nxt[0] += 1
+                    last[i] = wls[i].step()
+            except BaseException as e:  # noqa: BLE001 -- re-raised on the main thread
+                errs.append(e)
+
+        ths = [threading.Thread(target=worker, args=(i,)) for i in range(inflight)]
+        for t_ in ths:
+            t_.start()
+        for t_ in ths:
+            t_.join()
+        if errs:
+            raise errs[0]
+        return next(r for r in last if r is not None)
+
+    for w in wls:  # W warmup steps on every context (pool, tables)
+        for _ in range(args.warmup):
+            w.step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = wl.step()
+    res = run_steps(args.steps)
     blob = wl.blob(res)
     # the one collective: fixed-size result blobs to rank 0 over RCCL/xGMI
     gathered = vx.shard.gather_blobs(blob, dist, device="cuda" if dist else None)
@@ -217,7 +255,7 @@ def main():
             "metric": f"header_range_{N_HEADERS} proofs/sec", "value": round(world * args.steps / elapsed, 4), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks) / u8 (hashes)",
-            "data": "synthetic",
+            "data": "synthetic", "inflight_per_gpu": inflight,
             "config": {
                 "workload": f"header_range_{N_HEADERS}: {N_HEADERS} x 15,360-B synthetic Avail headers (P15k), 300 authorities, one input per GPU; "
                             f"{120 * N_HEADERS:,} Blake2b compressions -> BlakeChainAir trace 2^{19 if N_HEADERS == 256 else 20} rows x {BLAKE_COLS} columns",
@@ -249,7 +287,8 @@ def main():
         elif not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline(vx)
         print(json.dumps(line), flush=True)
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if dist:
         dist.destroy_process_group()
 
