@@ -375,7 +375,13 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
         (void)vx_free(c, st);
         return r;
     };
-    if (side) sha_thread = std::thread([&] { rc_sha = prove_sha(side); });
+    if (side) {
+        try {
+            sha_thread = std::thread([&] { rc_sha = prove_sha(side); });
+        } catch (...) {  // no thread to be had: prove one after the other below
+            side = nullptr;
+        }
+    }
     // 2. Blake2b parent-hash-chain STARK over every compression of every header
     size_t chunks = 0;
     for (size_t i = 0; i < n_fetched; ++i) chunks += (sizes[i] + 127) / 128;

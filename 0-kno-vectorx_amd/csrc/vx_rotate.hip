@@ -159,7 +159,13 @@ int32_t vx_rotate_prove(vx_ctx* ctx, const vx_buf* header, uint32_t header_size,
     }
     vx_ctx* side = just->num_authorities ? vx_side_ctx(ctx) : nullptr;
     std::thread cur_thread;
-    if (side) cur_thread = std::thread([&] { rc_cur = prove_set(side, just->pubkeys, just->num_authorities, commit[0], cur_proof.data(), cur_proof.size(), &cur_len); });
+    if (side) {
+        try {
+            cur_thread = std::thread([&] { rc_cur = prove_set(side, just->pubkeys, just->num_authorities, commit[0], cur_proof.data(), cur_proof.size(), &cur_len); });
+        } catch (...) {  // no thread to be had: proven on this context further down
+            side = nullptr;
+        }
+    }
     struct Joiner {  // every exit path waits for the thread
         std::thread& t;
         ~Joiner() {
