@@ -86,6 +86,8 @@ __device__ __forceinline__ void poseidon_mds_part(const TIn* x, T* y) {
 // that; poseidon_permute canonicalises once at the end.  (v_mad_u64_u32 issues at the rate of any other VOP3
 // instruction on gfx950 and plain 32-bit add/sub/shift at almost twice that rate, tools/isa_rate.hip: the
 // 52/12 split puts half of the layer on the cheap instructions and needs no zero-extension moves.)
+// (Tried: a 55/9 split with the high part as packed 16-bit dot products, v_dot2_u32_u16, 84 instructions instead of
+// ~140: the permutation went from 66.3 k to 70.6 k cycles -- the dot instructions do not issue at full rate.)
 // RC: 0 = no constants, 1 = the next round's constant for element 0 only (a partial round follows), 12 = all twelve
 template <int RC>
 __device__ __forceinline__ void poseidon_mds(uint64_t* s, int rc_next) {
