@@ -159,3 +159,54 @@ __device__ __forceinline__ void poseidon_permute(uint64_t* s) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = gl_canon(s[i]);
 }
+
+// ---- cooperative permutation: one state element per lane, 16-lane groups (lanes 12..15 idle) -------------------
+// For small trees (few leaves, upper Merkle levels, FRI tails) the one-lane-per-permutation kernels leave the chip
+// empty and each permutation is a 15 k-instruction dependency chain (47 us for a lone wave).  Here the twelve
+// s-boxes of a full round run in twelve lanes and the MDS row of lane r is a dot product over the group's state,
+// exchanged through LDS: a shorter chain per permutation.  `g` = the group's 12 LDS slots.  A group never spans two
+// waves and LDS operations of one wave execute in order, so the exchange needs no block barrier -- only that the
+// compiler keeps the write before the reads and the reads before the next write (wave-scope fences).
+__device__ __forceinline__ uint64_t poseidon_mds_coop(uint64_t s, int l, uint64_t* g) {
+    constexpr uint32_t C[12] = VX_POSEIDON_MDS_CIRC_INIT;
+    if (l < 12) g[l] = s;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint64_t al = 0, ah = 0;  // sum C_i lo32(x_i), sum C_i hi32(x_i): both < 2^41
+    const int r = l < 12 ? l : 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        int j = r + i;
+        if (j >= 12) j -= 12;
+        const uint64_t x = g[j];
+        al += (uint64_t)(uint32_t)x * C[i];
+        ah += (x >> 32) * C[i];
+    }
+    if (l == 0) {
+        const uint64_t x0 = g[0];
+        al += (uint64_t)(uint32_t)x0 * VX_POSEIDON_MDS_DIAG0;
+        ah += (x0 >> 32) * VX_POSEIDON_MDS_DIAG0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // all reads issued before the next layer overwrites the slots
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // y = al + ah 2^32 = al + hi32(ah) 2^64 + lo32(ah) 2^32, 2^64 = eps
+    const uint64_t w = (ah >> 32) * GL_EPS + al;  // < 2^42
+    uint32_t yhi;
+    const bool carry = __builtin_add_overflow((uint32_t)(w >> 32), (uint32_t)ah, &yhi);
+    const uint64_t y = ((uint64_t)yhi << 32) | (uint32_t)w;
+    return y + (carry ? (uint64_t)GL_EPS : 0);
+}
+// s = this lane's state element (l < 12); returns the permuted element, canonical
+__device__ __forceinline__ uint64_t poseidon_permute_coop(uint64_t s, int l, uint64_t* g) {
+    const int lc = l < 12 ? l : 0;
+#pragma unroll 1
+    for (int r = 0; r < 30; ++r) {
+        s = gl_add_nc(s, POSEIDON_RC[12 * r + lc]);  // folded table: partial rounds carry a constant for element 0 only
+        const bool full = r < 4 || r >= 26;
+        if (full || l == 0) s = poseidon_sbox(s);
+        s = poseidon_mds_coop(s, l, g);
+    }
+    return gl_canon(s);
+}

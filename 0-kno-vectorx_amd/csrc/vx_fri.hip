@@ -98,17 +98,6 @@ __global__ __launch_bounds__(256) void k_fri_leaf_hash(const uint64_t* evals, in
     d[2] = s[2];
     d[3] = s[3];
 }
-__global__ __launch_bounds__(256) void k_merkle_level2(const uint64_t* child, uint64_t* parent, size_t n_parent) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= n_parent) return;
-    uint64_t s[12];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s[k] = child[8 * i + k];
-    s[8] = s[9] = s[10] = s[11] = 0;
-    poseidon_permute(s);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) parent[4 * i + k] = s[k];
-}
 // gather the leaves (arity ext values, flattened) of n_idx leaf indices
 __global__ void k_fri_gather_leaves(const uint64_t* evals, int log_n, int arity_bits, const uint64_t* idx, size_t n_idx,
                                     uint64_t* out) {
@@ -216,15 +205,7 @@ int32_t vx_fri_layer_tree_dev(vx_ctx* ctx, const uint64_t* evals_d, int log_n, i
     case 4: hipLaunchKernelGGL(k_fri_leaf_hash<4>, g, b, 0, ctx->stream, evals_d, log_n, t->levels); break;
     default: hipLaunchKernelGGL(k_fri_leaf_hash<5>, g, b, 0, ctx->stream, evals_d, log_n, t->levels); break;
     }
-    size_t off = 0;
-    cur = M;
-    while (cur > cap) {
-        size_t np = cur >> 1;
-        hipLaunchKernelGGL(k_merkle_level2, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, t->levels + off,
-                           t->levels + off + 4 * cur, np);
-        off += 4 * cur;
-        cur = np;
-    }
+    vx_merkle_levels_launch(ctx, t->levels, M, cap);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
         vx_pool_free(ctx, t->levels);

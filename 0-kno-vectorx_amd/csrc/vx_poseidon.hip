@@ -53,6 +53,41 @@ __global__ __launch_bounds__(256) void k_hash_leaves(const uint64_t* data, size_
     d[3] = s[3];
 }
 
+// Small trees: 16 lanes per leaf (cooperative permutation, poseidon.cuh); block = 16 leaves.
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void k_hash_leaves_coop(const uint64_t* data, size_t n_leaves, int log_n, size_t leaf_len,
+                                                          uint64_t* digests) {
+    __shared__ uint64_t lds[16 * 12];
+    const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    uint64_t* g = lds + 12 * grp;
+    const size_t t = blockIdx.x * (size_t)16 + grp;
+    const size_t p = t < n_leaves ? t : n_leaves - 1;  // surplus groups redo the last leaf and do not write
+    const size_t estride = LAYOUT == VX_LEAVES_ROW_MAJOR ? 1 : n_leaves;
+    const uint64_t* src = LAYOUT == VX_LEAVES_ROW_MAJOR ? data + p * leaf_len : data + p;
+    const size_t j = LAYOUT == VX_LEAVES_COLS_BITREV ? brev32((uint32_t)p, log_n) : p;
+    uint64_t s = 0;
+    if (leaf_len <= 4) {
+        if ((size_t)l < leaf_len) s = src[(size_t)l * estride];
+    } else {
+        for (size_t e = 0; e < leaf_len; e += 8) {
+            if (l < 8 && e + l < leaf_len) s = src[(e + l) * estride];
+            s = poseidon_permute_coop(s, l, g);
+        }
+    }
+    if (l < 4 && t < n_leaves) digests[4 * j + l] = s;
+}
+// parent[i] = compress(child[2i], child[2i+1]), 16 lanes per parent
+__global__ __launch_bounds__(256) void k_merkle_level_coop(const uint64_t* child, uint64_t* parent, size_t n_parent) {
+    __shared__ uint64_t lds[16 * 12];
+    const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const size_t t = blockIdx.x * (size_t)16 + grp;
+    const size_t i = t < n_parent ? t : n_parent - 1;
+    uint64_t s = l < 8 ? child[8 * i + l] : 0;
+    s = poseidon_permute_coop(s, l, lds + 12 * grp);
+    if (l < 4 && t < n_parent) parent[4 * i + l] = s;
+}
+constexpr size_t COOP_MAX_LEAVES = 16384;  // below this the one-lane kernels cannot fill the chip (1024 SIMDs x 64 lanes)
+
 // parent[i] = compress(child[2i], child[2i+1])
 __global__ __launch_bounds__(256) void k_merkle_level(const uint64_t* child, uint64_t* parent, size_t n_parent) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -83,6 +118,20 @@ __global__ void k_gather_siblings(const uint64_t* levels, size_t n_leaves, int d
     for (int e = 0; e < 4; ++e) out[4 * t + e] = levels[off + 4 * node + e];
 }
 
+// levels above the leaf digests, down to `cap` nodes (levels = digests of level 0 followed by each parent level)
+void vx_merkle_levels_launch(vx_ctx* ctx, uint64_t* levels, size_t n_leaves, size_t cap) {
+    size_t off = 0, cur = n_leaves;
+    while (cur > cap) {
+        const size_t np = cur >> 1;
+        if (np <= COOP_MAX_LEAVES)
+            hipLaunchKernelGGL(k_merkle_level_coop, dim3((unsigned)((np + 15) / 16)), dim3(256), 0, ctx->stream, levels + off, levels + off + 4 * cur, np);
+        else
+            hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, levels + off, levels + off + 4 * cur, np);
+        off += 4 * cur;
+        cur = np;
+    }
+}
+
 int32_t vx_merkle_build_dev(vx_ctx* ctx, const uint64_t* data, size_t n_leaves, size_t leaf_len, int layout,
                             int cap_height, vx_tree** out) {
     int log_n = 0;
@@ -103,21 +152,21 @@ int32_t vx_merkle_build_dev(vx_ctx* ctx, const uint64_t* data, size_t n_leaves, 
         return vx_fail(ctx, VX_ERR_OOM, "merkle: cannot allocate %zu bytes", total * 8);
     }
     unsigned g = (unsigned)((n_leaves + 255) / 256);
-    if (layout == VX_LEAVES_ROW_MAJOR)
+    if (n_leaves <= COOP_MAX_LEAVES && leaf_len > 4) {
+        const unsigned gc = (unsigned)((n_leaves + 15) / 16);
+        if (layout == VX_LEAVES_ROW_MAJOR)
+            hipLaunchKernelGGL(k_hash_leaves_coop<VX_LEAVES_ROW_MAJOR>, dim3(gc), dim3(256), 0, ctx->stream, data, n_leaves, log_n, leaf_len, t->levels);
+        else if (layout == VX_LEAVES_COLS_BITREV)
+            hipLaunchKernelGGL(k_hash_leaves_coop<VX_LEAVES_COLS_BITREV>, dim3(gc), dim3(256), 0, ctx->stream, data, n_leaves, log_n, leaf_len, t->levels);
+        else
+            hipLaunchKernelGGL(k_hash_leaves_coop<VX_LEAVES_COLS>, dim3(gc), dim3(256), 0, ctx->stream, data, n_leaves, log_n, leaf_len, t->levels);
+    } else if (layout == VX_LEAVES_ROW_MAJOR)
         hipLaunchKernelGGL(k_hash_leaves<VX_LEAVES_ROW_MAJOR>, dim3(g), dim3(256), 0, ctx->stream, data, n_leaves, log_n, leaf_len, t->levels);
     else if (layout == VX_LEAVES_COLS_BITREV)
         hipLaunchKernelGGL(k_hash_leaves<VX_LEAVES_COLS_BITREV>, dim3(g), dim3(256), 0, ctx->stream, data, n_leaves, log_n, leaf_len, t->levels);
     else
         hipLaunchKernelGGL(k_hash_leaves<VX_LEAVES_COLS>, dim3(g), dim3(256), 0, ctx->stream, data, n_leaves, log_n, leaf_len, t->levels);
-    size_t off = 0;
-    cur = n_leaves;
-    while (cur > cap) {
-        size_t np = cur >> 1;
-        hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, t->levels + off,
-                           t->levels + off + 4 * cur, np);
-        off += 4 * cur;
-        cur = np;
-    }
+    vx_merkle_levels_launch(ctx, t->levels, n_leaves, cap);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
         vx_pool_free(ctx, t->levels);
