@@ -166,8 +166,7 @@ def main():
     ap.add_argument("--headers", type=int, default=256, choices=(256, 512),
                     help="256 = BASELINE.json configs[1] (the headline metric, default); 512 = configs[2]/[5]")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="proofs in flight per GPU (contexts + host threads; steps are handed out from one queue). Default: 2 "
-                         "(header_range_256, rotate), 1 for --headers 512 (two 2^20-row proofs would not fit 288 GB)")
+                    help="proofs in flight per GPU (contexts + host threads; steps are handed out from one queue). Default: 2")
     ap.add_argument("--circuit", default="header_range", choices=("header_range", "rotate"),
                     help="header_range = the headline metric (default); rotate = BASELINE.json configs[3]")
     args = ap.parse_args()
@@ -185,7 +184,7 @@ def main():
         dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist = dist_mod
     vx = vx_import.load()
-    inflight = args.inflight or (1 if (args.circuit == "header_range" and N_HEADERS == 512) else 2)
+    inflight = args.inflight or 2  # two 2^20-row proofs (--headers 512) take 2 x 111 GB of the 288 GB: measured to fit
     inflight = max(1, min(inflight, args.steps))
     # `inflight` proofs are proven concurrently on this GPU: each worker thread owns a context (stream, pool) and an
     # input resident in HBM and takes the next step from a shared counter, so the tail of one proof (FRI layers, host
