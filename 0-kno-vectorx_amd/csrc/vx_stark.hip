@@ -413,6 +413,10 @@ static std::vector<int> fri_arity_plan(int degree_bits, const vx_stark_config& c
     return r;
 }
 
+struct DevMem;
+static int32_t quotient_eval_dev(vx_ctx* ctx, const AirDesc* air, int L, int r, const uint64_t* trace_lde, const uint64_t alphas[2],
+                                 const uint64_t* public_inputs, size_t n_public, uint64_t* qv, DevMem& mem);
+
 extern "C" {
 
 int32_t vx_stark_default_config(vx_stark_config* cfg) {
@@ -443,6 +447,20 @@ int32_t vx_stark_proof_bound(int air_id, const vx_stark_config* cfg, int log_n, 
     return VX_OK;
 }
 
+int32_t vx_quotient_eval(vx_ctx* ctx, int air_id, int rate_bits, const vx_buf* trace_lde, int log_n, const uint64_t alphas[2],
+                         const uint64_t* public_inputs, size_t n_public, vx_buf* out) {
+    if (!ctx || !trace_lde || !alphas || !out) return VX_ERR_ARG;
+    const AirDesc* air = find_air(air_id);
+    VX_CHECK(air, "quotient eval: unknown AIR id %d", air_id);
+    VX_CHECK(rate_bits >= 1 && rate_bits <= 3 && log_n >= 2 && log_n >= air->period_log && log_n + rate_bits <= 27, "quotient eval: bad log_n %d / rate_bits %d", log_n, rate_bits);
+    VX_CHECK((int)n_public == air->pub && (n_public == 0 || public_inputs), "quotient eval: AIR %d takes %d public inputs", air_id, air->pub);
+    const size_t N = (size_t)1 << (log_n + rate_bits);
+    VX_CHECK(trace_lde->n >= N * (size_t)air->cols && out->n >= 2 * N, "quotient eval: buffers too small");
+    VX_CHECK(alphas[0] < glh::P && alphas[1] < glh::P, "quotient eval: non-canonical challenge");
+    DevMem mem{ctx};
+    return quotient_eval_dev(ctx, air, log_n, rate_bits, trace_lde->d, alphas, public_inputs, n_public, out->d, mem);
+}
+
 int32_t vx_stark_prove(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_in, const vx_buf* trace, int log_n,
                        const uint64_t* public_inputs, size_t n_public, uint64_t* proof_out, size_t proof_cap,
                        size_t* proof_len) {
@@ -450,6 +468,67 @@ int32_t vx_stark_prove(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_in, c
     return vx_stark_prove_impl(ctx, air_id, cfg_in, trace->d, trace->n, 0, log_n, public_inputs, n_public, proof_out, proof_cap, proof_len);
 }
 }  // extern "C"
+
+// compute_quotient_polys on the size-N coset g<w_N>: qv[k*N + i] = (sum_j alpha_k^(K-1-j) c_j(x_i)) / Z_H(x_i), k = 0, 1
+static int32_t quotient_eval_dev(vx_ctx* ctx, const AirDesc* air, int L, int r, const uint64_t* trace_lde, const uint64_t alphas[2],
+                                 const uint64_t* public_inputs, size_t n_public, uint64_t* qv, DevMem& mem) {
+    const int LN = L + r;
+    const size_t n = (size_t)1 << L;
+    const uint64_t g = 7;
+    uint64_t* d_pub = mem.alloc(n_public ? n_public : 1);
+    VX_CHECK(d_pub, "stark prove: out of device memory (quotient)");
+    if (n_public) VX_HIP(hipMemcpyAsync(d_pub, public_inputs, n_public * 8, hipMemcpyHostToDevice, ctx->stream));
+    uint64_t* d_per = nullptr;
+    if (air->periodic) {
+        std::vector<uint64_t> pv, tab;
+        air->periodic_values(pv);
+        const size_t p = (size_t)1 << air->period_log, m = p << r;
+        tab.resize(air->periodic * m);
+        const uint64_t shift_pow = glh::pow(g, n >> air->period_log);
+        for (int j = 0; j < air->periodic; ++j) periodic_on_coset(pv.data() + j * p, air->period_log, r, shift_pow, tab.data() + j * m);
+        d_per = mem.alloc(tab.size());
+        VX_CHECK(d_per, "stark prove: out of device memory (periodic)");
+        VX_HIP(hipMemcpyAsync(d_per, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        VX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    {
+        QuotArgs qa{};
+        qa.lde = trace_lde;
+        qa.q_out = qv;
+        qa.log_N = LN;
+        qa.rate_bits = r;
+        qa.shift = g;
+        qa.last = glh::inv(glh::root(L));
+        qa.n_inv = glh::inv(n % glh::P);
+        qa.alpha[0] = alphas[0];
+        qa.alpha[1] = alphas[1];
+        const uint64_t gn = glh::pow(g, n), wr = glh::root(r);
+        for (int k = 0; k < (1 << r); ++k) {
+            qa.zh[k] = glh::sub(glh::mul(gn, glh::pow(wr, k)), 1);
+            qa.zh_inv[k] = glh::inv(qa.zh[k]);
+        }
+        qa.periodic = d_per;
+        qa.pub = d_pub;
+        qa.tw = ctx->tw_fwd.d;
+        // powers of the two alphas for the K constraints (the Horner recurrence as a dot product, air.cuh)
+        const int K = air->count();
+        std::vector<uint64_t> apow(2 * (size_t)K);
+        uint64_t pw[2] = {1, 1};
+        for (int kk = K - 1; kk >= 0; --kk)
+            for (int j = 0; j < 2; ++j) {
+                apow[2 * (size_t)kk + j] = pw[j];
+                pw[j] = glh::mul(pw[j], alphas[j]);
+            }
+        uint64_t* d_apow_q = mem.alloc(apow.size());
+        VX_CHECK(d_apow_q, "stark prove: out of device memory (alpha powers)");
+        VX_HIP(hipMemcpyAsync(d_apow_q, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        qa.apow = d_apow_q;
+        air->launch(qa, ctx->stream);
+        VX_HIP(hipStreamSynchronize(ctx->stream));  // apow (host vector) must outlive the copy
+        VX_HIP(hipGetLastError());
+    }
+    return VX_OK;
+}
 
 // consume_trace != 0: the trace buffer is overwritten (it ends up holding the bit-reversed coefficients);
 // saves the n*c coefficient scratch -- the caller must own the buffer.
@@ -508,58 +587,8 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
 
     // ---- 2. quotient polynomials (compute_quotient_polys) on the size-N coset
     uint64_t* qv = mem.alloc(2 * N);
-    uint64_t* d_pub = mem.alloc(n_public ? n_public : 1);
-    VX_CHECK(qv && d_pub, "stark prove: out of device memory (quotient)");
-    if (n_public) VX_HIP(hipMemcpyAsync(d_pub, public_inputs, n_public * 8, hipMemcpyHostToDevice, ctx->stream));
-    uint64_t* d_per = nullptr;
-    if (air->periodic) {
-        std::vector<uint64_t> pv, tab;
-        air->periodic_values(pv);
-        const size_t p = (size_t)1 << air->period_log, m = p << r;
-        tab.resize(air->periodic * m);
-        const uint64_t shift_pow = glh::pow(g, n >> air->period_log);
-        for (int j = 0; j < air->periodic; ++j) periodic_on_coset(pv.data() + j * p, air->period_log, r, shift_pow, tab.data() + j * m);
-        d_per = mem.alloc(tab.size());
-        VX_CHECK(d_per, "stark prove: out of device memory (periodic)");
-        VX_HIP(hipMemcpyAsync(d_per, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        VX_HIP(hipStreamSynchronize(ctx->stream));
-    }
-    {
-        QuotArgs qa{};
-        qa.lde = trace_lde;
-        qa.q_out = qv;
-        qa.log_N = LN;
-        qa.rate_bits = r;
-        qa.shift = g;
-        qa.last = glh::inv(glh::root(L));
-        qa.n_inv = glh::inv(n % glh::P);
-        qa.alpha[0] = alphas[0];
-        qa.alpha[1] = alphas[1];
-        const uint64_t gn = glh::pow(g, n), wr = glh::root(r);
-        for (int k = 0; k < (1 << r); ++k) {
-            qa.zh[k] = glh::sub(glh::mul(gn, glh::pow(wr, k)), 1);
-            qa.zh_inv[k] = glh::inv(qa.zh[k]);
-        }
-        qa.periodic = d_per;
-        qa.pub = d_pub;
-        qa.tw = ctx->tw_fwd.d;
-        // powers of the two alphas for the K constraints (the Horner recurrence as a dot product, air.cuh)
-        const int K = air->count();
-        std::vector<uint64_t> apow(2 * (size_t)K);
-        uint64_t pw[2] = {1, 1};
-        for (int kk = K - 1; kk >= 0; --kk)
-            for (int j = 0; j < 2; ++j) {
-                apow[2 * (size_t)kk + j] = pw[j];
-                pw[j] = glh::mul(pw[j], alphas[j]);
-            }
-        uint64_t* d_apow_q = mem.alloc(apow.size());
-        VX_CHECK(d_apow_q, "stark prove: out of device memory (alpha powers)");
-        VX_HIP(hipMemcpyAsync(d_apow_q, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        qa.apow = d_apow_q;
-        air->launch(qa, ctx->stream);
-        VX_HIP(hipStreamSynchronize(ctx->stream));  // apow (host vector) must outlive the copy
-        VX_HIP(hipGetLastError());
-    }
+    VX_CHECK(qv, "stark prove: out of device memory (quotient)");
+    VX_TRY(quotient_eval_dev(ctx, air, L, r, trace_lde, alphas, public_inputs, n_public, qv, mem));
     // values on the coset -> coefficients (coset_ifft), split into Q chunks of n, commit (from_coeffs)
     VX_TRY(vx_ntt_dev(ctx, qv, LN, 2, N, 1, g, VX_ORDER_NATURAL));
     // chunk j of challenge k = qv[k*N + j*n .. +n): already contiguous as 2*Q columns of n coefficients

@@ -26,7 +26,7 @@ SYMBOLS = [
     "vx_blake2b_256_batch", "vx_sha256_pairs", "vx_verify_subchain", "vx_blake_chain_trace",
     "vx_ed25519_verify_batch", "vx_verify_simple_justification", "vx_sha_chain_trace",
     "vx_verify_epoch_end_header", "vx_rotate_proof_bound", "vx_rotate_prove", "vx_rotate_verify",
-    "vx_gather_proofs",
+    "vx_gather_proofs", "vx_quotient_eval",
 ]
 
 VX_AIR_FIBONACCI, VX_AIR_MIX, VX_AIR_BLAKE_CHAIN = 1, 2, 3
@@ -122,6 +122,7 @@ def load_library():
         "vx_rotate_prove": [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.POINTER(JustificationStruct), C.POINTER(StarkConfig), vp, vp, sz, C.POINTER(sz)],
         "vx_rotate_verify": [C.POINTER(StarkConfig), vp, sz, u64, vp, vp, C.c_char_p, sz],
         "vx_gather_proofs": [vp, vp, C.c_int, vp, sz, vp],
+        "vx_quotient_eval": [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, sz, vp],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -411,6 +412,17 @@ class Context:
         self._ck(self.L.vx_rotate_prove(self.h, header_buf.h, header_size, epoch_end_block_number, num_authorities, start_position, _ptr(pk),
                                         C.byref(just.struct), C.byref(cfg), _ptr(out32), _ptr(out), out.size, C.byref(need)))
         return out32.tobytes(), out[: need.value]
+
+    def quotient_eval(self, air_id, rate_bits, trace_lde_buf, log_n, alphas, public_inputs):
+        """-> [2][N] quotient values on the coset for the two challenges."""
+        N = 1 << (log_n + rate_bits)
+        out = self.alloc(2 * N)
+        al = np.ascontiguousarray(alphas, dtype=np.uint64)
+        pub = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        self._ck(self.L.vx_quotient_eval(self.h, air_id, rate_bits, trace_lde_buf.h, log_n, _ptr(al), _ptr(pub) if pub.size else None, pub.size, out.h))
+        v = out.download().reshape(2, N)
+        out.free()
+        return v
 
     def gather_proofs(self, nccl_comm, world, blob_words):
         """All-gather equal-length proof blobs over RCCL (nccl_comm: a raw ncclComm_t as an integer / c_void_p)."""

@@ -160,6 +160,11 @@ typedef struct vx_stark_config {
 } vx_stark_config;
 enum { VX_AIR_FIBONACCI = 1, VX_AIR_MIX = 2 };
 int32_t vx_stark_default_config(vx_stark_config* cfg);
+/* K5: batched constraint / quotient-polynomial evaluation (starky prover.rs compute_quotient_polys) for an AIR compiled
+ * into the library.  trace_lde: column-major [cols][N], N = 2^(log_n + rate_bits), natural order, values on the coset
+ * 7 * <w_N>.  out[k*N + i] = (sum_j alpha_k^(K-1-j) c_j(x_i)) / Z_H(x_i) for the two challenges k = 0, 1. */
+int32_t vx_quotient_eval(vx_ctx* ctx, int air_id, int rate_bits, const vx_buf* trace_lde, int log_n, const uint64_t alphas[2],
+                         const uint64_t* public_inputs, size_t n_public, vx_buf* out);
 /* upper bound on the proof length (uint64 words) for buffer sizing */
 int32_t vx_stark_proof_bound(int air_id, const vx_stark_config* cfg, int log_n, size_t* n_words);
 int32_t vx_stark_prove(vx_ctx* ctx, int air_id, const vx_stark_config* cfg, const vx_buf* trace, int log_n,

@@ -256,35 +256,12 @@ def _ext_challenge(ch):
 
 
 # ----------------------------------------------------------------------------- prover
-def prove(air, trace, public_inputs, cfg=None):
-    cfg = dict(DEFAULT_CFG, **(cfg or {}))
-    L_ = _lib()
-    trace = np.ascontiguousarray(trace, dtype=np.uint64)
-    c, n = trace.shape
-    L, r = n.bit_length() - 1, cfg["rate_bits"]
-    LN, N = L + r, n << r
-    cap_h, nq = cfg["cap_height"], 4
-    assert c == air.COLS and len(public_inputs) == air.PUB
-    pub = [int(x) % P for x in public_inputs]
-
-    # 1. trace commitment (PolynomialBatch::from_values)
-    leaves_t, coeffs_t = O.lde_from_values(trace, r, G)
-    tree_t = O.MerkleTree(leaves_t, cap_h)
-    arities = fri_arity_plan(L, cfg)
-    final_log = LN - sum(arities)
-    final_len = (1 << final_log) >> r
-    proof = [MAGIC, air.ID, L, c, nq, r, cap_h, cfg["num_queries"], cfg["pow_bits"], len(arities)] + arities + [final_len, len(pub)] + pub
-    proof += [int(x) for x in tree_t.cap.reshape(-1)]
-
-    ch = O.Challenger()
-    if pub:
-        ch.observe(np.array(pub, dtype=np.uint64))
-    ch.observe(tree_t.cap.reshape(-1))
-    alphas = [ch.challenge(), ch.challenge()]
-
-    # 2. quotient polys on the coset g*<w_N>, natural order (compute_quotient_polys)
-    perm = bitrev_perm(LN)
-    lde_nat = leaves_t[perm].T.copy()  # [c][N], lde_nat[:, i] = values at g*w_N^i
+def quotient_values(air, lde_nat, pub, alphas, L, r):
+    """starky compute_quotient_polys on the coset: lde_nat [c][N] (natural order) -> [2][N] values
+    (sum_j alpha_k^(K-1-j) c_j(x)) / Z_H(x), the Horner recurrence of ConstraintConsumer."""
+    c = lde_nat.shape[0]
+    n, LN = 1 << L, L + r
+    N = n << r
     wN = O.root(LN)
     xs = np.empty(N, dtype=np.uint64)
     acc = G
@@ -318,6 +295,39 @@ def prove(air, trace, public_inputs, cfg=None):
             per.append(a_)
     air.eval(loc, nxt, per, [VecF.const(x, X) for x in pub], cons)
     qvals = np.stack([(cons.acc[k] * zh_inv).v for k in range(2)])
+    return qvals
+
+
+def prove(air, trace, public_inputs, cfg=None):
+    cfg = dict(DEFAULT_CFG, **(cfg or {}))
+    L_ = _lib()
+    trace = np.ascontiguousarray(trace, dtype=np.uint64)
+    c, n = trace.shape
+    L, r = n.bit_length() - 1, cfg["rate_bits"]
+    LN, N = L + r, n << r
+    cap_h, nq = cfg["cap_height"], 4
+    assert c == air.COLS and len(public_inputs) == air.PUB
+    pub = [int(x) % P for x in public_inputs]
+
+    # 1. trace commitment (PolynomialBatch::from_values)
+    leaves_t, coeffs_t = O.lde_from_values(trace, r, G)
+    tree_t = O.MerkleTree(leaves_t, cap_h)
+    arities = fri_arity_plan(L, cfg)
+    final_log = LN - sum(arities)
+    final_len = (1 << final_log) >> r
+    proof = [MAGIC, air.ID, L, c, nq, r, cap_h, cfg["num_queries"], cfg["pow_bits"], len(arities)] + arities + [final_len, len(pub)] + pub
+    proof += [int(x) for x in tree_t.cap.reshape(-1)]
+
+    ch = O.Challenger()
+    if pub:
+        ch.observe(np.array(pub, dtype=np.uint64))
+    ch.observe(tree_t.cap.reshape(-1))
+    alphas = [ch.challenge(), ch.challenge()]
+
+    # 2. quotient polys on the coset g*<w_N>, natural order (compute_quotient_polys)
+    perm = bitrev_perm(LN)
+    lde_nat = leaves_t[perm].T.copy()  # [c][N], lde_nat[:, i] = values at g*w_N^i
+    qvals = quotient_values(air, lde_nat, pub, alphas, L, r)
     qcoef = O.ntt(qvals, inverse=True, shift=G)  # coset_ifft
     chunks = qcoef.reshape(nq, n)  # flat_map(|q| q.chunks(degree))
     leaves_q = O.lde_from_coeffs(chunks, r, G)

@@ -5,6 +5,8 @@ import pytest
 
 from oracle import stark_ref as S
 
+P = 2**64 - 2**32 + 1
+
 pytestmark = pytest.mark.gpu
 
 
@@ -52,3 +54,18 @@ def test_argument_errors(ctx, vx):
         ctx.stark_prove(S.FibAir.ID, buf, 6, pub[:2])
     with pytest.raises(vx.VxError):
         ctx.stark_prove(S.FibAir.ID, buf, 9, pub)  # trace buffer too small for 2^9 rows
+
+
+@pytest.mark.parametrize("air_name,log_n", [("mix", 6), ("fib", 5)])
+def test_quotient_eval_primitive_matches_reference(ctx, vx, oracle, air_name, log_n):
+    """K5 on its own (vx_quotient_eval): every quotient value on the coset, both challenges, equals the reference's
+    compute_quotient_polys restatement (oracle/stark_ref.quotient_values)."""
+    air = S.MixAir if air_name == "mix" else S.FibAir
+    trace, pub = air.trace(log_n)
+    r = 1
+    leaves, _ = oracle.lde_from_values(trace, r, 7)
+    lde_nat = leaves[S.bitrev_perm(log_n + r)].T.copy()
+    alphas = [0x123456789ABCDEF % P, 0xFEDCBA987654321 % P]
+    want = S.quotient_values(air, lde_nat, [int(x) % P for x in pub], alphas, log_n, r)
+    got = ctx.quotient_eval(air.ID, r, ctx.from_host(np.ascontiguousarray(lde_nat)), log_n, alphas, pub)
+    assert (got == want).all()
