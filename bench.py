@@ -180,8 +180,16 @@ def main():
         import torch
         import torch.distributed as dist_mod
 
+        # VX_BENCH_BACKEND=gloo + VX_BENCH_DEVICE=0 rehearse the N > 1 control flow (barrier, gather, max-reduce) with
+        # several ranks on ONE GPU, which RCCL cannot do; the driver's runs use nccl (= RCCL), one rank per GPU.
+        backend = os.environ.get("VX_BENCH_BACKEND", "nccl")
+        if os.environ.get("VX_BENCH_DEVICE"):
+            local_rank = int(os.environ["VX_BENCH_DEVICE"])
         torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist_mod.init_process_group(backend)
         dist = dist_mod
     vx = vx_import.load()
     inflight = args.inflight or 2  # two 2^20-row proofs (--headers 512) take 2 x 111 GB of the 288 GB: measured to fit
@@ -236,13 +244,14 @@ def main():
     res = run_steps(args.steps)
     blob = wl.blob(res)
     # the one collective: fixed-size result blobs to rank 0 over RCCL/xGMI
-    gathered = vx.shard.gather_blobs(blob, dist, device="cuda" if dist else None)
+    tdev = "cuda" if dist and dist.get_backend() == "nccl" else ("cpu" if dist else None)
+    gathered = vx.shard.gather_blobs(blob, dist, device=tdev)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist:
         import torch
 
-        t = torch.tensor([elapsed], device="cuda")
+        t = torch.tensor([elapsed], device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
