@@ -30,6 +30,40 @@ def test_field_batches(ctx, oracle, rng):
     assert (do.download(2 * m) == oracle.ext_mul(a[: 2 * m], b[: 2 * m])).all()
 
 
+def test_field_edge_values(ctx):
+    """All pairs of a set of special values through add / sub / mul / ext-mul against Python integers.  The reduction
+    after a multiply has branches random inputs reach with probability ~2^-32 (a borrow in lo - hi_hi that no carry of
+    the hi_lo * eps term undoes, e.g. 2^63 * (k 2^33) = k 2^96 = -k): they are hit here on purpose."""
+    S = [0, 1, 2, 7, P - 1, P - 2, P - 7, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, P - (1 << 32), P - (1 << 32) + 1, P - (1 << 32) - 1,
+         1 << 48, 1 << 63, (1 << 63) - 1, (1 << 63) + 1, (1 << 62) + 12345, 0xFFFFFFFF00000000, 0xFFFFFFFE00000002, 0x00000001FFFFFFFF,
+         0x8000000080000000, 0x7FFFFFFF7FFFFFFF, 1753635133440165772]
+    S += [k << 33 for k in (1, 2, 5, 0x7FFF, 0x3FFFFFFF)] + [k << 48 for k in (1, 3, 0xFFFE)] + [(k << 32) - 1 for k in (2, 3, 0x10000)]
+    S = sorted({x % P for x in S})
+    a = np.array([x for x in S for _ in S], dtype=np.uint64)
+    b = np.array([y for _ in S for y in S], dtype=np.uint64)
+    n = a.size
+    da, db, do = ctx.from_host(a), ctx.from_host(b), ctx.alloc(n)
+    for op, f in (("add", lambda x, y: (x + y) % P), ("sub", lambda x, y: (x - y) % P), ("mul", lambda x, y: x * y % P)):
+        ctx.field_op(op, da, db, do, n)
+        want = np.array([f(int(x), int(y)) for x, y in zip(a, b)], dtype=np.uint64)
+        got = do.download()
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (op, hex(int(a[bad[0]])), hex(int(b[bad[0]])), hex(int(got[bad[0]])), hex(int(want[bad[0]])))
+    m = n // 2  # pairs (a[2i], a[2i+1]) x (b[2i], b[2i+1]) in F_p[X]/(X^2 - 7)
+    ctx.ext_mul(da, db, do, m)
+    got = do.download(2 * m)
+    for i in range(m):
+        x0, x1, y0, y1 = int(a[2 * i]), int(a[2 * i + 1]), int(b[2 * i]), int(b[2 * i + 1])
+        assert (int(got[2 * i]), int(got[2 * i + 1])) == ((x0 * y0 + 7 * x1 * y1) % P, (x0 * y1 + x1 * y0) % P), i
+    # the same products through the lazy paths: Poseidon on states built from the special values
+    st = np.array([S[(i * 7 + j) % len(S)] for i in range(64) for j in range(12)], dtype=np.uint64)
+    from oracle import oracle as O
+
+    buf = ctx.from_host(st)
+    ctx.poseidon(buf, 64)
+    assert (buf.download().reshape(64, 12) == O.poseidon(st.reshape(64, 12))).all()
+
+
 def test_fill_random_is_canonical(ctx):
     buf = ctx.alloc(1 << 16)
     ctx.fill_random(buf, 1 << 16, 42)
