@@ -326,14 +326,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             }
         }
     };
-    uint64_t x[16];
+    // VX_NTT_PREFETCH=1: the DIT passes (96 VGPRs) hold the next tile's 16 raw values per lane while the current tile is
+    // in its rounds (126 VGPRs, still 3 blocks per CU).  Measured: LDE 2^19 x 1024 21.97 ms with, 21.67 ms without -- the
+    // pass is not waiting for its loads; off by default.
+#ifndef VX_NTT_PREFETCH
+#define VX_NTT_PREFETCH 0
+#endif
+    constexpr bool PF = VX_NTT_PREFETCH && MODE == 1;
+    uint64_t x[16], nx[PF ? 16 : 1];
+    if (PF) load_raw(tile0, nx);
 #pragma unroll 1
     for (int t = 0; t < n_here; ++t) {
         // keep per-element index math and twiddle lookups inside the loop: hoisted they cost 100+ VGPRs (occupancy)
         asm volatile("" : "+v"(tid));
         size_t col0;
         const size_t base = tile_base(tile0 + t, col0);
-        load_raw(tile0 + t, x);
+        if (PF) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x[e] = nx[PF ? e : 0];
+            if (t + 1 < n_here) load_raw(tile0 + t + 1, nx);  // in flight during the rounds below
+        } else {
+            load_raw(tile0 + t, x);
+        }
         if (MODE == 0) {
             const bool sk_tw = a.dbg_skip & 1, sk_ip = a.dbg_skip & 2, sk_bf = a.dbg_skip & 4;
             if (!sk_bf) tile_round<0, INV>(x, qA);
