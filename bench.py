@@ -280,6 +280,15 @@ def main():
             },
             "roofline": roof,
         }
+        if args.circuit == "header_range":
+            # SURVEY 8d "whole proof" figure: compulsory (algorithmic) bytes of every streaming stage of the BlakeChainAir
+            # proof over the time of a step -- trace written 8nc, LDE 8nc(1+2^r), leaf hashing 8Nc, quotient 16Nc,
+            # openings 8nc, FRI combine 8Nc (N = 2n, r = 1); the small ShaChainAir proof and FRI tail are left out
+            n_rows = float(1 << (19 if N_HEADERS == 256 else 20))
+            alg = 8 * n_rows * BLAKE_COLS * (1 + 3 + 2 + 4 + 1 + 2)
+            line["proof_roofline"] = {"bound": "hbm", "algorithmic_GB": round(alg / 1e9, 1), "achieved": round(alg / 1e9 / (elapsed / args.steps), 1),
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / 1e9 / (elapsed / args.steps) / HBM_PEAK_GBS, 4),
+                                      "note": "the proof is bound by VALU issue (Poseidon leaf hashing 54 %), not by bytes"}
         if args.circuit == "rotate":
             line["metric"] = "rotate proofs/sec"
             line["config"] = {
