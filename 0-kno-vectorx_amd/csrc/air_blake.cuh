@@ -68,7 +68,10 @@ struct BlakeAir {
         F g_on = sel[0];
         for (int r = 1; r < 12; ++r) g_on = g_on + sel[r];
         auto at = [&](int which, int col) -> F { return which ? nxt[col] : loc[col]; };
-        auto xorf = [&](F x, F y) -> F { return x + y - two * (x * y); };
+        auto xorf = [&](F x, F y) -> F {  // x + y - 2xy (the doubling as an addition: a modular add is a third of a multiply)
+            const F xy = x * y;
+            return x + y - (xy + xy);
+        };
         auto limb = [&](int which, int col0, int h) -> F {  // sum_i 2^i x_i over the 32 cells of one limb
             if constexpr (is_device_field<F>::value) {
                 // device: the low and high halves of the 32 cells accumulate as plain integers (each sum < 2^64),
