@@ -38,7 +38,7 @@ def main(d, out):
             e["valu_insts_per_wave"] = round(c["SQ_INSTS_VALU"] / c["SQ_WAVES"], 1)
         res[k] = e
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
-    for k, e in sorted(res.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:12]:
+    for k, e in sorted(res.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:12]:  # (do not pipe into head: BrokenPipe)
         print(k, {n: v for n, v in e.items() if "/" in n or n.startswith("valu") or n == "launches"})
 
 
