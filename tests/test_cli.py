@@ -121,3 +121,22 @@ def test_cli_rotate_round_trip(cli, vx, tmp_path):
     assert run("rotate", "verify", str(tmp_path / "input.json")).returncode == 0
     r = run("dummy_rotate", "prove", str(tmp_path / "input.json"), "--witness", str(tmp_path / "w.npz"), "--output", str(tmp_path / "d.json"))
     assert r.returncode == 0 and cli.read_result(str(tmp_path / "d.json")) == (out, None)
+
+
+@pytest.mark.gpu
+def test_cli_full_size_synthetic_witness(cli, vx, tmp_path):
+    """The reference's command line as is -- `header_range_256 prove input.json` -- at full size (256 x 15,360-byte
+    headers, 300 authorities) with the seeded generator standing in for the RPC hints, then `verify`."""
+    ch = vx.synth.Chain(256, profile="P15k")
+    just = vx.synth.Justification(ch.target_block, ch.target_hash, set_id=1)
+    raw = vx.synth.pack_input(ch.trusted_block, ch.trusted_hash, 1, just.authority_set_hash, ch.target_block)
+    (tmp_path / "input.json").write_text(json.dumps({"type": "req_bytes", "releaseId": "r", "data": {"input": "0x" + raw.hex()}}))
+    r = run("header_range_256", "prove", "input.json", cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out, words = cli.read_result(str(tmp_path / "output.json"))
+    assert out == ch.expected_outputs(256) and words.size > 400000
+    assert run("header_range_256", "verify", "input.json", cwd=str(tmp_path)).returncode == 0
+    # a request whose trusted hash is not the synthetic chain's is refused before any proving
+    bad = vx.synth.pack_input(ch.trusted_block, bytes(32), 1, just.authority_set_hash, ch.target_block)
+    (tmp_path / "bad.json").write_text(json.dumps({"type": "req_bytes", "data": {"input": bad.hex()}}))
+    assert run("header_range_256", "prove", "bad.json", "--output", str(tmp_path / "o.json"), cwd=str(tmp_path)).returncode == 1
