@@ -287,6 +287,11 @@ struct BlakeAir {
         c.constraint(loc[CAP] - loc[ACT] * fin);
         c.constraint(loc[FA] - first * loc[ACT]);
         c.transition(sel[15] * (nxt[NUM] - loc[NUM] - nxt[FA]));  // sequential numbers (subchain_verification.rs:166-168)
+        // ACT is a property of a whole MESSAGE, not of a block: it may not change between the chunks of one message
+        // (else a junk message could bump NUM through FA on its first chunk and skip the digest capture on its last),
+        // and once the chain has gone inactive (padding) it stays inactive
+        c.constraint(sel[15] * (one - fin) * (nxt[ACT] - loc[ACT]));
+        c.transition(nxt[ACT] * (one - loc[ACT]));
         c.constraint(sel[15] * (nxt[FIRST] - fin));
         c.constraint(sel[15] * (nxt[T] - (one - fin) * loc[T] - nxt[INC]));
         {

@@ -198,6 +198,16 @@ int32_t vx_stark_verify(const vx_stark_config* cfg, const uint64_t* pr, size_t l
     int final_log = LN;
     for (int a : arities) final_log -= a;
     NEED(c == (size_t)air->cols && n_pub == (size_t)air->pub && nq == 4 && final_len == (((size_t)1 << final_log) >> r), "shape mismatch");
+    // the proof is untrusted input: the shapes the prover refuses (vx_stark_prove_impl) are refused here too, so no
+    // Merkle depth below can go negative (a crafted L = 2 proof used to reach v_merkle with n_sib = SIZE_MAX)
+    NEED(r >= 1 && r <= 3 && cap_h >= 0 && LN >= cap_h && LN <= 27 && L >= air->period_log, "degree bits %d out of range for this AIR / cap height", L);
+    {
+        int cur = LN;
+        for (int a : arities) {
+            NEED(cur - a - cap_h >= 0, "FRI layer below the cap height");
+            cur -= a;
+        }
+    }
     for (size_t i = 0; i < len; ++i) NEED(pr[i] < glh::P || i < pos, "non-canonical element at word %zu", i);
     NEED(have(n_pub), "proof truncated (public inputs)");
     const uint64_t* pub = pr + pos;

@@ -187,12 +187,15 @@ def compress(h, m_bytes, t, fin):
     return h_out, recs, v0, m
 
 
-def gen_trace(messages, log_n, trusted_hash, first_number=None):
-    """Full trace [COLS][n] (uint64) + public inputs (trusted / target hash limbs, first / last number)."""
+def gen_trace(messages, log_n, trusted_hash, first_number=None, forge=None):
+    """Full trace [COLS][n] (uint64) + public inputs (trusted / target hash limbs, first / last number).
+    forge(blocks, target, last_number) -> (blocks, target, last_number) lets a negative test edit the block list."""
     n = 1 << log_n
     if first_number is None:
         first_number = (int.from_bytes(messages[0][32:36], "little") - 2) // 4
     blocks, target, last_number = gen_blocks(messages, n // 16, trusted_hash, first_number)
+    if forge is not None:
+        blocks, target, last_number = forge(blocks, target, last_number)
     tr = np.zeros((COLS, n), dtype=np.uint64)
 
     def put_bits(row, col0, val, nbits=64):
@@ -420,6 +423,10 @@ class BlakeChainAir:
         c.constraint(loc[CAP] - loc[ACT] * loc[FIN])
         c.constraint(loc[FA] - loc[FIRST] * loc[ACT])
         c.transition(sel[15] * (nxt[NUM] - loc[NUM] - nxt[FA]))  # numbers are sequential (subchain_verification.rs:166-168)
+        # ACT belongs to a whole message: constant across its chunks (a junk message must not bump NUM on its first
+        # chunk and dodge the digest capture on its last), and monotone (padding stays padding)
+        c.constraint(sel[15] * (1 - loc[FIN]) * (nxt[ACT] - loc[ACT]))
+        c.transition(nxt[ACT] * (1 - loc[ACT]))
         c.constraint(sel[15] * (nxt[FIRST] - loc[FIN]))
         c.constraint(sel[15] * (nxt[T] - (1 - loc[FIN]) * loc[T] - nxt[INC]))
         tb = loc[TB0 + 31]

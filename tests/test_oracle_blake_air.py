@@ -57,3 +57,30 @@ def test_broken_link_or_numbering_rejected():
     skip = d1 + (4 * 70002 + 2).to_bytes(4, "little") + msgs[1][36:]
     with pytest.raises(AssertionError):
         B.gen_trace([msgs[0], skip], 6, trusted)
+
+
+def test_act_cannot_change_inside_a_message():
+    """a junk 2-chunk message with ACT = 1 on its first chunk and ACT = 0 on its final chunk used to
+    bump NUM (through FA = FIRST * ACT) without capturing a digest, so a verifying trace could bind the target hash to
+    the wrong block number (the reference asserts the number: subchain_verification.rs:166-168, header_range.rs:49)."""
+    msgs, trusted, target = make([100])
+
+    def forge(blocks, tgt, last):
+        n_blocks = len(blocks)
+        junk = tgt + (4 * (last + 1) + 2).to_bytes(4, "little") + bytes(92) + bytes(40)  # 168 bytes = 2 chunks
+        h0 = list(B.IVP)
+        b0 = dict(m=junk[:128], h=h0, t=128, inc=128, fin=False, first=True, act=1, D=tgt, num=last + 1)
+        h1 = B.compress(h0, b0["m"], 128, False)[0]
+        b1 = dict(m=junk[128:] + bytes(88), h=h1, t=168, inc=40, fin=True, first=False, act=0, D=tgt, num=last + 1)
+        real = [b for b in blocks if b["act"]]
+        pad = dict(m=tgt + (4 * (last + 1) + 2).to_bytes(4, "little") + bytes(92), h=list(B.IVP), t=36, inc=36, fin=True, first=True, act=0, D=tgt, num=last + 1)
+        out = real + [b0, b1]
+        return out + [dict(pad) for _ in range(n_blocks - len(out))], tgt, last + 1
+
+    tr, pub, tgt = B.gen_trace(msgs, 6, trusted, forge=forge)
+    assert tgt == target and pub[17] == 70001  # the forged claim: target hash bound to number + 1
+    bad = B.first_violation(tr, pub)
+    assert bad is not None and bad[0] == 16 + 15  # caught at the PAD row of the junk message's first chunk
+    # the honest trace of the same message is still fine
+    tr, pub, _ = B.gen_trace(msgs, 6, trusted)
+    assert B.first_violation(tr, pub) is None and pub[17] == 70000

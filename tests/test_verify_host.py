@@ -48,3 +48,16 @@ def test_blake_chain_proof(vx, oracle):
         vx.lib.stark_verify(bad, pcfg)
     with pytest.raises(S.VerifyError):
         S.verify(bad, cfg)
+
+
+def test_short_crafted_proof_is_rejected_not_crashing(vx):
+    """L is read from the (untrusted) proof; with cap_height 4 and rate_bits 1 a claimed L = 2 made
+    the Merkle depth LN - cap_height negative and the verifier walked SIZE_MAX siblings (SIGSEGV).  Must be refused."""
+    for L in (2, 1, 0, 27, 2**31):
+        blob = np.zeros(232, dtype=np.uint64)
+        blob[:10] = [S.MAGIC, 1, L, 2, 4, 1, 4, 84, 16, 0]
+        blob[10:12] = [4, 3]  # final_len for L = 2 (LN = 3, no FRI layers), 3 public inputs
+        with pytest.raises(vx.VxError):
+            vx.lib.stark_verify(blob)
+        with pytest.raises(S.VerifyError):
+            S.verify(blob)
