@@ -1,11 +1,18 @@
 // AIR interface shared by the GPU quotient kernel (base field, one LDE point per lane) and
 // the host verifier (extension field, at zeta).  An AIR is a struct with
-//   static constexpr int COLS, PUB, PERIODIC, PERIOD_LOG;
-//   static void periodic_values(std::vector<uint64_t>& out);   // [PERIODIC][1 << PERIOD_LOG], host
-//   template <class F, class Row, class C> static void eval(const Row& loc, const Row& nxt,
-//                                                           const F* per, const F* pub, C& c);
+//   static constexpr int COLS, PUB, PERIODIC, PERIOD_LOG;      // PERIOD_LOG = the largest period
+//   static constexpr int AUX, CHAL, AUXPUB;                     // auxiliary round (0 0 0 = none), see below
+//   static constexpr int plog(int q);                           // period (log2) of periodic column q
+//   template <class F, class Row, class C> static void eval(const Row& loc, const Row& nxt, const F* per,
+//                                                           const F* pub, const F* chal, const F* apub, C& c);
 // `eval` pushes constraints into the consumer IN A FIXED ORDER (the order is part of the
 // protocol: the oracle restates it independently in oracle/stark_ref.py).
+//
+// Auxiliary round (lookup arguments, logUp): after the trace cap the transcript yields CHAL base-field challenges;
+// the prover derives AUX further columns from the trace and the challenges (helper sums 1/(beta + tuple), running
+// sums), commits them in a second Merkle tree, and only then the constraint challenges alpha are drawn.  Rows seen
+// by eval hold the COLS main columns followed by the AUX auxiliary ones; `apub` are 2*AUXPUB values the prover
+// publishes with the auxiliary cap (bus totals).  Lookup arithmetic runs in the quadratic extension (X2 below).
 //
 // Consumer semantics follow starky v0.2.0 ConstraintConsumer (crate `starky`, same git rev as
 // plonky2 in /root/reference Cargo.lock:4848): acc = acc * alpha + c for each of the
@@ -83,6 +90,31 @@ struct HostRow {
     Fx operator[](int col) const { return v[col]; }
 };
 
+// Quadratic-extension element F[X]/(X^2 - 7) over any field type of this file (device FpN, host Fx, CountF): the
+// challenges beta / gamma and the helper and running-sum columns of a lookup argument are extension elements kept as
+// two base columns; a constraint on X2 values is two base constraints (consumer.constraint_x2).
+template <class F>
+struct X2 {
+    F a, b;
+};
+template <class F>
+VX_HD F f_mul7(const F& x) {  // 7x = 8x - x: three doublings and a subtraction instead of a modular multiply
+    const F x2 = x + x, x4 = x2 + x2;
+    return x4 + x4 - x;
+}
+template <class F>
+VX_HD X2<F> operator+(const X2<F>& x, const X2<F>& y) { return {x.a + y.a, x.b + y.b}; }
+template <class F>
+VX_HD X2<F> operator-(const X2<F>& x, const X2<F>& y) { return {x.a - y.a, x.b - y.b}; }
+template <class F>
+VX_HD X2<F> operator+(const X2<F>& x, const F& y) { return {x.a + y, x.b}; }
+template <class F>
+VX_HD X2<F> operator-(const X2<F>& x, const F& y) { return {x.a - y, x.b}; }
+template <class F>
+VX_HD X2<F> operator*(const X2<F>& x, const X2<F>& y) { return {x.a * y.a + f_mul7(x.b * y.b), x.a * y.b + x.b * y.a}; }
+template <class F>
+VX_HD X2<F> operator*(const X2<F>& x, const F& y) { return {x.a * y, x.b * y}; }
+
 // Gates: a run of constraints that share one factor g (a row selector) may be pushed as
 //   auto G = c.open(g); ... c.gated(G, e) ... ; c.close(G);
 // which stands for c.constraint(g * e) at each position (several gates may be open at once, interleaved with plain
@@ -100,6 +132,10 @@ struct Consumer {
     VX_HD void transition(F c) { constraint(c * z_last); }
     VX_HD void first_row(F c) { constraint(c * l_first); }
     VX_HD void last_row(F c) { constraint(c * l_last); }
+    VX_HD void constraint_x2(const X2<F>& e) {
+        constraint(e.a);
+        constraint(e.b);
+    }
     VX_HD Gate open(F g) { return Gate{g}; }
     VX_HD void gated(Gate& G, F e) { constraint(G.g * e); }
     VX_HD void close(Gate&) {}
@@ -140,6 +176,10 @@ struct Consumer<FpN<R>> {
     __device__ __forceinline__ void transition(const F& c) { constraint(c * z_last); }
     __device__ __forceinline__ void first_row(const F& c) { constraint(c * l_first); }
     __device__ __forceinline__ void last_row(const F& c) { constraint(c * l_last); }
+    __device__ __forceinline__ void constraint_x2(const X2<F>& e) {
+        constraint(e.a);
+        constraint(e.b);
+    }
     __device__ __forceinline__ Gate open(const F& g) {
         Gate G;
         G.g = g;
@@ -173,6 +213,7 @@ struct Consumer<CountF> {
     void transition(CountF) { ++k; }
     void first_row(CountF) { ++k; }
     void last_row(CountF) { ++k; }
+    void constraint_x2(const X2<CountF>&) { k += 2; }
     Gate open(CountF) { return {}; }
     void gated(Gate&, CountF) { ++k; }
     void close(Gate&) {}
@@ -197,9 +238,10 @@ struct RowViewN {  // column-major LDE, rows i[0..R) of it
 // ---- AIR 1: Fibonacci (the canonical starky example; used to pin the generic prover) ----
 // columns (x0, x1); public inputs (x0[0], x1[0], x1[n-1]); next.x0 = x1, next.x1 = x0 + x1.
 struct FibAir {
-    static constexpr int ID = 1, COLS = 2, PUB = 3, PERIODIC = 0, PERIOD_LOG = 0, QUOT_ROWS_PER_LANE = 1;
+    static constexpr int ID = 1, COLS = 2, PUB = 3, PERIODIC = 0, PERIOD_LOG = 0, QUOT_ROWS_PER_LANE = 1, AUX = 0, CHAL = 0, AUXPUB = 0;
+    static constexpr int plog(int) { return 0; }
     template <class F, class Row, class C>
-    VX_HD static void eval(const Row& loc, const Row& nxt, const F*, const F* pub, C& c) {
+    VX_HD static void eval(const Row& loc, const Row& nxt, const F*, const F* pub, const F*, const F*, C& c) {
         c.first_row(loc[0] - pub[0]);
         c.first_row(loc[1] - pub[1]);
         c.last_row(loc[1] - pub[2]);
@@ -214,9 +256,10 @@ struct FibAir {
 //   rows with s = 1: next.a = d         (re-seed; s = (0,0,0,1) so the wrap-around pair re-seeds)
 //   next.b = a + b, next.c = c*c + d    (transition: degree 2 * z_last = 3), d boolean
 struct MixAir {
-    static constexpr int ID = 2, COLS = 4, PUB = 2, PERIODIC = 2, PERIOD_LOG = 2, QUOT_ROWS_PER_LANE = 2;
+    static constexpr int ID = 2, COLS = 4, PUB = 2, PERIODIC = 2, PERIOD_LOG = 2, QUOT_ROWS_PER_LANE = 2, AUX = 0, CHAL = 0, AUXPUB = 0;
+    static constexpr int plog(int) { return 2; }
     template <class F, class Row, class C>
-    VX_HD static void eval(const Row& loc, const Row& nxt, const F* per, const F* pub, C& c) {
+    VX_HD static void eval(const Row& loc, const Row& nxt, const F* per, const F* pub, const F*, const F*, C& c) {
         F a = loc[0], b = loc[1], cc = loc[2], d = loc[3];
         F s = per[0], k = per[1];
         F one = F::from(1);
@@ -226,5 +269,24 @@ struct MixAir {
         c.constraint(d * (d - one));
         c.first_row(a - pub[0]);
         c.last_row(b - pub[1]);
+    }
+};
+
+// ---- AIR 5: the smallest AIR with an auxiliary round (pins the logUp machinery; oracle/stark_ref.py LookupAir) ----
+// Main: two lookups per row (x0,y0,z0), (x1,y1,z1) claiming z = x ^ y on 4-bit values, and the multiplicity m of the
+// table row living in this trace row.  Table (ta, tb, ta ^ tb): periodic, period 2^8.  Challenges beta, gamma (X2).
+// Aux: h = 1/(beta+fp0) + 1/(beta+fp1), ht = m/(beta+fp_t), Z with Z(wx) = Z(x) + h(x) - ht(x) cyclically.
+struct LookupAir {
+    static constexpr int ID = 5, COLS = 7, PUB = 0, PERIODIC = 3, PERIOD_LOG = 8, QUOT_ROWS_PER_LANE = 1, AUX = 6, CHAL = 4, AUXPUB = 0;
+    static constexpr int plog(int) { return 8; }
+    template <class F, class Row, class C>
+    VX_HD static void eval(const Row& loc, const Row& nxt, const F* per, const F*, const F* chal, const F*, C& c) {
+        const X2<F> beta{chal[0], chal[1]}, gamma{chal[2], chal[3]}, g2 = gamma * gamma;
+        auto fp = [&](const F& a, const F& b, const F& cc) { return beta + a + gamma * b + g2 * cc; };
+        const X2<F> d0 = fp(loc[0], loc[1], loc[2]), d1 = fp(loc[3], loc[4], loc[5]), dt = fp(per[0], per[1], per[2]);
+        const X2<F> h{loc[7], loc[8]}, ht{loc[9], loc[10]}, z{loc[11], loc[12]}, zn{nxt[11], nxt[12]};
+        c.constraint_x2(h * d0 * d1 - d0 - d1);
+        c.constraint_x2(ht * dt - loc[6]);
+        c.constraint_x2(zn - z - h + ht);
     }
 };

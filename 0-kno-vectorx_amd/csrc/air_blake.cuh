@@ -59,10 +59,11 @@ VX_HD int rc_slot(int r) { return RC_SLOT_H[r]; }
 }  // namespace blk
 
 struct BlakeAir {
-    static constexpr int ID = 3, COLS = blk::COLS, PUB = 18, PERIODIC = 16, PERIOD_LOG = 4, QUOT_ROWS_PER_LANE = 1;  // 2 rows per lane: 266 VGPRs, 53 ms instead of 41
+    static constexpr int ID = 3, COLS = blk::COLS, PUB = 18, PERIODIC = 16, PERIOD_LOG = 4, QUOT_ROWS_PER_LANE = 1, AUX = 0, CHAL = 0, AUXPUB = 0;
+    static constexpr int plog(int) { return 4; }  // 2 rows per lane: 266 VGPRs, 53 ms instead of 41
 
     template <class F, class Row, class C>
-    __host__ __device__ static void eval(const Row& loc, const Row& nxt, const F* sel, const F* pub, C& c) {
+    __host__ __device__ static void eval(const Row& loc, const Row& nxt, const F* sel, const F* pub, const F*, const F*, C& c) {
         using namespace blk;
         const F one = F::from(1), two = F::from(2), two32 = F::from(1ULL << 32);
         F g_on = sel[0];

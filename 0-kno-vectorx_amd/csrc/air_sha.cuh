@@ -39,10 +39,11 @@ VX_HD constexpr uint32_t pad64(int j) { return j == 0 ? 0x80000000u : (j == 15 ?
 }  // namespace shc
 
 struct ShaAir {
-    static constexpr int ID = 4, COLS = shc::COLS, PUB = 8, PERIODIC = 4, PERIOD_LOG = 6, QUOT_ROWS_PER_LANE = 1;
+    static constexpr int ID = 4, COLS = shc::COLS, PUB = 8, PERIODIC = 4, PERIOD_LOG = 6, QUOT_ROWS_PER_LANE = 1, AUX = 0, CHAL = 0, AUXPUB = 0;
+    static constexpr int plog(int) { return 6; }
 
     template <class F, class Row, class C>
-    __host__ __device__ static void eval(const Row& loc, const Row& nxt, const F* per, const F* pub, C& c) {
+    __host__ __device__ static void eval(const Row& loc, const Row& nxt, const F* per, const F* pub, const F*, const F*, C& c) {
         using namespace shc;
         const F sel0 = per[0], sel63 = per[1], sched_on = per[2], kr = per[3];
         const F one = F::from(1), two = F::from(2), two32 = F::from(1ULL << 32);

@@ -183,6 +183,38 @@ __device__ bool decode_compact(const uint8_t* b, uint32_t* val, uint32_t* mode) 
     return true;
 }
 
+// decode_header (decoder.rs:104-157) of n encoded headers, one lane each: the same decode_compact / offset select the
+// map job below uses.  ok[i] = 0 where the mode-3 assertion (decoder.rs:83-89) fails.
+__global__ __launch_bounds__(64) void k_decode_headers(const uint8_t* headers, size_t stride, const uint32_t* sizes, size_t n, uint32_t* numbers,
+                                                       uint8_t* modes, uint8_t* ok, uint8_t* parents, uint8_t* state_roots, uint8_t* data_roots) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* hb = headers + i * stride;
+    const uint32_t sz = sizes[i];
+    uint32_t num = 0, mode = 0;
+    ok[i] = decode_compact(hb + 32, &num, &mode) ? 1 : 0;
+    numbers[i] = num;
+    modes[i] = (uint8_t)mode;
+    const int off = mode == 0 ? 33 : mode == 1 ? 34 : mode == 2 ? 36 : 37;
+    cp32(parents + 32 * i, hb);
+    cp32(state_roots + 32 * i, hb + off);
+    cp32(data_roots + 32 * i, hb + (sz == 0 ? 0 : sz - 32));
+}
+// decode_precommit (decoder.rs:159-200), one lane per 53-byte message
+__global__ __launch_bounds__(64) void k_decode_precommits(const uint8_t* pc, size_t n, uint8_t* ok, uint8_t* hashes, uint32_t* numbers, uint64_t* rounds,
+                                                          uint64_t* set_ids) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* p = pc + 53 * i;
+    ok[i] = p[0] == 1;  // :165-167
+    cp32(hashes + 32 * i, p + 1);
+    uint32_t bn = 0;
+    uint64_t r = 0, sid = 0;
+    for (int k = 0; k < 4; ++k) bn |= (uint32_t)p[33 + k] << (8 * k);
+    for (int k = 0; k < 8; ++k) r |= (uint64_t)p[37 + k] << (8 * k), sid |= (uint64_t)p[45 + k] << (8 * k);
+    numbers[i] = bn, rounds[i] = r, set_ids[i] = sid;
+}
+
 // blockDim.x = J (number of map jobs, power of two <= 1024); LDS: 2 * J * sizeof(MapOut)
 __global__ void k_subchain(const uint8_t* headers, size_t stride, const uint32_t* sizes, size_t n_fetched,
                            const uint8_t* digests, uint32_t global_start, uint32_t global_end, MapOut* result,
@@ -322,6 +354,61 @@ int32_t vx_sha256_pairs(vx_ctx* ctx, const uint8_t* pairs64, size_t n, uint8_t* 
                        (uint8_t*)(sc + n * 8));
     VX_HIP(hipGetLastError());
     VX_HIP(hipMemcpyAsync(out32, sc + n * 8, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipStreamSynchronize(ctx->stream));
+    return VX_OK;
+}
+
+int32_t vx_decode_header_batch(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n, uint32_t* numbers_out,
+                               uint8_t* modes_out, uint8_t* ok_out, uint8_t* parent_out, uint8_t* state_root_out, uint8_t* data_root_out) {
+    if (!ctx || !headers || !sizes || !numbers_out || !modes_out || !ok_out || !parent_out || !state_root_out || !data_root_out) return VX_ERR_ARG;
+    VX_CHECK(stride >= 72 && n >= 1 && n * stride <= headers->n * 8, "decode_header: %zu headers x %zu B exceed the buffer (stride >= 72)", n, stride);
+    for (size_t i = 0; i < n; ++i) VX_CHECK(sizes[i] <= stride && (sizes[i] == 0 || sizes[i] >= 32), "decode_header: header %zu has size %u", i, sizes[i]);
+    // device scratch: sizes | numbers | modes | ok | parents | state roots | data roots
+    const size_t w4 = (n * 4 + 7) / 8, w1 = (n + 7) / 8, w32 = n * 4;
+    uint64_t* sc;
+    VX_TRY(vx_scratch(ctx, 2 * w4 + 2 * w1 + 3 * w32, &sc));
+    uint32_t* d_sizes = (uint32_t*)sc;
+    uint32_t* d_num = (uint32_t*)(sc + w4);
+    uint8_t* d_mode = (uint8_t*)(sc + 2 * w4);
+    uint8_t* d_ok = (uint8_t*)(sc + 2 * w4 + w1);
+    uint8_t* d_par = (uint8_t*)(sc + 2 * w4 + 2 * w1);
+    uint8_t* d_sr = d_par + 32 * n;
+    uint8_t* d_dr = d_sr + 32 * n;
+    VX_HIP(hipMemcpyAsync(d_sizes, sizes, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_decode_headers, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, (const uint8_t*)headers->d, stride,
+                       (const uint32_t*)d_sizes, n, d_num, d_mode, d_ok, d_par, d_sr, d_dr);
+    VX_HIP(hipGetLastError());
+    VX_HIP(hipMemcpyAsync(numbers_out, d_num, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipMemcpyAsync(modes_out, d_mode, n, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipMemcpyAsync(ok_out, d_ok, n, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipMemcpyAsync(parent_out, d_par, 32 * n, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipMemcpyAsync(state_root_out, d_sr, 32 * n, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipMemcpyAsync(data_root_out, d_dr, 32 * n, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipStreamSynchronize(ctx->stream));
+    return VX_OK;
+}
+
+int32_t vx_decode_precommit_batch(vx_ctx* ctx, const uint8_t* precommits, size_t n, uint8_t* ok_out, uint8_t* hash_out, uint32_t* block_number_out,
+                                  uint64_t* round_out, uint64_t* set_id_out) {
+    if (!ctx || !precommits || !ok_out || !hash_out || !block_number_out || !round_out || !set_id_out) return VX_ERR_ARG;
+    VX_CHECK(n >= 1 && n <= (1u << 20), "decode_precommit: n %zu out of range", n);
+    const size_t w_in = (53 * n + 7) / 8, w1 = (n + 7) / 8, w4 = (n * 4 + 7) / 8;
+    uint64_t* sc;
+    VX_TRY(vx_scratch(ctx, w_in + w1 + 4 * n + w4 + 2 * n, &sc));
+    uint8_t* d_in = (uint8_t*)sc;
+    uint8_t* d_ok = (uint8_t*)(sc + w_in);
+    uint8_t* d_hash = (uint8_t*)(sc + w_in + w1);
+    uint32_t* d_bn = (uint32_t*)(sc + w_in + w1 + 4 * n);
+    uint64_t* d_round = sc + w_in + w1 + 4 * n + w4;
+    uint64_t* d_sid = d_round + n;
+    VX_HIP(hipMemcpyAsync(d_in, precommits, 53 * n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_decode_precommits, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, (const uint8_t*)d_in, n, d_ok, d_hash, d_bn, d_round, d_sid);
+    VX_HIP(hipGetLastError());
+    VX_HIP(hipMemcpyAsync(ok_out, d_ok, n, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipMemcpyAsync(hash_out, d_hash, 32 * n, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipMemcpyAsync(block_number_out, d_bn, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipMemcpyAsync(round_out, d_round, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
+    VX_HIP(hipMemcpyAsync(set_id_out, d_sid, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
     VX_HIP(hipStreamSynchronize(ctx->stream));
     return VX_OK;
 }

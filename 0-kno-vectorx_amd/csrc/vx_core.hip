@@ -185,6 +185,7 @@ int32_t vx_ctx_destroy(vx_ctx* ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->shift_tabs) hipFree(kv.second.d);
+    for (auto& kv : ctx->periodic_cache) hipFree(kv.second);
     for (auto& kv : ctx->tw2) hipFree(kv.second);
     hipFree(ctx->tw_fwd.d);
     hipFree(ctx->tw_inv.d);

@@ -68,6 +68,8 @@ struct vx_ctx {
     // a second context on the same device (own stream, scratch and pool), made on first use: independent small proofs
     // (the authority-set commitment STARKs) run on it from a host thread while this context proves the hash chain
     vx_ctx* side = nullptr;
+    // periodic columns of an AIR on the LDE coset, by (air id, degree bits, rate bits): identical for every proof of a shape
+    std::map<uint64_t, uint64_t*> periodic_cache;
 };
 vx_ctx* vx_side_ctx(vx_ctx* ctx);  // nullptr if it cannot be created
 void* vx_pool_alloc(vx_ctx* ctx, size_t bytes);
@@ -126,4 +128,8 @@ int32_t vx_lde_consume_dev(vx_ctx* ctx, uint64_t* values, int log_n, size_t n_co
 int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg, uint64_t* trace_d, size_t trace_len, int consume_trace,
                             int log_n, const uint64_t* public_inputs, size_t n_public, uint64_t* proof_out, size_t proof_cap,
                             size_t* proof_len);
+int32_t vx_lde_keep_dev(vx_ctx* ctx, const uint64_t* values, int log_n, size_t n_cols, int rate_bits, uint64_t shift, uint64_t* coef_brev,
+                        uint64_t* dst);
+int32_t vx_scan_cols_dev(vx_ctx* ctx, uint64_t* data, int log_n, size_t n_cols, uint64_t* totals_host);
+int32_t vx_lookup_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, uint64_t* aux, uint64_t* aux_pub);
 void vx_merkle_levels_launch(vx_ctx* ctx, uint64_t* levels, size_t n_leaves, size_t cap);

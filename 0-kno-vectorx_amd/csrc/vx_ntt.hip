@@ -608,6 +608,23 @@ int32_t vx_lde_consume_dev(vx_ctx* ctx, uint64_t* values, int log_n, size_t n_co
     return ntt_dit(ctx, values, n, dst, N, log_n + rate_bits, n_cols, 0, rate_bits, st.d);
 }
 
+// Values (kept intact) -> coefficients in bit-reversed positions (coef_brev, n*c) -> coset evaluations (dst, N*c).
+// What an AIR with an auxiliary round needs: the trace values are read again after the challenges are known, and the
+// coefficient buffer serves the openings at zeta.  The inverse transform's first pass simply writes elsewhere.
+int32_t vx_lde_keep_dev(vx_ctx* ctx, const uint64_t* values, int log_n, size_t n_cols, int rate_bits, uint64_t shift, uint64_t* coef_brev,
+                        uint64_t* dst) {
+    const size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    PowTab st{nullptr};
+    if (shift > 1) VX_TRY(vx_get_shift_tab(ctx, shift, &st));
+    if (log_n == 0) VX_HIP(hipMemcpyAsync(coef_brev, values, n_cols * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    else VX_TRY(ntt_dif(ctx, values, n, coef_brev, n, log_n, n_cols, 1, glh::inv((uint64_t)n % glh::P)));
+    if (log_n + rate_bits == 0) {
+        VX_HIP(hipMemcpyAsync(dst, coef_brev, n_cols * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return VX_OK;
+    }
+    return ntt_dit(ctx, coef_brev, n, dst, N, log_n + rate_bits, n_cols, 0, rate_bits, st.d);
+}
+
 int32_t vx_gather_rows_dev(vx_ctx* ctx, const uint64_t* lde, int log_N, size_t n_cols, const uint64_t* leaf_idx, size_t n_idx,
                            uint64_t* out) {
     if (n_idx == 0) return VX_OK;

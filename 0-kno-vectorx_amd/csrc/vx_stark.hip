@@ -112,10 +112,12 @@ struct QuotArgs {
     uint64_t alpha[2];
     uint64_t zh_inv[8];    // 1 / (g^n * w_{2^r}^k - 1), k < 2^r
     uint64_t zh[8];        // g^n * w_{2^r}^k - 1
-    const uint64_t* periodic;  // [PERIODIC][(1<<PERIOD_LOG) << rate_bits] on the LDE coset
+    const uint64_t* periodic;  // periodic column q on the LDE coset: (1 << (plog(q) + rate_bits)) values, columns back to back
     const uint64_t* pub;       // [PUB] (device)
     const uint64_t* tw;        // forward w_{2^32} power table
     const uint64_t* apow;      // [2K]: apow[2k + j] = alpha_j^(K-1-k), K = the AIR's constraint count (device)
+    uint64_t chal[8];          // auxiliary-round challenges (beta, gamma, ...)
+    uint64_t apub[8];          // values published with the auxiliary cap
 };
 
 #ifndef VX_Q_WAVES
@@ -127,11 +129,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_Q_WAVES,
     using F = FpN<R>;
     const size_t N = (size_t)1 << a.log_N;
     const size_t i0 = blockIdx.x * (size_t)(256 * R) + threadIdx.x;
-    const size_t step = (size_t)1 << a.rate_bits, plen = (size_t)1 << (Air::PERIOD_LOG + a.rate_bits);
+    const size_t step = (size_t)1 << a.rate_bits;
     Consumer<F> c;
     c.init(a.apow);
     RowViewN<R> loc{a.lde, N, {}}, nxt{a.lde, N, {}};
     F per[Air::PERIODIC > 0 ? Air::PERIODIC : 1], pub[Air::PUB > 0 ? Air::PUB : 1];
+    F chal[Air::CHAL > 0 ? Air::CHAL : 1], apub[Air::AUXPUB > 0 ? 2 * Air::AUXPUB : 1];
     uint64_t zinv[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
@@ -146,12 +149,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_Q_WAVES,
         zinv[j] = a.zh_inv[k];
         loc.i[j] = i;
         nxt.i[j] = (i + step) & (N - 1);
+        size_t poff = 0;
 #pragma unroll
-        for (int q = 0; q < Air::PERIODIC; ++q) per[q].v[j] = a.periodic[q * plen + (i & (plen - 1))];
+        for (int q = 0; q < Air::PERIODIC; ++q) {
+            const size_t plen = (size_t)1 << (Air::plog(q) + a.rate_bits);
+            per[q].v[j] = a.periodic[poff + (i & (plen - 1))];
+            poff += plen;
+        }
     }
 #pragma unroll
     for (int q = 0; q < Air::PUB; ++q) pub[q] = F::from(a.pub[q]);
-    Air::template eval<F>(loc, nxt, per, pub, c);
+#pragma unroll
+    for (int q = 0; q < Air::CHAL; ++q) chal[q] = F::from(a.chal[q]);
+#pragma unroll
+    for (int q = 0; q < 2 * Air::AUXPUB; ++q) apub[q] = F::from(a.apub[q]);
+    Air::template eval<F>(loc, nxt, per, pub, chal, apub, c);
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         a.q_out[loc.i[j]] = gl_mul(c.result(0, j), zinv[j]);
@@ -302,19 +314,23 @@ __global__ __launch_bounds__(256) void k_fri_combine(CombineArgs a) {
 }
 
 // ------------------------------------------------------------------ AIR registry
+typedef int32_t (*gen_aux_fn)(vx_ctx*, const uint64_t* trace, int log_n, const uint64_t* chal, uint64_t* aux, uint64_t* aux_pub);
 struct AirDesc {
     int id, cols, pub, periodic, period_log;
-    void (*periodic_values)(std::vector<uint64_t>&);  // [periodic][1 << period_log] values on the trace rows
+    void (*periodic_values)(std::vector<uint64_t>&);  // one period of every periodic column, back to back
     void (*launch)(QuotArgs&, hipStream_t);
     int (*count)();  // number of constraints eval pushes
+    int aux, chal, auxpub;  // auxiliary round: columns, base-field challenges, published extension values
+    int (*plog)(int);       // period (log2) of periodic column q
+    gen_aux_fn gen_aux;     // trace + challenges -> auxiliary columns [aux][n] (+ 2*auxpub published words, host)
 };
 template <class Air>
 static int count_q() {
     static const int k = [] {
         Consumer<CountF> c;
         CountRow r;
-        CountF per[Air::PERIODIC > 0 ? Air::PERIODIC : 1], pub[Air::PUB > 0 ? Air::PUB : 1];
-        Air::template eval<CountF>(r, r, per, pub, c);
+        CountF per[Air::PERIODIC > 0 ? Air::PERIODIC : 1], pub[Air::PUB > 0 ? Air::PUB : 1], chal[Air::CHAL > 0 ? Air::CHAL : 1], apub[Air::AUXPUB > 0 ? 2 * Air::AUXPUB : 1];
+        Air::template eval<CountF>(r, r, per, pub, chal, apub, c);
         return c.k;
     }();
     return k;
@@ -339,11 +355,17 @@ static void sha_periodic(std::vector<uint64_t>& v) {
     for (int r = 0; r <= 47; ++r) v[128 + r] = 1;  // schedule active
     for (int r = 0; r < 64; ++r) v[192 + r] = shc::K_H[r];
 }
+static void lookup_periodic(std::vector<uint64_t>& v) {
+    v.resize(3 * 256);
+    for (int i = 0; i < 256; ++i) v[i] = i & 15, v[256 + i] = i >> 4, v[512 + i] = (i & 15) ^ (i >> 4);
+}
+template <class Air>
+static AirDesc desc(void (*pv)(std::vector<uint64_t>&), gen_aux_fn ga = nullptr) {
+    return {Air::ID, Air::COLS, Air::PUB, Air::PERIODIC, Air::PERIOD_LOG, pv, launch_q<Air>, count_q<Air>, Air::AUX, Air::CHAL, Air::AUXPUB, Air::plog, ga};
+}
 static const AirDesc AIRS[] = {
-    {ShaAir::ID, ShaAir::COLS, ShaAir::PUB, ShaAir::PERIODIC, ShaAir::PERIOD_LOG, sha_periodic, launch_q<ShaAir>, count_q<ShaAir>},
-    {BlakeAir::ID, BlakeAir::COLS, BlakeAir::PUB, BlakeAir::PERIODIC, BlakeAir::PERIOD_LOG, blake_periodic, launch_q<BlakeAir>, count_q<BlakeAir>},
-    {FibAir::ID, FibAir::COLS, FibAir::PUB, FibAir::PERIODIC, FibAir::PERIOD_LOG, no_periodic, launch_q<FibAir>, count_q<FibAir>},
-    {MixAir::ID, MixAir::COLS, MixAir::PUB, MixAir::PERIODIC, MixAir::PERIOD_LOG, mix_periodic, launch_q<MixAir>, count_q<MixAir>},
+    desc<ShaAir>(sha_periodic), desc<BlakeAir>(blake_periodic), desc<FibAir>(no_periodic), desc<MixAir>(mix_periodic),
+    desc<LookupAir>(lookup_periodic, vx_lookup_air_gen_aux),
 };
 static const AirDesc* find_air(int id) {
     for (const AirDesc& d : AIRS)
@@ -415,7 +437,7 @@ static std::vector<int> fri_arity_plan(int degree_bits, const vx_stark_config& c
 
 struct DevMem;
 static int32_t quotient_eval_dev(vx_ctx* ctx, const AirDesc* air, int L, int r, const uint64_t* trace_lde, const uint64_t alphas[2],
-                                 const uint64_t* public_inputs, size_t n_public, uint64_t* qv, DevMem& mem);
+                                 const uint64_t* public_inputs, size_t n_public, const uint64_t* chal, const uint64_t* apub, uint64_t* qv, DevMem& mem);
 
 extern "C" {
 
@@ -434,9 +456,10 @@ int32_t vx_stark_default_config(vx_stark_config* cfg) {
 int32_t vx_stark_proof_bound(int air_id, const vx_stark_config* cfg, int log_n, size_t* n_words) {
     const AirDesc* air = find_air(air_id);
     if (!air || !cfg || !n_words || log_n < 2 || cfg->rate_bits < 1) return VX_ERR_ARG;
-    const size_t c = air->cols, nq = 4, LN = log_n + cfg->rate_bits, cap = (size_t)4 << cfg->cap_height;
+    const size_t c = (size_t)air->cols + air->aux, nq = 4, LN = log_n + cfg->rate_bits, cap = (size_t)4 << cfg->cap_height;
     const std::vector<int> ar = fri_arity_plan(log_n, *cfg);
     size_t per_query = c + nq + 2 * 4 * LN, words = 16 + ar.size() + air->pub + 2 * cap + 2 * (2 * c + nq) + ar.size() * cap + 1;
+    if (air->aux) per_query += 4 * LN, words += cap + 2 * (size_t)air->auxpub;  // the auxiliary tree: cap, published values, one more path
     size_t cur = LN;
     for (int a : ar) {
         per_query += 2 * (((size_t)1 << a) - 1) + 4 * cur;
@@ -452,13 +475,14 @@ int32_t vx_quotient_eval(vx_ctx* ctx, int air_id, int rate_bits, const vx_buf* t
     if (!ctx || !trace_lde || !alphas || !out) return VX_ERR_ARG;
     const AirDesc* air = find_air(air_id);
     VX_CHECK(air, "quotient eval: unknown AIR id %d", air_id);
+    VX_CHECK(air->aux == 0, "quotient eval: AIR %d has an auxiliary round (its challenges are not part of this entry point)", air_id);
     VX_CHECK(rate_bits >= 1 && rate_bits <= 3 && log_n >= 2 && log_n >= air->period_log && log_n + rate_bits <= 27, "quotient eval: bad log_n %d / rate_bits %d", log_n, rate_bits);
     VX_CHECK((int)n_public == air->pub && (n_public == 0 || public_inputs), "quotient eval: AIR %d takes %d public inputs", air_id, air->pub);
     const size_t N = (size_t)1 << (log_n + rate_bits);
     VX_CHECK(trace_lde->n >= N * (size_t)air->cols && out->n >= 2 * N, "quotient eval: buffers too small");
     VX_CHECK(alphas[0] < glh::P && alphas[1] < glh::P, "quotient eval: non-canonical challenge");
     DevMem mem{ctx};
-    return quotient_eval_dev(ctx, air, log_n, rate_bits, trace_lde->d, alphas, public_inputs, n_public, out->d, mem);
+    return quotient_eval_dev(ctx, air, log_n, rate_bits, trace_lde->d, alphas, public_inputs, n_public, nullptr, nullptr, out->d, mem);
 }
 
 int32_t vx_stark_prove(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_in, const vx_buf* trace, int log_n,
@@ -470,27 +494,66 @@ int32_t vx_stark_prove(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_in, c
 }  // extern "C"
 
 // compute_quotient_polys on the size-N coset g<w_N>: qv[k*N + i] = (sum_j alpha_k^(K-1-j) c_j(x_i)) / Z_H(x_i), k = 0, 1
+// The periodic columns of an AIR on the LDE coset (column q: (1 << (plog(q) + r)) values, back to back).  Short periods
+// are interpolated on the host; a long one (a 2^16-entry lookup table) goes through the device LDE with the coset
+// shift g^(n/p).  The table depends on (AIR, L, r) only, so it is built once per context and shape.
+static int32_t periodic_table_dev(vx_ctx* ctx, const AirDesc* air, int L, int r, const uint64_t** out) {
+    const uint64_t key = ((uint64_t)air->id << 16) | ((uint64_t)L << 8) | (uint64_t)r;
+    auto it = ctx->periodic_cache.find(key);
+    if (it != ctx->periodic_cache.end()) {
+        *out = it->second;
+        return VX_OK;
+    }
+    const size_t n = (size_t)1 << L;
+    std::vector<uint64_t> pv;
+    air->periodic_values(pv);
+    size_t total = 0, in_total = 0;
+    for (int q = 0; q < air->periodic; ++q) total += (size_t)1 << (air->plog(q) + r), in_total += (size_t)1 << air->plog(q);
+    VX_CHECK(pv.size() == in_total, "periodic table of AIR %d has %zu values, expected %zu", air->id, pv.size(), in_total);
+    uint64_t* d = nullptr;
+    VX_HIP(hipMalloc((void**)&d, total * 8));
+    std::vector<uint64_t> tab(total);
+    size_t off = 0, in_off = 0;
+    for (int q = 0; q < air->periodic; ++q) {
+        const int pl = air->plog(q);
+        const size_t p = (size_t)1 << pl, m = p << r;
+        const uint64_t shift_pow = glh::pow(7, n >> pl);
+        if (pl <= 6) {
+            periodic_on_coset(pv.data() + in_off, pl, r, shift_pow, tab.data() + off);
+            VX_HIP(hipMemcpyAsync(d + off, tab.data() + off, m * 8, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            uint64_t* tmp = (uint64_t*)vx_pool_alloc(ctx, p * 8);
+            if (!tmp) {
+                (void)hipFree(d);
+                return vx_fail(ctx, VX_ERR_OOM, "stark prove: out of device memory (periodic table)");
+            }
+            VX_HIP(hipMemcpyAsync(tmp, pv.data() + in_off, p * 8, hipMemcpyHostToDevice, ctx->stream));
+            int32_t rc = vx_lde_dev(ctx, tmp, pl, 1, r, shift_pow, VX_LDE_SRC_VALUES, d + off, nullptr);
+            VX_HIP(hipStreamSynchronize(ctx->stream));
+            vx_pool_free(ctx, tmp);
+            if (rc != VX_OK) {
+                (void)hipFree(d);
+                return rc;
+            }
+        }
+        off += m, in_off += p;
+    }
+    VX_HIP(hipStreamSynchronize(ctx->stream));  // tab / pv (host vectors) must outlive the copies
+    ctx->periodic_cache[key] = d;
+    *out = d;
+    return VX_OK;
+}
+
 static int32_t quotient_eval_dev(vx_ctx* ctx, const AirDesc* air, int L, int r, const uint64_t* trace_lde, const uint64_t alphas[2],
-                                 const uint64_t* public_inputs, size_t n_public, uint64_t* qv, DevMem& mem) {
+                                 const uint64_t* public_inputs, size_t n_public, const uint64_t* chal, const uint64_t* apub, uint64_t* qv, DevMem& mem) {
     const int LN = L + r;
     const size_t n = (size_t)1 << L;
     const uint64_t g = 7;
     uint64_t* d_pub = mem.alloc(n_public ? n_public : 1);
     VX_CHECK(d_pub, "stark prove: out of device memory (quotient)");
     if (n_public) VX_HIP(hipMemcpyAsync(d_pub, public_inputs, n_public * 8, hipMemcpyHostToDevice, ctx->stream));
-    uint64_t* d_per = nullptr;
-    if (air->periodic) {
-        std::vector<uint64_t> pv, tab;
-        air->periodic_values(pv);
-        const size_t p = (size_t)1 << air->period_log, m = p << r;
-        tab.resize(air->periodic * m);
-        const uint64_t shift_pow = glh::pow(g, n >> air->period_log);
-        for (int j = 0; j < air->periodic; ++j) periodic_on_coset(pv.data() + j * p, air->period_log, r, shift_pow, tab.data() + j * m);
-        d_per = mem.alloc(tab.size());
-        VX_CHECK(d_per, "stark prove: out of device memory (periodic)");
-        VX_HIP(hipMemcpyAsync(d_per, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        VX_HIP(hipStreamSynchronize(ctx->stream));
-    }
+    const uint64_t* d_per = nullptr;
+    if (air->periodic) VX_TRY(periodic_table_dev(ctx, air, L, r, &d_per));
     {
         QuotArgs qa{};
         qa.lde = trace_lde;
@@ -509,6 +572,8 @@ static int32_t quotient_eval_dev(vx_ctx* ctx, const AirDesc* air, int L, int r, 
         }
         qa.periodic = d_per;
         qa.pub = d_pub;
+        for (int q = 0; q < air->chal && q < 8; ++q) qa.chal[q] = chal[q];
+        for (int q = 0; q < 2 * air->auxpub && q < 8; ++q) qa.apub[q] = apub[q];
         qa.tw = ctx->tw_fwd.d;
         // powers of the two alphas for the K constraints (the Horner recurrence as a dot product, air.cuh)
         const int K = air->count();
@@ -546,8 +611,11 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
     VX_CHECK(L >= air->period_log && L >= 2 && LN <= 27, "stark prove: log_n %d out of range", L);
     VX_CHECK(cfg.cap_height >= 0 && cfg.cap_height <= LN, "stark prove: cap_height %d > log2(lde size) %d", cfg.cap_height, LN);
     VX_CHECK((int)n_public == air->pub && (n_public == 0 || public_inputs), "stark prove: AIR %d takes %d public inputs", air_id, air->pub);
-    const size_t n = (size_t)1 << L, N = (size_t)1 << LN, c = air->cols;
-    VX_CHECK(trace_len >= n * c, "stark prove: trace holds %zu < %zu elements", trace_len, n * c);
+    // c = every committed trace column (main ++ auxiliary); the first cm come from the caller, the other ca are derived
+    // after the lookup challenges are known
+    const size_t n = (size_t)1 << L, N = (size_t)1 << LN, cm = air->cols, ca = air->aux, c = cm + ca;
+    VX_CHECK(trace_len >= n * cm, "stark prove: trace holds %zu < %zu elements", trace_len, n * cm);
+    VX_CHECK(air->chal <= 8 && 2 * air->auxpub <= 8 && (ca == 0 || air->gen_aux), "stark prove: AIR %d auxiliary round is misconfigured", air_id);
     for (size_t i = 0; i < n_public; ++i) VX_CHECK(public_inputs[i] < glh::P, "stark prove: public input %zu not canonical", i);
     const int Q = 2, nq = 2 * Q;  // quotient_degree_factor 2 (constraint degree 3), 2 challenges
     const uint64_t g = 7;         // F::coset_shift()
@@ -557,10 +625,18 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
     // ---- 1. trace commitment: PolynomialBatch::from_values
     uint64_t* trace_lde = mem.alloc(N * c);
     VX_CHECK(trace_lde, "stark prove: out of device memory (trace LDE)");
-    if (consume_trace) VX_TRY(vx_lde_consume_dev(ctx, trace_d, L, c, r, g, trace_lde));
-    else VX_TRY(vx_lde_dev(ctx, trace_d, L, c, r, g, VX_LDE_SRC_VALUES, trace_lde, nullptr));
+    // coef_main: the main columns' coefficients in bit-reversed positions (openings at zeta as plain dot products)
+    uint64_t* coef_main = nullptr;
+    if (ca) {  // the trace values are needed again for the auxiliary columns: the inverse transform writes elsewhere
+        coef_main = mem.alloc(n * cm);
+        VX_CHECK(coef_main, "stark prove: out of device memory (coefficients)");
+        VX_TRY(vx_lde_keep_dev(ctx, trace_d, L, cm, r, g, coef_main, trace_lde));
+    } else if (consume_trace) {
+        VX_TRY(vx_lde_consume_dev(ctx, trace_d, L, cm, r, g, trace_lde));
+        coef_main = trace_d;
+    } else VX_TRY(vx_lde_dev(ctx, trace_d, L, cm, r, g, VX_LDE_SRC_VALUES, trace_lde, nullptr));
     vx_tree* t_trace = nullptr;
-    VX_TRY(vx_merkle_build_dev(ctx, trace_lde, N, c, VX_LEAVES_COLS_BITREV, cfg.cap_height, &t_trace));
+    VX_TRY(vx_merkle_build_dev(ctx, trace_lde, N, cm, VX_LEAVES_COLS_BITREV, cfg.cap_height, &t_trace));
     mem.trees.push_back(t_trace);
 
     const std::vector<int> arities = fri_arity_plan(L, cfg);
@@ -569,7 +645,7 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
     const size_t final_len = ((size_t)1 << final_log) >> r;
 
     proof.push_back(VX_PROOF_MAGIC);
-    for (uint64_t w : {(uint64_t)air_id, (uint64_t)L, (uint64_t)c, (uint64_t)nq, (uint64_t)r, (uint64_t)cfg.cap_height,
+    for (uint64_t w : {(uint64_t)air_id, (uint64_t)L, (uint64_t)cm, (uint64_t)nq, (uint64_t)r, (uint64_t)cfg.cap_height,
                        (uint64_t)cfg.num_queries, (uint64_t)cfg.pow_bits, (uint64_t)arities.size()})
         proof.push_back(w);
     for (int a : arities) proof.push_back((uint64_t)a);
@@ -582,13 +658,30 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
     Challenger ch;
     ch.observe(public_inputs, n_public);
     ch.observe(proof.data() + proof.size() - cap_words, cap_words);
+    // ---- 1b. auxiliary round (lookup arguments): challenges after the trace cap, derived columns in a second tree
+    uint64_t chal[8] = {0}, apub[8] = {0};
+    uint64_t* aux_d = nullptr;  // [ca][n]: values, then (after the in-place inverse NTT) coefficients in bit-reversed positions
+    vx_tree* t_aux = nullptr;
+    if (ca) {
+        for (int q = 0; q < air->chal; ++q) chal[q] = ch.challenge();
+        aux_d = mem.alloc(n * ca);
+        VX_CHECK(aux_d, "stark prove: out of device memory (auxiliary trace)");
+        VX_TRY(air->gen_aux(ctx, trace_d, L, chal, aux_d, apub));
+        VX_TRY(vx_lde_consume_dev(ctx, aux_d, L, ca, r, g, trace_lde + N * cm));
+        VX_TRY(vx_merkle_build_dev(ctx, trace_lde + N * cm, N, ca, VX_LEAVES_COLS_BITREV, cfg.cap_height, &t_aux));
+        mem.trees.push_back(t_aux);
+        for (int q = 0; q < 2 * air->auxpub; ++q) proof.push_back(apub[q]);
+        push_cap(ctx, t_aux, proof);
+        ch.observe(apub, 2 * (size_t)air->auxpub);
+        ch.observe(proof.data() + proof.size() - cap_words, cap_words);
+    }
     uint64_t alphas[2] = {ch.challenge(), 0};
     alphas[1] = ch.challenge();
 
     // ---- 2. quotient polynomials (compute_quotient_polys) on the size-N coset
     uint64_t* qv = mem.alloc(2 * N);
     VX_CHECK(qv, "stark prove: out of device memory (quotient)");
-    VX_TRY(quotient_eval_dev(ctx, air, L, r, trace_lde, alphas, public_inputs, n_public, qv, mem));
+    VX_TRY(quotient_eval_dev(ctx, air, L, r, trace_lde, alphas, public_inputs, n_public, chal, apub, qv, mem));
     // values on the coset -> coefficients (coset_ifft), split into Q chunks of n, commit (from_coeffs)
     VX_TRY(vx_ntt_dev(ctx, qv, LN, 2, N, 1, g, VX_ORDER_NATURAL));
     // chunk j of challenge k = qv[k*N + j*n .. +n): already contiguous as 2*Q columns of n coefficients
@@ -618,8 +711,8 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
                        gl2{zeta_next.a, zeta_next.b}, (const uint64_t*)ctx->tw_fwd.d, w0, w1);
     hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)((nq + BARY_CPB - 1) / BARY_CPB)), dim3(256), 0, ctx->stream, (const uint64_t*)quot_lde, N, r, n, (size_t)nq, (const uint64_t*)w0,
                        (const uint64_t*)w1, d_open + 4 * c);
-    if (consume_trace) {
-        // the trace buffer holds the coefficients (bit-reversed positions): plain evaluation, no barycentric factor
+    if (coef_main) {
+        // the coefficients are at hand (bit-reversed positions): plain evaluation, no barycentric factor
         PowBrevArgs pa{};
         pa.log_n = L;
         Ext z0 = zeta, z1 = zeta_next;
@@ -630,8 +723,11 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
             z1 = e_mul(z1, z1);
         }
         hipLaunchKernelGGL(k_pow_brev_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, pa, w0, w1);
-        hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)((c + BARY_CPB - 1) / BARY_CPB)), dim3(256), 0, ctx->stream, (const uint64_t*)trace_d, n, 0, n, c, (const uint64_t*)w0,
+        hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)((cm + BARY_CPB - 1) / BARY_CPB)), dim3(256), 0, ctx->stream, (const uint64_t*)coef_main, n, 0, n, cm, (const uint64_t*)w0,
                            (const uint64_t*)w1, d_open);
+        if (ca)
+            hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)((ca + BARY_CPB - 1) / BARY_CPB)), dim3(256), 0, ctx->stream, (const uint64_t*)aux_d, n, 0, n, ca, (const uint64_t*)w0,
+                               (const uint64_t*)w1, d_open + 4 * cm);
     } else {
         hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)((c + BARY_CPB - 1) / BARY_CPB)), dim3(256), 0, ctx->stream, (const uint64_t*)trace_lde, N, r, n, c, (const uint64_t*)w0,
                            (const uint64_t*)w1, d_open);
@@ -645,7 +741,7 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
     const Ext f1 = e_scale(e_sub(e_pow(zeta_next, n), Ext{gn_, 0}), fsc);  // ((w zeta)^n - g^n) / (n g^n)
     std::vector<Ext> o_local(c), o_next(c), o_quot(nq);
     const Ext one_{1, 0};
-    const Ext t0 = consume_trace ? one_ : f0, t1 = consume_trace ? one_ : f1;  // coefficient sums need no factor
+    const Ext t0 = coef_main ? one_ : f0, t1 = coef_main ? one_ : f1;  // coefficient sums need no factor
     for (size_t j = 0; j < c; ++j) {
         o_local[j] = e_mul(t0, Ext{h_open[4 * j], h_open[4 * j + 1]});
         o_next[j] = e_mul(t1, Ext{h_open[4 * j + 2], h_open[4 * j + 3]});
@@ -766,11 +862,13 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
     std::vector<uint64_t> qidx(nqr);
     for (size_t k = 0; k < nqr; ++k) qidx[k] = ch.challenge() % N;
     const int depth0 = LN - cfg.cap_height;
-    std::vector<uint64_t> rows_t(nqr * c), rows_q(nqr * nq), sib_t(nqr * depth0 * 4), sib_q(nqr * depth0 * 4);
-    VX_TRY(vx_gather_rows_dev(ctx, trace_lde, LN, c, qidx.data(), nqr, rows_t.data()));
+    std::vector<uint64_t> rows_t(nqr * cm), rows_a(nqr * ca), rows_q(nqr * nq), sib_t(nqr * depth0 * 4), sib_a(ca ? nqr * depth0 * 4 : 0), sib_q(nqr * depth0 * 4);
+    VX_TRY(vx_gather_rows_dev(ctx, trace_lde, LN, cm, qidx.data(), nqr, rows_t.data()));
+    if (ca) VX_TRY(vx_gather_rows_dev(ctx, trace_lde + N * cm, LN, ca, qidx.data(), nqr, rows_a.data()));
     VX_TRY(vx_gather_rows_dev(ctx, quot_lde, LN, nq, qidx.data(), nqr, rows_q.data()));
     if (depth0 > 0) {
         VX_TRY(vx_merkle_open(ctx, t_trace, qidx.data(), nqr, sib_t.data()));
+        if (ca) VX_TRY(vx_merkle_open(ctx, t_aux, qidx.data(), nqr, sib_a.data()));
         VX_TRY(vx_merkle_open(ctx, t_quot, qidx.data(), nqr, sib_q.data()));
     }
     std::vector<std::vector<uint64_t>> l_leaves(arities.size()), l_sibs(arities.size());
@@ -784,8 +882,12 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
         if (depth > 0) VX_TRY(vx_merkle_open(ctx, ltrees[l], lidx.data(), nqr, l_sibs[l].data()));
     }
     for (size_t k = 0; k < nqr; ++k) {
-        proof.insert(proof.end(), rows_t.begin() + k * c, rows_t.begin() + (k + 1) * c);
+        proof.insert(proof.end(), rows_t.begin() + k * cm, rows_t.begin() + (k + 1) * cm);
         proof.insert(proof.end(), sib_t.begin() + k * depth0 * 4, sib_t.begin() + (k + 1) * depth0 * 4);
+        if (ca) {
+            proof.insert(proof.end(), rows_a.begin() + k * ca, rows_a.begin() + (k + 1) * ca);
+            proof.insert(proof.end(), sib_a.begin() + k * depth0 * 4, sib_a.begin() + (k + 1) * depth0 * 4);
+        }
         proof.insert(proof.end(), rows_q.begin() + k * nq, rows_q.begin() + (k + 1) * nq);
         proof.insert(proof.end(), sib_q.begin() + k * depth0 * 4, sib_q.begin() + (k + 1) * depth0 * 4);
         uint64_t x_index = qidx[k];

@@ -112,11 +112,44 @@ bool fx_eq(Fx x, Fx y) { return x.a == y.a && x.b == y.b; }
 struct AirV {
     int id, cols, pub, periodic, period_log;
     void (*periodic_values)(std::vector<uint64_t>&);
-    void (*eval)(const HostRow&, const HostRow&, const Fx*, const Fx*, Consumer<Fx>&);
+    void (*eval)(const HostRow&, const HostRow&, const Fx*, const Fx*, const Fx*, const Fx*, Consumer<Fx>&);
+    int aux, chal, auxpub;
+    int (*plog)(int);
 };
 template <class Air>
-void eval_host(const HostRow& l, const HostRow& n, const Fx* per, const Fx* pub, Consumer<Fx>& c) {
-    Air::template eval<Fx>(l, n, per, pub, c);
+void eval_host(const HostRow& l, const HostRow& n, const Fx* per, const Fx* pub, const Fx* chal, const Fx* apub, Consumer<Fx>& c) {
+    Air::template eval<Fx>(l, n, per, pub, chal, apub, c);
+}
+template <class Air>
+AirV vdesc(void (*pv)(std::vector<uint64_t>&)) {
+    return {Air::ID, Air::COLS, Air::PUB, Air::PERIODIC, Air::PERIOD_LOG, pv, eval_host<Air>, Air::AUX, Air::CHAL, Air::AUXPUB, Air::plog};
+}
+// coefficients of P(Y), deg < p, with P(w_p^k) = v[k]: in-place radix-2 inverse NTT on the host (a 2^16-entry lookup
+// table is far too long for the O(p^2) sum the short selectors get away with)
+void host_intt(std::vector<uint64_t>& a) {
+    const size_t p = a.size();
+    int lg = 0;
+    while (((size_t)1 << lg) < p) ++lg;
+    for (size_t i = 0; i < p; ++i) {
+        size_t j = 0;
+        for (int b = 0; b < lg; ++b) j |= ((i >> b) & 1) << (lg - 1 - b);
+        if (j > i) std::swap(a[i], a[j]);
+    }
+    for (int st = 1; st <= lg; ++st) {
+        const size_t half = (size_t)1 << (st - 1);
+        const uint64_t wl = glh::inv(glh::root(st));
+        for (size_t blk = 0; blk < p; blk += 2 * half) {
+            uint64_t w = 1;
+            for (size_t k = 0; k < half; ++k) {
+                const uint64_t u = a[blk + k], t = glh::mul(a[blk + k + half], w);
+                a[blk + k] = glh::add(u, t);
+                a[blk + k + half] = glh::sub(u, t);
+                w = glh::mul(w, wl);
+            }
+        }
+    }
+    const uint64_t pinv = glh::inv(p % glh::P);
+    for (uint64_t& x : a) x = glh::mul(x, pinv);
 }
 void v_no_periodic(std::vector<uint64_t>& v) { v.clear(); }
 void v_mix_periodic(std::vector<uint64_t>& v) { v = {0, 0, 0, 1, 3, 5, 7, 11}; }
@@ -131,11 +164,13 @@ void v_sha_periodic(std::vector<uint64_t>& v) {
     for (int r = 0; r <= 47; ++r) v[128 + r] = 1;
     for (int r = 0; r < 64; ++r) v[192 + r] = shc::K_H[r];
 }
+void v_lookup_periodic(std::vector<uint64_t>& v) {
+    v.resize(3 * 256);
+    for (int i = 0; i < 256; ++i) v[i] = i & 15, v[256 + i] = i >> 4, v[512 + i] = (i & 15) ^ (i >> 4);
+}
 const AirV V_AIRS[] = {
-    {ShaAir::ID, ShaAir::COLS, ShaAir::PUB, ShaAir::PERIODIC, ShaAir::PERIOD_LOG, v_sha_periodic, eval_host<ShaAir>},
-    {FibAir::ID, FibAir::COLS, FibAir::PUB, FibAir::PERIODIC, FibAir::PERIOD_LOG, v_no_periodic, eval_host<FibAir>},
-    {MixAir::ID, MixAir::COLS, MixAir::PUB, MixAir::PERIODIC, MixAir::PERIOD_LOG, v_mix_periodic, eval_host<MixAir>},
-    {BlakeAir::ID, BlakeAir::COLS, BlakeAir::PUB, BlakeAir::PERIODIC, BlakeAir::PERIOD_LOG, v_blake_periodic, eval_host<BlakeAir>},
+    vdesc<ShaAir>(v_sha_periodic), vdesc<FibAir>(v_no_periodic), vdesc<MixAir>(v_mix_periodic), vdesc<BlakeAir>(v_blake_periodic),
+    vdesc<LookupAir>(v_lookup_periodic),
 };
 size_t brev(size_t x, int bits) {
     size_t r = 0;
@@ -167,7 +202,7 @@ int32_t vx_stark_verify(const vx_stark_config* cfg, const uint64_t* pr, size_t l
     NEED(have(10), "proof truncated (header)");
     NEED(pr[0] == 0x314b524154535856ULL, "bad magic");
     const int air_id = (int)pr[1], L = (int)pr[2];
-    const size_t c = pr[3], nq = pr[4];
+    const size_t nq = pr[4];
     const int r = (int)pr[5], cap_h = (int)pr[6];
     const size_t n_queries = pr[7];
     const int pow_bits = (int)pr[8];
@@ -179,6 +214,7 @@ int32_t vx_stark_verify(const vx_stark_config* cfg, const uint64_t* pr, size_t l
     for (const AirV& a : V_AIRS)
         if (a.id == air_id) air = &a;
     NEED(air && (expect_air == 0 || expect_air == air_id), "unexpected AIR %d", air_id);
+    const size_t cm = air->cols, ca = air->aux, c = cm + ca;  // main ++ auxiliary columns
     // FRI reduction plan (ConstantArityBits)
     std::vector<int> arities;
     {
@@ -197,7 +233,7 @@ int32_t vx_stark_verify(const vx_stark_config* cfg, const uint64_t* pr, size_t l
     const size_t n = (size_t)1 << L, N = (size_t)1 << LN;
     int final_log = LN;
     for (int a : arities) final_log -= a;
-    NEED(c == (size_t)air->cols && n_pub == (size_t)air->pub && nq == 4 && final_len == (((size_t)1 << final_log) >> r), "shape mismatch");
+    NEED(pr[3] == (uint64_t)air->cols && n_pub == (size_t)air->pub && nq == 4 && final_len == (((size_t)1 << final_log) >> r), "shape mismatch");
     // the proof is untrusted input: the shapes the prover refuses (vx_stark_prove_impl) are refused here too, so no
     // Merkle depth below can go negative (a crafted L = 2 proof used to reach v_merkle with n_sib = SIZE_MAX)
     NEED(r >= 1 && r <= 3 && cap_h >= 0 && LN >= cap_h && LN <= 27 && L >= air->period_log, "degree bits %d out of range for this AIR / cap height", L);
@@ -217,10 +253,17 @@ int32_t vx_stark_verify(const vx_stark_config* cfg, const uint64_t* pr, size_t l
         for (size_t i = 0; i < n_pub; ++i) NEED(pub[i] == expect_public[i], "public input %zu differs", i);
     }
     const size_t cap_words = (size_t)4 << cap_h;
-    NEED(have(2 * cap_words + 2 * (2 * c + nq)), "proof truncated (caps/openings)");
+    NEED(have((ca ? 3 : 2) * cap_words + 2 * (size_t)air->auxpub + 2 * (2 * c + nq)), "proof truncated (caps/openings)");
     const uint64_t* cap_t = pr + pos;
-    const uint64_t* cap_q = pr + pos + cap_words;
-    pos += 2 * cap_words;
+    pos += cap_words;
+    const uint64_t *apub = nullptr, *cap_a = nullptr;
+    if (ca) {
+        apub = pr + pos;
+        cap_a = pr + pos + 2 * (size_t)air->auxpub;
+        pos += 2 * (size_t)air->auxpub + cap_words;
+    }
+    const uint64_t* cap_q = pr + pos;
+    pos += cap_words;
     std::vector<Fx> o_local(c), o_next(c), o_quot(nq);
     for (size_t j = 0; j < c; ++j) o_local[j] = {pr[pos + 2 * j], pr[pos + 2 * j + 1]};
     pos += 2 * c;
@@ -232,6 +275,13 @@ int32_t vx_stark_verify(const vx_stark_config* cfg, const uint64_t* pr, size_t l
     VChallenger ch;
     ch.observe(pub, n_pub);
     ch.observe(cap_t, cap_words);
+    uint64_t chal[8] = {0};
+    if (ca) {  // auxiliary round: lookup challenges after the trace cap, then the published values and the second cap
+        NEED(air->chal <= 8 && 2 * air->auxpub <= 8, "AIR %d auxiliary round is misconfigured", air_id);
+        for (int q = 0; q < air->chal; ++q) chal[q] = ch.challenge();
+        ch.observe(apub, 2 * (size_t)air->auxpub);
+        ch.observe(cap_a, cap_words);
+    }
     const uint64_t alphas[2] = {ch.challenge(), ch.challenge()};
     ch.observe(cap_q, cap_words);
     const Fx zeta = ch.ext();
@@ -248,31 +298,29 @@ int32_t vx_stark_verify(const vx_stark_config* cfg, const uint64_t* pr, size_t l
         cons.z_last = zeta - Fx{last, 0};
         cons.l_first = zh * Fx{ninv, 0} * fx_inv(zeta - one);
         cons.l_last = zh * Fx{glh::mul(ninv, last), 0} * fx_inv(zeta - Fx{last, 0});
-        std::vector<Fx> per(air->periodic ? air->periodic : 1), pubx(n_pub ? n_pub : 1);
+        std::vector<Fx> per(air->periodic ? air->periodic : 1), pubx(n_pub ? n_pub : 1), chalx(8), apubx(8);
         if (air->periodic) {
             std::vector<uint64_t> pv;
             air->periodic_values(pv);
-            const size_t p = (size_t)1 << air->period_log;
-            const Fx y = fx_pow(zeta, n >> air->period_log);
-            const uint64_t wp_inv = glh::inv(glh::root(air->period_log)), pinv = glh::inv(p % glh::P);
+            size_t in_off = 0;
             for (int j = 0; j < air->periodic; ++j) {
-                std::vector<uint64_t> coef(p);
-                for (size_t k = 0; k < p; ++k) {
-                    uint64_t acc = 0, w = glh::pow(wp_inv, k), cur = 1;
-                    for (size_t i = 0; i < p; ++i) {
-                        acc = glh::add(acc, glh::mul(pv[j * p + i], cur));
-                        cur = glh::mul(cur, w);
-                    }
-                    coef[k] = glh::mul(acc, pinv);
-                }
+                const int pl = air->plog(j);
+                const size_t p = (size_t)1 << pl;
+                NEED(in_off + p <= pv.size(), "periodic table of AIR %d is short", air_id);
+                std::vector<uint64_t> coef(pv.begin() + in_off, pv.begin() + in_off + p);
+                host_intt(coef);
+                const Fx y = fx_pow(zeta, n >> pl);
                 Fx a{0, 0};
                 for (size_t k = p; k-- > 0;) a = a * y + Fx{coef[k], 0};
                 per[j] = a;
+                in_off += p;
             }
         }
         for (size_t i = 0; i < n_pub; ++i) pubx[i] = {pub[i], 0};
+        for (int q = 0; q < air->chal; ++q) chalx[q] = {chal[q], 0};
+        for (int q = 0; q < 2 * air->auxpub; ++q) apubx[q] = {apub[q], 0};
         HostRow loc{o_local.data()}, nxt{o_next.data()};
-        air->eval(loc, nxt, per.data(), pubx.data(), cons);
+        air->eval(loc, nxt, per.data(), pubx.data(), chalx.data(), apubx.data(), cons);
         for (int k = 0; k < 2; ++k) {
             const Fx q = o_quot[2 * k] + o_quot[2 * k + 1] * zn;
             NEED(fx_eq(cons.acc[k], zh * q), "constraint identity fails at zeta (challenge %d)", k);
@@ -316,18 +364,21 @@ int32_t vx_stark_verify(const vx_stark_config* cfg, const uint64_t* pr, size_t l
     const uint64_t wN = glh::root(LN);
     for (size_t qi = 0; qi < n_queries; ++qi) {
         size_t x_index = ch.challenge() % N;
-        NEED(have(c + nq + 8 * (size_t)depth0), "proof truncated (query %zu)", qi);
+        NEED(have(c + nq + (ca ? 12 : 8) * (size_t)depth0), "proof truncated (query %zu)", qi);
         const uint64_t* row_t = pr + pos;
-        const uint64_t* sib_t = row_t + c;
-        const uint64_t* row_q = sib_t + 4 * depth0;
+        const uint64_t* sib_t = row_t + cm;
+        const uint64_t* row_a = sib_t + 4 * depth0;
+        const uint64_t* sib_a = row_a + ca;
+        const uint64_t* row_q = ca ? sib_a + 4 * depth0 : row_a;
         const uint64_t* sib_q = row_q + nq;
-        pos += c + nq + 8 * (size_t)depth0;
-        NEED(v_merkle(row_t, c, x_index, sib_t, depth0, cap_t), "trace Merkle proof invalid (query %zu)", qi);
+        pos += c + nq + (ca ? 12 : 8) * (size_t)depth0;
+        NEED(v_merkle(row_t, cm, x_index, sib_t, depth0, cap_t), "trace Merkle proof invalid (query %zu)", qi);
+        if (ca) NEED(v_merkle(row_a, ca, x_index, sib_a, depth0, cap_a), "auxiliary Merkle proof invalid (query %zu)", qi);
         NEED(v_merkle(row_q, nq, x_index, sib_q, depth0, cap_q), "quotient Merkle proof invalid (query %zu)", qi);
         uint64_t x = glh::mul(7, glh::pow(wN, brev(x_index, LN)));
         Fx s1{0, 0}, ap{1, 0};
         for (size_t j = 0; j < c; ++j) {
-            s1 = s1 + ap * Fx{row_t[j], 0};
+            s1 = s1 + ap * Fx{j < cm ? row_t[j] : row_a[j - cm], 0};
             ap = ap * alpha;
         }
         Fx s0 = s1;

@@ -26,7 +26,7 @@ SYMBOLS = [
     "vx_blake2b_256_batch", "vx_sha256_pairs", "vx_verify_subchain", "vx_blake_chain_trace",
     "vx_ed25519_verify_batch", "vx_verify_simple_justification", "vx_sha_chain_trace",
     "vx_verify_epoch_end_header", "vx_rotate_proof_bound", "vx_rotate_prove", "vx_rotate_verify",
-    "vx_gather_proofs", "vx_quotient_eval",
+    "vx_gather_proofs", "vx_quotient_eval", "vx_decode_header_batch", "vx_decode_precommit_batch",
 ]
 
 VX_AIR_FIBONACCI, VX_AIR_MIX, VX_AIR_BLAKE_CHAIN = 1, 2, 3
@@ -123,6 +123,8 @@ def load_library():
         "vx_rotate_verify": [C.POINTER(StarkConfig), vp, sz, u64, vp, vp, C.c_char_p, sz],
         "vx_gather_proofs": [vp, vp, C.c_int, vp, sz, vp],
         "vx_quotient_eval": [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, sz, vp],
+        "vx_decode_header_batch": [vp, vp, sz, vp, sz, vp, vp, vp, vp, vp, vp],
+        "vx_decode_precommit_batch": [vp, vp, sz, vp, vp, vp, vp, vp],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -486,6 +488,23 @@ class Context:
         pc = np.frombuffer(bytes(just.precommit), dtype=np.uint8).copy()
         self._ck(self.L.vx_verify_simple_justification(self.h, block_number, _ptr(bh), set_id, _ptr(sh), _ptr(pc), _ptr(pk), _ptr(sg), _ptr(en),
                                                        just.num_authorities, mx))
+
+    def decode_headers(self, headers_buf, stride, sizes):
+        """decode_header of every header -> dict(number, mode, ok, parent, state_root, data_root) of numpy arrays."""
+        sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+        n = sizes.size
+        num, mode, ok = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+        par, sr, dr = (np.zeros((n, 32), dtype=np.uint8) for _ in range(3))
+        self._ck(self.L.vx_decode_header_batch(self.h, headers_buf.h, stride, _ptr(sizes), n, _ptr(num), _ptr(mode), _ptr(ok), _ptr(par), _ptr(sr), _ptr(dr)))
+        return dict(number=num, mode=mode, ok=ok, parent=par, state_root=sr, data_root=dr)
+
+    def decode_precommits(self, precommits):
+        pc = np.ascontiguousarray(np.frombuffer(b"".join(bytes(p) for p in precommits), dtype=np.uint8))
+        n = pc.size // 53
+        ok, h = np.zeros(n, dtype=np.uint8), np.zeros((n, 32), dtype=np.uint8)
+        bn, rnd, sid = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        self._ck(self.L.vx_decode_precommit_batch(self.h, _ptr(pc), n, _ptr(ok), _ptr(h), _ptr(bn), _ptr(rnd), _ptr(sid)))
+        return dict(ok=ok, hash=h, block_number=bn, round=rnd, set_id=sid)
 
     def verify_subchain(self, headers_buf, stride, sizes, max_headers, trusted_block, trusted_hash, target_block):
         sizes = np.ascontiguousarray(sizes, dtype=np.uint32)

@@ -39,3 +39,61 @@ def gather_blobs(blob, dist=None, device=None):
     out = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
     dist.gather(mine, out, dst=0)
     return [t.cpu().numpy() for t in out] if rank == 0 else None
+
+
+class RcclComm:
+    """A raw ncclComm_t (one rank per GPU) made with the RCCL copy PyTorch ships, for the C-ABI gather
+    `vx_gather_proofs` (include/vx.h).  The unique id travels over the already initialised torch.distributed group.
+    torch must have initialised the HIP runtime on `device` first (RCCL wants the runtime it was built with)."""
+
+    def __init__(self, dist, device):
+        import ctypes as C
+        import os
+
+        import torch
+
+        self.handle, self._lib = None, None
+        for name in ("librccl.so.1", "librccl.so", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")):
+            try:
+                self._lib = C.CDLL(name)
+                break
+            except OSError:
+                pass
+        if self._lib is None:
+            raise OSError("no RCCL library to make a communicator with")
+
+        class Uid(C.Structure):
+            _fields_ = [("b", C.c_char * 128)]
+
+        rank, world = dist.get_rank(), dist.get_world_size()
+        u = Uid()
+        if rank == 0 and self._lib.ncclGetUniqueId(C.byref(u)) != 0:
+            raise OSError("ncclGetUniqueId failed")
+        box = [bytes(u) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        C.memmove(C.byref(u), box[0], 128)
+        torch.cuda.set_device(device)
+        comm = C.c_void_p()
+        self._lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
+        rc = self._lib.ncclCommInitRank(C.byref(comm), world, u, rank)
+        if rc != 0:
+            raise OSError(f"ncclCommInitRank failed ({rc})")
+        self.handle, self.world = comm.value, world
+
+    def close(self):
+        if self.handle:
+            import ctypes as C
+
+            self._lib.ncclCommDestroy.argtypes = [C.c_void_p]
+            self._lib.ncclCommDestroy(C.c_void_p(self.handle))
+            self.handle = None
+
+
+def gather_blobs_abi(ctx, comm, blob):
+    """The same exchange through the exported C-ABI collective: all-gather of equal-length u64 blobs over RCCL on the
+    ctx stream.  Returns the list of blobs (rank order) on EVERY rank."""
+    words = np.ascontiguousarray(blob).view(np.uint8)
+    if words.size % 8:
+        words = np.concatenate([words, np.zeros(8 - words.size % 8, dtype=np.uint8)])
+    got = ctx.gather_proofs(comm.handle, comm.world, words.view(np.uint64))
+    return [got[r].view(np.uint8)[: np.asarray(blob).nbytes] for r in range(comm.world)]

@@ -157,6 +157,44 @@ def cpu_baseline(vx):
     }
 
 
+def launch_ranks(n_gpus, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run as a CHILD process (one
+    rank per GPU, rendezvous on 127.0.0.1) and exit with its code.  Nothing in this parent has touched the GPU or
+    imported torch, and it never execs: rank 0 of the child prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_launch(args):
+    """--dry-launch: the N > 1 control flow without a GPU -- every rank joins a gloo group and reports the launcher
+    environment it sees; rank 0 prints one JSON line (tests/test_bench_launch.py)."""
+    import torch.distributed as dist
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    seen = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "-1")), "world_size": world,
+            "master_addr": os.environ.get("MASTER_ADDR"), "headers": args.headers}
+    got = [seen]
+    if world > 1:
+        dist.init_process_group("gloo")
+        got = [None] * world
+        dist.all_gather_object(got, seen)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "gpus_arg": args.gpus, "ranks": got}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,9 +207,19 @@ def main():
                     help="proofs in flight per GPU (contexts + host threads; steps are handed out from one queue). Default: 2")
     ap.add_argument("--circuit", default="header_range", choices=("header_range", "rotate"),
                     help="header_range = the headline metric (default); rotate = BASELINE.json configs[3]")
+    ap.add_argument("--dry-launch", action="store_true", help="rehearse the multi-rank launch on CPU (gloo), no GPU work")
     args = ap.parse_args()
     global N_HEADERS
     N_HEADERS = args.headers
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:  # the driver's plain `python bench.py --gpus N`: become the launcher (no GPU touched here)
+            sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
+    if args.dry_launch:
+        return dry_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -236,6 +284,27 @@ def main():
             raise errs[0]
         return next(r for r in last if r is not None)
 
+    # the one collective goes through the exported C ABI (vx_gather_proofs, RCCL all-gather on the ctx stream) when every
+    # rank could make a raw communicator; otherwise through torch.distributed (same RCCL underneath) -- the line says which
+    comm, gather_kind = None, "none (1 rank)"
+    if dist and dist.get_backend() == "nccl":
+        import torch
+
+        try:
+            comm = vx.shard.RcclComm(dist, local_rank)
+            ok, why = 1, ""
+        except Exception as e:  # noqa: BLE001 -- reported in the JSON line
+            ok, why = 0, f"{type(e).__name__}: {e}"
+        flag = torch.tensor([ok], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            gather_kind = "vx_gather_proofs (C ABI, RCCL all-gather)"
+        else:
+            if comm:
+                comm.close()
+            comm, gather_kind = None, f"torch.distributed.gather (RCCL); raw communicator unavailable on some rank {why}".strip()
+    elif dist:
+        gather_kind = f"torch.distributed.gather ({dist.get_backend()})"
     for w in wls:  # W warmup steps on every context (pool, tables)
         for _ in range(args.warmup):
             w.step()
@@ -245,7 +314,7 @@ def main():
     blob = wl.blob(res)
     # the one collective: fixed-size result blobs to rank 0 over RCCL/xGMI
     tdev = "cuda" if dist and dist.get_backend() == "nccl" else ("cpu" if dist else None)
-    gathered = vx.shard.gather_blobs(blob, dist, device=tdev)
+    gathered = vx.shard.gather_blobs_abi(ctx, comm, blob) if comm else vx.shard.gather_blobs(blob, dist, device=tdev)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist:
@@ -263,7 +332,7 @@ def main():
             "metric": f"header_range_{N_HEADERS} proofs/sec", "value": round(world * args.steps / elapsed, 4), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks) / u8 (hashes)",
-            "data": "synthetic", "inflight_per_gpu": inflight,
+            "data": "synthetic", "inflight_per_gpu": inflight, "gather": gather_kind,
             "config": {
                 "workload": f"header_range_{N_HEADERS}: {N_HEADERS} x 15,360-B synthetic Avail headers (P15k), 300 authorities, one input per GPU; "
                             f"{120 * N_HEADERS:,} Blake2b compressions -> BlakeChainAir trace 2^{19 if N_HEADERS == 256 else 20} rows x {BLAKE_COLS} columns",
@@ -304,6 +373,8 @@ def main():
         elif not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline(vx)
         print(json.dumps(line), flush=True)
+    if comm:
+        comm.close()
     for c in ctxs:
         c.close()
     if dist:

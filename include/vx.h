@@ -158,7 +158,10 @@ typedef struct vx_stark_config {
     int32_t arity_bits;      /* ConstantArityBits(4, 5) */
     int32_t final_poly_bits;
 } vx_stark_config;
-enum { VX_AIR_FIBONACCI = 1, VX_AIR_MIX = 2 };
+/* AIRs are COMPILED INTO the library (there is no run-time AIR descriptor): 1 Fibonacci and 2 "cubic mixer" pin the
+ * generic prover, 5 is the smallest AIR with an auxiliary (lookup / logUp) commitment round; 3 / 4 below are the
+ * Blake2b header-chain and SHA-256 authority-commitment AIRs of the header_range statement. */
+enum { VX_AIR_FIBONACCI = 1, VX_AIR_MIX = 2, VX_AIR_LOOKUP = 5 };
 int32_t vx_stark_default_config(vx_stark_config* cfg);
 /* K5: batched constraint / quotient-polynomial evaluation (starky prover.rs compute_quotient_polys) for an AIR compiled
  * into the library.  trace_lde: column-major [cols][N], N = 2^(log_n + rate_bits), natural order, values on the coset
@@ -219,6 +222,19 @@ int32_t vx_sha_chain_trace(vx_ctx* ctx, const uint8_t* pubkeys, size_t n_keys, i
 int32_t vx_verify_subchain(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes,
                            size_t n_fetched, uint32_t max_headers, uint32_t trusted_block,
                            const uint8_t trusted_hash[32], uint32_t target_block, uint8_t out96[96]);
+
+/* ---- decoders on their own (test surface for the reference's literal vectors, decoder.rs:238-249 and :388-395).
+ * vx_decode_header_batch = decode_header (circuits/builder/decoder.rs:104-157) over n encoded headers in HBM (layout as
+ * vx_verify_subchain): block number and mode of the SCALE compact int at byte 32 (decode_compact_int, :39-92; all four
+ * modes), ok = 0 where the mode-3 upper-bits assertion (:83-89) fails, parent hash = bytes 0..32, state root at offset
+ * 33 / 34 / 36 / 37 by mode (:121-128), data root = the 32 bytes at size - 32, or at 0 for a size-0 padding header
+ * (:132-149).  Outputs are host arrays of n (x 32) entries.
+ * vx_decode_precommit_batch = decode_precommit (:159-200) over n 53-byte messages (host in / host out, device compute):
+ * ok = (byte 0 == 1), block hash [1..33), LE u32 block number, LE u64 round, LE u64 authority set id. */
+int32_t vx_decode_header_batch(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n, uint32_t* numbers_out,
+                               uint8_t* modes_out, uint8_t* ok_out, uint8_t* parent_out, uint8_t* state_root_out, uint8_t* data_root_out);
+int32_t vx_decode_precommit_batch(vx_ctx* ctx, const uint8_t* precommits, size_t n, uint8_t* ok_out, uint8_t* hash_out, uint32_t* block_number_out,
+                                  uint64_t* round_out, uint64_t* set_id_out);
 
 /* ---- justification, statement level (circuits/builder/justification.rs:195-257 and the hint's native
  * checks :29-83 -> circuits/input/mod.rs:241-260).  All byte arrays are host buffers.

@@ -126,6 +126,31 @@ class ExtS:
         return np.array([self.a, self.b], dtype=np.uint64)
 
 
+class X2:
+    """Element of the quadratic extension F[X]/(X^2 - 7) over ANY of the backends above (VecF, ExtS, ints):
+    lookup arguments run over the extension (challenges beta, gamma and the helper / running-sum columns are
+    extension elements stored as two base columns); a constraint on X2 values is two base constraints."""
+
+    __slots__ = ("a", "b")
+
+    def __init__(self, a, b=0):
+        self.a, self.b = a, b
+
+    def __add__(self, o):
+        return X2(self.a + o.a, self.b + o.b) if isinstance(o, X2) else X2(self.a + o, self.b)
+
+    def __sub__(self, o):
+        return X2(self.a - o.a, self.b - o.b) if isinstance(o, X2) else X2(self.a - o, self.b)
+
+    def __mul__(self, o):
+        if isinstance(o, X2):
+            return X2(self.a * o.a + 7 * (self.b * o.b), self.a * o.b + self.b * o.a)
+        return X2(self.a * o, self.b * o)
+
+    __radd__ = __add__
+    __rmul__ = __mul__
+
+
 class Consumer:
     """starky ConstraintConsumer: acc = acc * alpha + c, per challenge."""
 
@@ -144,6 +169,63 @@ class Consumer:
 
     def last_row(self, c):
         self.constraint(c * self.l_last)
+
+    def constraint_x2(self, e):
+        self.constraint(e.a)
+        self.constraint(e.b)
+
+
+def air_eval(air, loc, nxt, per, pub, cons, chal=None, aux_pub=None):
+    """AIRs without an auxiliary round keep the five-argument eval."""
+    if getattr(air, "AUX", 0):
+        air.eval(loc, nxt, per, pub, cons, chal, aux_pub)
+    else:
+        air.eval(loc, nxt, per, pub, cons)
+
+
+def period_logs(air):
+    return list(getattr(air, "PERIOD_LOGS", [air.PERIOD_LOG] * air.PERIODIC))
+
+
+def check_trace(air, trace, pub, chal=None, aux=None, aux_pub=None):
+    """Every constraint on every row of the trace domain, vectorised (the AIR's eval over VecF with x = w^i).
+    Returns None or (constraint index, first violating row)."""
+    tr = np.ascontiguousarray(trace, dtype=np.uint64)
+    if aux is not None:
+        tr = np.concatenate([tr, np.ascontiguousarray(aux, dtype=np.uint64)])
+    c, n = tr.shape
+    L = n.bit_length() - 1
+    w = O.root(L)
+    xs = np.empty(n, dtype=np.uint64)
+    acc = 1
+    for i in range(n):
+        xs[i] = acc
+        acc = acc * w % P
+    X = VecF(xs)
+    first = np.zeros(n, dtype=np.uint64)
+    last = np.zeros(n, dtype=np.uint64)
+    first[0] = last[n - 1] = 1
+
+    class Check(Consumer):
+        def __init__(self):
+            self.z_last, self.l_first, self.l_last = X - pow(w, P - 2, P), VecF(first), VecF(last)
+            self.k, self.bad = 0, None
+
+        def constraint(self, cc):
+            if self.bad is None:
+                v = cc.v if isinstance(cc, VecF) else np.full(n, int(cc) % P, dtype=np.uint64)
+                nz = np.flatnonzero(v)
+                if nz.size:
+                    self.bad = (self.k, int(nz[0]))
+            self.k += 1
+
+    cons = Check()
+    per = [VecF(np.tile(np.array(v, dtype=np.uint64), n // len(v))) for v in air.periodic_values()]
+    loc = [VecF(tr[j]) for j in range(c)]
+    nxt = [VecF(np.roll(tr[j], -1)) for j in range(c)]
+    air_eval(air, loc, nxt, per, [VecF.const(x, X) for x in pub], cons,
+             None if chal is None else [VecF.const(x, X) for x in chal], None if aux_pub is None else [VecF.const(x, X) for x in aux_pub])
+    return cons.bad
 
 
 # ----------------------------------------------------------------------------- AIRs (restated)
@@ -206,7 +288,79 @@ class MixAir:
         return t, [int(t[0, 0]), int(t[1, n - 1])]
 
 
-AIRS = {1: FibAir, 2: MixAir}
+class LookupAir:
+    """AIR 5: the smallest AIR with an auxiliary (challenge-dependent) round -- pins the logUp machinery.
+    Main columns: two lookups per row (x0, y0, z0), (x1, y1, z1) that claim z = x ^ y on 4-bit values, and the
+    multiplicity m of the table row that lives in the same trace row.  The table (ta, tb, tc = ta ^ tb), 256 entries,
+    is PERIODIC with period 2^8 (its own period, independent of the row selectors of other AIRs).
+    Challenges (after the trace cap): beta, gamma in the quadratic extension = 4 base elements.
+    Auxiliary columns (three extension elements = 6 base columns):
+        h  = 1/(beta + fp(x0,y0,z0)) + 1/(beta + fp(x1,y1,z1)),   fp(a,b,c) = a + gamma b + gamma^2 c
+        ht = m / (beta + fp(ta,tb,tc))
+        Z  : Z(w x) = Z(x) + h(x) - ht(x)   cyclically, which forces  sum_rows (h - ht) = 0   (logUp).
+    Every constraint has degree <= 3 and holds on the wrap-around pair too (no z_last)."""
+
+    ID, COLS, PUB, PERIODIC, PERIOD_LOG = 5, 7, 0, 3, 8
+    PERIOD_LOGS = [8, 8, 8]
+    AUX, CHAL, AUXPUB = 6, 4, 0
+
+    @staticmethod
+    def periodic_values():
+        idx = range(256)
+        return [[i & 15 for i in idx], [i >> 4 for i in idx], [(i & 15) ^ (i >> 4) for i in idx]]
+
+    @staticmethod
+    def eval(loc, nxt, per, pub, c, chal, aux_pub):
+        beta, gamma = X2(chal[0], chal[1]), X2(chal[2], chal[3])
+        g2 = gamma * gamma
+
+        def fp(a, b, cc):
+            return beta + a + gamma * b + g2 * cc
+
+        d0, d1 = fp(loc[0], loc[1], loc[2]), fp(loc[3], loc[4], loc[5])
+        dt = fp(per[0], per[1], per[2])
+        h, ht, z, zn = X2(loc[7], loc[8]), X2(loc[9], loc[10]), X2(loc[11], loc[12]), X2(nxt[11], nxt[12])
+        c.constraint_x2(h * d0 * d1 - d0 - d1)
+        c.constraint_x2(ht * dt - loc[6])
+        c.constraint_x2(zn - z - h + ht)
+
+    @staticmethod
+    def trace(log_n, seed=11):
+        n = 1 << log_n
+        assert n >= 256
+        rng = np.random.default_rng(seed)
+        t = np.zeros((7, n), dtype=np.uint64)
+        for k in range(2):
+            x, y = rng.integers(0, 16, n), rng.integers(0, 16, n)
+            t[3 * k], t[3 * k + 1], t[3 * k + 2] = x, y, x ^ y
+        counts = np.zeros(256, dtype=np.uint64)
+        for k in range(2):
+            np.add.at(counts, (t[3 * k] + 16 * t[3 * k + 1]).astype(np.int64), 1)
+        t[6, :256] = counts  # all multiplicity in the first copy of the periodic table
+        return t, []
+
+    @staticmethod
+    def gen_aux(trace, chal):
+        """-> (aux [6][n], aux_pub [])"""
+        n = trace.shape[1]
+        beta, gamma = ExtS(chal[0], chal[1]), ExtS(chal[2], chal[3])
+        g2 = gamma * gamma
+        tab = LookupAir.periodic_values()
+        aux = np.zeros((6, n), dtype=np.uint64)
+        z = ExtS(0)
+        tr = [[int(v) for v in trace[j]] for j in range(7)]
+        for i in range(n):
+            d0 = beta + tr[0][i] + gamma * tr[1][i] + g2 * tr[2][i]
+            d1 = beta + tr[3][i] + gamma * tr[4][i] + g2 * tr[5][i]
+            dt = beta + tab[0][i % 256] + gamma * tab[1][i % 256] + g2 * tab[2][i % 256]
+            h = d0.inv() + d1.inv()
+            ht = dt.inv() * tr[6][i]
+            aux[0, i], aux[1, i], aux[2, i], aux[3, i], aux[4, i], aux[5, i] = h.a, h.b, ht.a, ht.b, z.a, z.b
+            z = z + h - ht
+        return aux, []
+
+
+AIRS = {1: FibAir, 2: MixAir, 5: LookupAir}
 
 
 def register_air(air):
@@ -239,6 +393,18 @@ def periodic_poly_coeffs(values):
     return pyref.dft([int(v) % P for v in values], inverse=True)
 
 
+def periodic_on_lde(vals, L, r):
+    """Values of the periodic column with one period `vals` (length p) on the LDE coset g<w_N>, natural order:
+    P(Y) with P(w_p^k) = vals[k], at Y_i = x_i^(n/p) = g^(n/p) w_{p 2^r}^i -- a coset NTT of size p 2^r, tiled."""
+    p = len(vals)
+    n = 1 << L
+    co = O.ntt(np.array([[int(v) % P for v in vals]], dtype=np.uint64), inverse=True)[0]
+    pad = np.zeros((1, p << r), dtype=np.uint64)
+    pad[0, :p] = co
+    ev = O.ntt(pad, shift=pow(G, n // p, P))[0]
+    return np.tile(ev, n // p)
+
+
 def poly_eval_ext(coeffs, z):
     out = np.empty(2, dtype=np.uint64)
     _lib().vxo_poly_eval_ext(np.ascontiguousarray(coeffs, dtype=np.uint64), len(coeffs), z.arr(), out)
@@ -256,7 +422,7 @@ def _ext_challenge(ch):
 
 
 # ----------------------------------------------------------------------------- prover
-def quotient_values(air, lde_nat, pub, alphas, L, r):
+def quotient_values(air, lde_nat, pub, alphas, L, r, chal=None, aux_pub=None):
     """starky compute_quotient_polys on the coset: lde_nat [c][N] (natural order) -> [2][N] values
     (sum_j alpha_k^(K-1-j) c_j(x)) / Z_H(x), the Horner recurrence of ConstraintConsumer."""
     c = lde_nat.shape[0]
@@ -281,19 +447,9 @@ def quotient_values(air, lde_nat, pub, alphas, L, r):
     cons = Consumer([VecF.const(a, X) for a in alphas], X - last, l_first, l_last, VecF.const(0, X))
     loc = [VecF(lde_nat[j]) for j in range(c)]
     nxt = [VecF(np.roll(lde_nat[j], -(1 << r))) for j in range(c)]
-    per = []
-    if air.PERIODIC:
-        p = 1 << air.PERIOD_LOG
-        Y = X
-        for _ in range(L - air.PERIOD_LOG):
-            Y = Y * Y  # x^(n/p)
-        for vals in air.periodic_values():
-            co = periodic_poly_coeffs(vals)
-            a_ = VecF.const(0, X)
-            for k in range(p - 1, -1, -1):
-                a_ = a_ * Y + co[k]
-            per.append(a_)
-    air.eval(loc, nxt, per, [VecF.const(x, X) for x in pub], cons)
+    per = [VecF(periodic_on_lde(vals, L, r)) for vals in air.periodic_values()] if air.PERIODIC else []
+    air_eval(air, loc, nxt, per, [VecF.const(x, X) for x in pub], cons,
+             None if chal is None else [VecF.const(x, X) for x in chal], None if aux_pub is None else [VecF.const(x, X) for x in aux_pub])
     qvals = np.stack([(cons.acc[k] * zh_inv).v for k in range(2)])
     return qvals
 
@@ -308,6 +464,7 @@ def prove(air, trace, public_inputs, cfg=None):
     cap_h, nq = cfg["cap_height"], 4
     assert c == air.COLS and len(public_inputs) == air.PUB
     pub = [int(x) % P for x in public_inputs]
+    c_aux = getattr(air, "AUX", 0)
 
     # 1. trace commitment (PolynomialBatch::from_values)
     leaves_t, coeffs_t = O.lde_from_values(trace, r, G)
@@ -322,12 +479,32 @@ def prove(air, trace, public_inputs, cfg=None):
     if pub:
         ch.observe(np.array(pub, dtype=np.uint64))
     ch.observe(tree_t.cap.reshape(-1))
+    # 1b. auxiliary round (lookup arguments): challenges after the trace cap, helper / running-sum columns committed
+    # in a second tree before the constraint challenges are drawn
+    chal = aux_pub = None
+    if c_aux:
+        chal = [ch.challenge() for _ in range(air.CHAL)]
+        aux, aux_pub = air.gen_aux(trace, chal)
+        aux = np.ascontiguousarray(aux, dtype=np.uint64)
+        aux_pub = [int(x) % P for x in aux_pub]
+        assert aux.shape == (c_aux, n) and len(aux_pub) == 2 * air.AUXPUB
+        leaves_a, coeffs_a = O.lde_from_values(aux, r, G)
+        tree_a = O.MerkleTree(leaves_a, cap_h)
+        proof += aux_pub + [int(x) for x in tree_a.cap.reshape(-1)]
+        if aux_pub:
+            ch.observe(np.array(aux_pub, dtype=np.uint64))
+        ch.observe(tree_a.cap.reshape(-1))
+        leaves_t_all = np.concatenate([leaves_t, leaves_a], axis=1)
+        coeffs_t = np.concatenate([coeffs_t, coeffs_a])
+    else:
+        leaves_t_all = leaves_t
     alphas = [ch.challenge(), ch.challenge()]
+    c_main, c = c, c + c_aux  # from here on "trace" = main ++ auxiliary columns
 
     # 2. quotient polys on the coset g*<w_N>, natural order (compute_quotient_polys)
     perm = bitrev_perm(LN)
-    lde_nat = leaves_t[perm].T.copy()  # [c][N], lde_nat[:, i] = values at g*w_N^i
-    qvals = quotient_values(air, lde_nat, pub, alphas, L, r)
+    lde_nat = leaves_t_all[perm].T.copy()  # [c][N], lde_nat[:, i] = values at g*w_N^i
+    qvals = quotient_values(air, lde_nat, pub, alphas, L, r, chal, aux_pub)
     qcoef = O.ntt(qvals, inverse=True, shift=G)  # coset_ifft
     chunks = qcoef.reshape(nq, n)  # flat_map(|q| q.chunks(degree))
     leaves_q = O.lde_from_coeffs(chunks, r, G)
@@ -399,6 +576,8 @@ def prove(air, trace, public_inputs, cfg=None):
     for _ in range(cfg["num_queries"]):
         x_index = ch.challenge() % N
         proof += [int(v) for v in leaves_t[x_index]] + [int(v) for v in tree_t.prove(x_index).reshape(-1)]
+        if c_aux:
+            proof += [int(v) for v in leaves_a[x_index]] + [int(v) for v in tree_a.prove(x_index).reshape(-1)]
         proof += [int(v) for v in leaves_q[x_index]] + [int(v) for v in tree_q.prove(x_index).reshape(-1)]
         for l, a in enumerate(arities):
             arity = 1 << a
@@ -445,6 +624,7 @@ def verify(proof, cfg=None, expect_air=None, expect_public=None):
     final_len, n_pub = take(2)
     pub = take(n_pub)
     _need(c == air.COLS and n_pub == air.PUB and nq == 4, "shape mismatch")
+    c_aux = getattr(air, "AUX", 0)
     _need(all(0 <= v < P for v in pr), "non-canonical field element in proof")
     if expect_public is not None:
         _need(pub == [int(x) % P for x in expect_public], "public inputs differ")
@@ -454,7 +634,12 @@ def verify(proof, cfg=None, expect_air=None, expect_public=None):
     _need(2 <= L <= 26 and LN >= cap_h and L >= air.PERIOD_LOG, "degree bits out of range for this AIR / cap height")
     cap_words = 4 << cap_h
     cap_t = np.array(take(cap_words), dtype=np.uint64).reshape(-1, 4)
+    aux_pub, cap_a = None, None
+    if c_aux:
+        aux_pub = take(2 * air.AUXPUB)
+        cap_a = np.array(take(cap_words), dtype=np.uint64).reshape(-1, 4)
     cap_q = np.array(take(cap_words), dtype=np.uint64).reshape(-1, 4)
+    c_main, c = c, c + c_aux
 
     def take_ext(k):
         w = take(2 * k)
@@ -465,6 +650,12 @@ def verify(proof, cfg=None, expect_air=None, expect_public=None):
     if pub:
         ch.observe(np.array(pub, dtype=np.uint64))
     ch.observe(cap_t.reshape(-1))
+    chal = None
+    if c_aux:
+        chal = [ch.challenge() for _ in range(air.CHAL)]
+        if aux_pub:
+            ch.observe(np.array(aux_pub, dtype=np.uint64))
+        ch.observe(cap_a.reshape(-1))
     alphas = [ch.challenge(), ch.challenge()]
     ch.observe(cap_q.reshape(-1))
     zeta = _ext_challenge(ch)
@@ -479,15 +670,11 @@ def verify(proof, cfg=None, expect_air=None, expect_public=None):
     l_last = zh * (ninv * last % P) * (zeta - last).inv()
     cons = Consumer([ExtS(a) for a in alphas], zeta - last, l_first, l_last, ExtS(0))
     per = []
-    if air.PERIODIC:
-        y = zeta ** (n >> air.PERIOD_LOG)
-        for vals in air.periodic_values():
-            co = periodic_poly_coeffs(vals)
-            a_ = ExtS(0)
-            for k in range(len(co) - 1, -1, -1):
-                a_ = a_ * y + co[k]
-            per.append(a_)
-    air.eval(o_local, o_next, per, [ExtS(x) for x in pub], cons)
+    for vals in (air.periodic_values() if air.PERIODIC else []):
+        co = O.ntt(np.array([[int(v) % P for v in vals]], dtype=np.uint64), inverse=True)[0]  # P(Y), P(w_p^k) = vals[k]
+        per.append(poly_eval_ext(co, zeta ** (n // len(vals))))
+    air_eval(air, o_local, o_next, per, [ExtS(x) for x in pub], cons, None if chal is None else [ExtS(x) for x in chal],
+             None if aux_pub is None else [ExtS(x) for x in aux_pub])
     zeta_n = zeta ** n
     for k in range(2):
         # vanishing(zeta) == Z_H(zeta) * reduce_with_powers(chunks, zeta^n)
@@ -524,11 +711,16 @@ def verify(proof, cfg=None, expect_air=None, expect_public=None):
     wN = O.root(LN)
     for _ in range(n_queries):
         x_index = ch.challenge() % N
-        row_t = take(c)
+        row_t = take(c_main)
         sib_t = np.array(take(4 * depth0), dtype=np.uint64).reshape(-1, 4)
+        _need(O.merkle_verify(np.array(row_t, dtype=np.uint64), x_index, sib_t, cap_t), "trace Merkle proof invalid")
+        if c_aux:
+            row_a = take(c_aux)
+            sib_a = np.array(take(4 * depth0), dtype=np.uint64).reshape(-1, 4)
+            _need(O.merkle_verify(np.array(row_a, dtype=np.uint64), x_index, sib_a, cap_a), "auxiliary Merkle proof invalid")
+            row_t = row_t + row_a
         row_q = take(nq)
         sib_q = np.array(take(4 * depth0), dtype=np.uint64).reshape(-1, 4)
-        _need(O.merkle_verify(np.array(row_t, dtype=np.uint64), x_index, sib_t, cap_t), "trace Merkle proof invalid")
         _need(O.merkle_verify(np.array(row_q, dtype=np.uint64), x_index, sib_q, cap_q), "quotient Merkle proof invalid")
         x = G * pow(wN, pyref.bitrev(x_index, LN), P) % P
         s1, ap = ExtS(0), ExtS(1)

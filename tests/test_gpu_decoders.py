@@ -1,0 +1,110 @@
+"""The reference's own decoder vectors, and every arm of the SCALE compact decoder, through the HIP path
+(VERDICT r1 weak-2 / next-1): /root/reference circuits/builder/decoder.rs:238-249 (compact-int table) and :388-395
+(encoded precommit), committed as data in tests/golden/decoder_vectors.json.  Each case is run on the GPU
+(vx_decode_header_batch / vx_decode_precommit_batch / vx_verify_subchain) and through the C oracle, and both must
+give the reference's expected values."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+STRIDE = 512
+
+
+def header_with_number(vx, number, size=200, compact=None, seed=1):
+    enc = vx.synth.compact_u32(number) if compact is None else compact
+    body = bytes((seed * 31 + 7 * i) & 0xFF for i in range(size - 32 - len(enc)))
+    return hashlib.sha256(b"p%d" % seed).digest() + enc + body
+
+
+def test_compact_int_reference_vectors_on_gpu(ctx, vx, oracle):
+    vec = json.load(open(os.path.join(GOLD, "decoder_vectors.json")))["compact_int"]
+    hdrs = [header_with_number(vx, v, size=150 + 13 * k, seed=k) for k, (v, _) in enumerate(vec)]
+    # + a size-0 padding header (decoder.rs:135-138: data root read at offset 0) and the rejected mode 3 (:83-89)
+    hdrs.append(b"")
+    hdrs.append(header_with_number(vx, 0, compact=bytes([0x07, 1, 0, 0, 0]), seed=99))
+    hdrs.append(header_with_number(vx, 0, compact=bytes([0xFF, 0xFF, 0xFF, 0xFF, 0xFF]), seed=98))
+    buf = np.zeros((len(hdrs), STRIDE), dtype=np.uint8)
+    for i, h in enumerate(hdrs):
+        buf[i, : len(h)] = np.frombuffer(h, dtype=np.uint8)
+    sizes = [len(h) for h in hdrs]
+    got = ctx.decode_headers(ctx.from_host(buf), STRIDE, sizes)
+    offs = {0: 33, 1: 34, 2: 36, 3: 37}
+    for i, (value, mode) in enumerate(vec):
+        assert (int(got["number"][i]), int(got["mode"][i]), int(got["ok"][i])) == (value, mode, 1), (i, value)
+        assert got["parent"][i].tobytes() == hdrs[i][:32]
+        assert got["state_root"][i].tobytes() == hdrs[i][offs[mode]: offs[mode] + 32]
+        assert got["data_root"][i].tobytes() == hdrs[i][-32:]
+    k = len(vec)
+    assert int(got["number"][k]) == 0 and got["data_root"][k].tobytes() == bytes(32) and got["state_root"][k].tobytes() == bytes(32)
+    assert int(got["ok"][k + 1]) == 0 and int(got["mode"][k + 1]) == 3 and int(got["number"][k + 1]) == 1
+    assert int(got["ok"][k + 2]) == 0 and int(got["number"][k + 2]) == 0xFFFFFFFF
+    # the oracle agrees cell for cell (including the rejected ones)
+    for i in range(len(hdrs)):
+        rc, bn, par, sr, dr = oracle.decode_header(buf[i], sizes[i])
+        assert (rc == 0) == bool(got["ok"][i]) and bn == int(got["number"][i])
+        assert par == got["parent"][i].tobytes() and sr == got["state_root"][i].tobytes() and dr == got["data_root"][i].tobytes()
+
+
+def test_precommit_reference_vector_on_gpu(ctx, oracle):
+    vec = json.load(open(os.path.join(GOLD, "decoder_vectors.json")))["precommit"]
+    good = bytes(vec["bytes"])
+    bad = bytes([0]) + good[1:]
+    other = bytes([1]) + bytes(range(52))
+    got = ctx.decode_precommits([good, bad, other])
+    assert [int(x) for x in got["ok"]] == [1, 0, 1]
+    assert int(got["block_number"][0]) == vec["block_number"] == 317857 and int(got["set_id"][0]) == vec["authority_set_id"] == 298
+    assert int(got["round"][0]) == 14923 and got["hash"][0].tobytes() == good[1:33]
+    for i, pc in enumerate((good, bad, other)):
+        rc, h, bn, rnd, sid = oracle.decode_precommit(pc)
+        assert (rc == 0) == bool(got["ok"][i])
+        assert (h, bn, rnd, sid) == (got["hash"][i].tobytes(), int(got["block_number"][i]), int(got["round"][i]), int(got["set_id"][i])) or rc != 0
+
+
+@pytest.mark.parametrize("trusted", [60, 16380, (1 << 30) - 4, (1 << 30) + 5, (1 << 32) - 10, 0])
+def test_verify_subchain_across_compact_mode_boundaries(ctx, vx, oracle, trusted):
+    """Chains whose block numbers straddle 63/64, 16383/16384, 2^30-1/2^30 (and sit wholly in mode 3 / mode 0): every arm
+    of the state-root offset select (vx_chain.hip, decoder.rs:121-128) runs on the GPU inside verify_subchain; outputs
+    equal the oracle's and the hashlib mirror's."""
+    n = 8
+    ch = vx.synth.Chain(n, profile="Ptiny", stride=STRIDE, trusted_block=trusted)
+    modes = {len(vx.synth.compact_u32(trusted + 1 + i)) for i in range(n)}
+    if trusted in (60, 16380, (1 << 30) - 4):
+        assert len(modes) == 2  # the chain really crosses a boundary
+    hb = ctx.from_host(ch.headers)
+    out = ctx.verify_subchain(hb, STRIDE, ch.sizes, 8, ch.trusted_block, ch.trusted_hash, ch.target_block)
+    rc, want = oracle.verify_subchain(ch.headers, ch.sizes, 8, ch.trusted_block, ch.trusted_hash, ch.target_block)
+    assert rc == 0 and out == want == ch.expected_outputs(8)
+    d = ctx.decode_headers(hb, STRIDE, ch.sizes)
+    assert [int(x) for x in d["number"]] == list(range(trusted + 1, trusted + 1 + n))
+    assert [r.tobytes() for r in d["state_root"]] == ch.state_roots and [r.tobytes() for r in d["data_root"]] == ch.data_roots
+
+
+def test_mode3_header_with_upper_bits_is_rejected_by_verify_subchain(ctx, vx, oracle):
+    """decoder.rs:83-89: a 5-byte compact int whose first byte carries length bits must fail the statement."""
+    ch = vx.synth.Chain(8, profile="Ptiny", stride=STRIDE, trusted_block=(1 << 30) + 100)
+    h = ch.headers.copy()
+    assert h[3, 32] == 3
+    h[3, 32] = 0x07  # mode 3, upper six bits = 1
+    # re-link the chain after the edit so that ONLY the compact assertion is violated
+    parent = hashlib.blake2b(h[3, : ch.sizes[3]].tobytes(), digest_size=32).digest()
+    for i in range(4, 8):
+        h[i, :32] = np.frombuffer(parent, dtype=np.uint8)
+        parent = hashlib.blake2b(h[i, : ch.sizes[i]].tobytes(), digest_size=32).digest()
+    with pytest.raises(vx.VxError) as e:
+        ctx.verify_subchain(ctx.from_host(h), STRIDE, ch.sizes, 8, ch.trusted_block, ch.trusted_hash, ch.target_block)
+    assert e.value.code == -5 and "0x10" in str(e.value)  # ST_COMPACT only
+    assert oracle.verify_subchain(h, ch.sizes, 8, ch.trusted_block, ch.trusted_hash, ch.target_block)[0] != 0
+
+
+def test_blake_chain_air_number_range_is_pinned(ctx, vx):
+    """Known deviation (include/vx.h): the hash-chain AIR covers 4-byte-mode block numbers [2^14, 2^30) only --
+    decoder.rs:39-92 accepts all four modes natively.  The error is an argument error, not a wrong proof."""
+    ch = vx.synth.Chain(8, profile="Ptiny", stride=STRIDE, trusted_block=60)
+    with pytest.raises(vx.VxError) as e:
+        ctx.blake_chain_trace(ctx.from_host(ch.headers), STRIDE, ch.sizes, ch.trusted_hash, ch.trusted_block + 1, 9)
+    assert e.value.code == -1 and "4-byte SCALE compact range" in str(e.value)

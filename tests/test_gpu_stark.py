@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("air,log_n", [(S.FibAir, 5), (S.FibAir, 6), (S.FibAir, 9), (S.FibAir, 13), (S.MixAir, 4), (S.MixAir, 6),
-                                        (S.MixAir, 10), (S.MixAir, 14)])
+                                        (S.MixAir, 10), (S.MixAir, 14), (S.LookupAir, 8), (S.LookupAir, 9), (S.LookupAir, 13)])
 def test_proof_bytes_match_reference_prover(ctx, oracle, air, log_n):
     trace, pub = air.trace(log_n)
     got = ctx.stark_prove(air.ID, ctx.from_host(trace), log_n, pub)
@@ -69,3 +69,28 @@ def test_quotient_eval_primitive_matches_reference(ctx, vx, oracle, air_name, lo
     want = S.quotient_values(air, lde_nat, [int(x) % P for x in pub], alphas, log_n, r)
     got = ctx.quotient_eval(air.ID, r, ctx.from_host(np.ascontiguousarray(lde_nat)), log_n, alphas, pub)
     assert (got == want).all()
+
+
+def test_lookup_air_broken_multiplicity_is_rejected(ctx, vx, oracle):
+    """The auxiliary (logUp) round on the GPU: a wrong multiplicity or a tuple outside the table gives a proof that
+    BOTH verifiers reject."""
+    A = S.LookupAir
+    tr, pub = A.trace(10)
+    cfg, pcfg = dict(S.DEFAULT_CFG, num_queries=9), ctx.stark_config(num_queries=9)
+    good = ctx.stark_prove(A.ID, ctx.from_host(tr), 10, pub, pcfg)
+    S.verify(good, cfg, expect_air=A.ID)
+    vx.lib.stark_verify(good, pcfg, expect_air=A.ID)
+    for col, row in ((6, 5), (5, 700)):
+        bad = tr.copy()
+        bad[col, row] = bad[col, row] ^ np.uint64(1)
+        pr = ctx.stark_prove(A.ID, ctx.from_host(bad), 10, pub, pcfg)
+        with pytest.raises(S.VerifyError):
+            S.verify(pr, cfg)
+        with pytest.raises(vx.VxError):
+            vx.lib.stark_verify(pr, pcfg)
+    # tampering with the auxiliary cap or an auxiliary opening is caught too
+    for w in (14 + 16 * 4 + 3, 14 + 2 * 16 * 4 + 2 * 9):
+        bad = good.copy()
+        bad[w] ^= np.uint64(1)
+        with pytest.raises(vx.VxError):
+            vx.lib.stark_verify(bad, pcfg)

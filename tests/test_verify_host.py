@@ -12,7 +12,7 @@ from oracle import stark_ref as S
 S.register_air(B.BlakeChainAir)
 
 
-@pytest.mark.parametrize("air,log_n", [(S.FibAir, 5), (S.FibAir, 10), (S.MixAir, 6), (S.MixAir, 9)])
+@pytest.mark.parametrize("air,log_n", [(S.FibAir, 5), (S.FibAir, 10), (S.MixAir, 6), (S.MixAir, 9), (S.LookupAir, 8), (S.LookupAir, 11)])
 def test_accepts_reference_proofs_and_rejects_tampering(vx, oracle, air, log_n):
     trace, pub = air.trace(log_n)
     proof = S.prove(air, trace, pub)
@@ -25,7 +25,7 @@ def test_accepts_reference_proofs_and_rejects_tampering(vx, oracle, air, log_n):
     with pytest.raises(vx.VxError):
         vx.lib.stark_verify(proof[:-1])
     with pytest.raises(vx.VxError):
-        vx.lib.stark_verify(proof, expect_public=[pub[0] + 1] + list(pub[1:]))
+        vx.lib.stark_verify(proof, expect_public=([pub[0] + 1] + list(pub[1:])) if len(pub) else [1])
     with pytest.raises(vx.VxError):
         vx.lib.stark_verify(proof, expect_air=air.ID + 1)
     with pytest.raises(vx.VxError):
