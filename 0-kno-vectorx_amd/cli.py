@@ -138,7 +138,7 @@ def cmd_build(vx, name, args):
     os.makedirs(args.build_dir, exist_ok=True)
     cfg = vx.lib.default_stark_config()
     desc = {"entrypoint": name, "circuit": kind, "max_headers": n, "backend": "libvxprove (gfx950)",
-            "stark_config": {f: getattr(cfg, f) for f, _ in cfg._fields_}, "airs": {"blake_chain": [3, vx.lib.VX_BLAKE_AIR_COLS], "sha_chain": [4, vx.lib.VX_SHA_AIR_COLS]}}
+            "stark_config": {f: getattr(cfg, f) for f, _ in cfg._fields_}, "airs": {"blake_chain": [vx.lib.VX_AIR_BLAKE_CHAIN, vx.lib.VX_BLAKE_AIR_COLS, vx.lib.VX_BLAKE_AIR_AUX_COLS], "sha_chain": [4, vx.lib.VX_SHA_AIR_COLS]}}
     path = os.path.join(args.build_dir, name + ".circuit.json")
     json.dump(desc, open(path, "w"), indent=1)
     print(f"[vx] wrote {path}")

@@ -1,15 +1,18 @@
-// BlakeChainAir (AIR id 3): BLAKE2b-256 parent-hash chain over a sequence of encoded headers --
-// the hash-chain core of verify_subchain (/root/reference
-// circuits/builder/subchain_verification.rs:150-177: hash_encoded_header + parent-hash link;
-// circuits/builder/header.rs:14-19 curta_blake2b_variable).  The reference proves Blake2b with
-// curta's byte-lookup STARK (starkyx v1.0.0, not vendored); this AIR is a from-scratch
-// bit-decomposed ARX arithmetisation of RFC 7693, degree <= 3, 16 rows per compression:
-//   r = 0 INIT (out-state = initial work vector), r = 1..12 ROUND (row r holds round r-1's eight
-//   G evaluations), r = 13 FIN1 (T = H ^ v_lo, V' = v_hi, bits of H), r = 14 FIN2 (bits of h_out = T ^ V'),
-//   r = 15 PAD (H = next h_in, digest register D updated).
-// Columns: 8 G x 8 words x 64 bits, 64 carries, 32 message-schedule limbs, 64 range-check bits,
-// H register (16 limbs; its bits only in free G cells of rows 13/14), digest register D (8 limbs), flags, byte counter, block number,
-// zero-padding mask (8 mask bits + running count per row).
+// BlakeChainAir (AIR id 6): BLAKE2b-256 parent-hash chain over a sequence of encoded headers -- the hash-chain core of
+// verify_subchain (/root/reference circuits/builder/subchain_verification.rs:150-177: hash_encoded_header + parent-hash
+// link; circuits/builder/header.rs:14-19 curta_blake2b_variable; block numbering decoder.rs:64-66,
+// subchain_verification.rs:166-168).  The reference proves Blake2b with curta's byte-lookup STARK (starkyx v1.0.0, not
+// vendored); this is a from-scratch byte-lookup arithmetisation of RFC 7693 in the same spirit: every 64-bit word is
+// 8 byte cells, XORs are lookups into 2^16-row tables through a logUp argument (auxiliary commitment round), additions
+// are 32-bit limb identities, rotations by 32 / 24 / 16 are byte re-indexings and the rotation by 63 is carried by a
+// (low 7 bits, top bit) split of the XOR bytes.  731 main + 268 auxiliary columns (the bit-decomposed AIR it replaces
+// had 4337), degree <= 3, 16 rows per compression:
+//   r = 0 INIT (out-state = initial work vector), r = 1..12 ROUND (row r holds round r-1's eight G evaluations),
+//   r = 13 FIN1 (U = v_lo ^ v_hi), r = 14 FIN2 (h_out = U ^ h), r = 15 PAD (H = next h_in, digest register D updated).
+// Per G nine groups of 8 cells: A1 D1 C1 B1 A2 D2 C2 L T with
+//   A1 = a + b + x, D1 = (d ^ A1) >>> 32, C1 = c + D1, B1 = (b ^ C1) >>> 24, A2 = A1 + B1 + y, D2 = (D1 ^ A2) >>> 16,
+//   C2 = C1 + D2, (L, T) = (low 7 bits, top bit) of each byte of B1 ^ C2;  byte j of B2 = (B1 ^ C2) >>> 63 is 2 L[j] + T[j-1].
+// Tables (periodic, period 2^16, row i = (a = i & 255, b = i >> 8)): T1 (a, b, a ^ b), T2 (a, b, (a ^ b) & 127, (a ^ b) >> 7).
 // Constraint ORDER is protocol: oracle/blake_air.py restates it independently.
 #pragma once
 #include <type_traits>
@@ -18,27 +21,18 @@
 #include "blake_tables.h"
 
 namespace blk {
-constexpr int W_A1 = 0, W_D1 = 1, W_C1 = 2, W_B1 = 3, W_A2 = 4, W_D2 = 5, W_C2 = 6, W_B2 = 7;
-constexpr int CAR0 = 4096, MS0 = 4160, MB0 = 4192, HL0 = 4256, D0 = 4272;
-constexpr int ACT = 4280, FIN = 4281, FIRST = 4282, CAP = 4283, T = 4284, INC = 4285, TB0 = 4286, IB0 = 4318, NUM = 4326, FA = 4327, MK0 = 4328, CNT = 4336, COLS = 4337;
-VX_HD constexpr int GB(int k, int w, int i) { return (k * 8 + w) * 64 + i; }
-VX_HD constexpr int CAR(int k, int j) { return CAR0 + k * 8 + j; }
+constexpr int S_A1 = 0, S_D1 = 1, S_C1 = 2, S_B1 = 3, S_A2 = 4, S_D2 = 5, S_C2 = 6, S_L = 7, S_T = 8;
+constexpr int CAR0 = 576, MS0 = 608, MB0 = 640, HL0 = 648, D0 = 664;
+constexpr int ACT = 672, FIN = 673, FIRST = 674, CAP = 675, T = 676, INC = 677, NUM = 678, FA = 679;
+constexpr int TB0 = 680, IB0 = 712, MK0 = 720, CNT = 728, M1 = 729, M2 = 730, COLS = 731;
+constexpr int N_HELP = 134, HM0 = 128, HT = 132, ZZ = 133, AUX = 2 * N_HELP, TABLE_LOG = 16;
+VX_HD constexpr int GC(int k, int slot, int j) { return (k * 9 + slot) * 8 + j; }
+VX_HD constexpr int CAR(int k, int q) { return CAR0 + 4 * k + q; }
 VX_HD constexpr int MS(int s, int h) { return MS0 + 2 * s + h; }
-VX_HD constexpr int HL(int w, int h) { return HL0 + 2 * w + h; }  // chaining value as 16 limbs
-// free G cells of the finalisation rows: row 13 holds T = H ^ v_lo (FT), V' = v_hi (FV), the bits of H (FH);
-// row 14 holds the bits of h_out (FT)
-VX_HD constexpr int FT(int w, int i) { return GB(w % 4, w / 4, i); }
-VX_HD constexpr int FV(int w, int i) { return GB(w % 4, 2 + w / 4, i); }
-VX_HD constexpr int FH(int w, int i) { return GB(w % 4, 4 + w / 4, i); }
-// first bit column of out-state word v[w] (the diagonal-step outputs of a row)
-VX_HD constexpr int OUT(int w) {
-    return w < 4 ? GB(4 + w, W_A2, 0)
-         : w < 8 ? GB(4 + ((w & 3) + 3) % 4, W_B2, 0)
-         : w < 12 ? GB(4 + ((w & 3) + 2) % 4, W_C2, 0)
-                  : GB(4 + ((w & 3) + 1) % 4, W_D2, 0);
-}
+VX_HD constexpr int HL(int w, int h) { return HL0 + 2 * w + h; }
+VX_HD constexpr int AX(int e, int comp) { return COLS + 2 * e + comp; }  // component of auxiliary extension element e
 #define BLK_IV_INIT {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL, \
-                     0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL}
+                    0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL}
 // the tables exist twice -- in device memory for the kernels, in host memory for the verifier
 static __device__ const uint64_t IV[8] = BLK_IV_INIT;
 static __device__ const uint8_t ORDER[16][16] = BLK_ORDER_INIT;
@@ -56,178 +50,198 @@ VX_HD uint64_t iv(int i) { return IV_H[i]; }
 VX_HD int ms_src(int r, int s) { return MS_SRC_H[r][s]; }
 VX_HD int rc_slot(int r) { return RC_SLOT_H[r]; }
 #endif
+
+// b0 + 2^8 b1 + 2^16 b2 + 2^24 b3 for arbitrary field elements (on the LDE coset a "byte" cell is any element).
+// Device: a 128-bit integer sum of shifted words and ONE reduction instead of three modular multiplications.
+template <class F>
+VX_HD F limb4(const F& b0, const F& b1, const F& b2, const F& b3) {
+    if constexpr (is_device_field<F>::value) {
+        F r;
+#pragma unroll
+        for (int j = 0; j < F::LANES; ++j) {
+            uint64_t lo = b0.v[j], hi = 0, t;
+            bool cy;
+            t = b1.v[j] << 8, cy = __builtin_add_overflow(lo, t, &lo), hi += (b1.v[j] >> 56) + (cy ? 1 : 0);
+            t = b2.v[j] << 16, cy = __builtin_add_overflow(lo, t, &lo), hi += (b2.v[j] >> 48) + (cy ? 1 : 0);
+            t = b3.v[j] << 24, cy = __builtin_add_overflow(lo, t, &lo), hi += (b3.v[j] >> 40) + (cy ? 1 : 0);
+            r.v[j] = gl_reduce128(hi, lo);
+        }
+        return r;
+    } else {
+        const F k = F::from(256);
+        return ((b3 * k + b2) * k + b1) * k + b0;
+    }
+}
 }  // namespace blk
 
 struct BlakeAir {
-    static constexpr int ID = 3, COLS = blk::COLS, PUB = 18, PERIODIC = 16, PERIOD_LOG = 4, QUOT_ROWS_PER_LANE = 1, AUX = 0, CHAL = 0, AUXPUB = 0;
-    static constexpr int plog(int) { return 4; }  // 2 rows per lane: 266 VGPRs, 53 ms instead of 41
+    static constexpr int ID = 6, COLS = blk::COLS, PUB = 18, PERIODIC = 20, PERIOD_LOG = 16, QUOT_ROWS_PER_LANE = 1, AUX = blk::AUX, CHAL = 4, AUXPUB = 0;
+    static constexpr int plog(int q) { return q < 16 ? 4 : 16; }
 
     template <class F, class Row, class C>
-    __host__ __device__ static void eval(const Row& loc, const Row& nxt, const F* sel, const F* pub, const F*, const F*, C& c) {
+    __host__ __device__ static void eval(const Row& loc, const Row& nxt, const F* per, const F* pub, const F* chal, const F*, C& c) {
         using namespace blk;
-        const F one = F::from(1), two = F::from(2), two32 = F::from(1ULL << 32);
+        const F* sel = per;
+        const F one = F::from(1), two = F::from(2), two32 = F::from(1ULL << 32), inv32 = F::from(0xFFFFFFFE00000002ULL);  // 2^-32 mod p
         F g_on = sel[0];
         for (int r = 1; r < 12; ++r) g_on = g_on + sel[r];
         auto at = [&](int which, int col) -> F { return which ? nxt[col] : loc[col]; };
-        auto xorf = [&](F x, F y) -> F {  // x + y - 2xy (the doubling as an addition: a modular add is a third of a multiply)
-            const F xy = x * y;
-            return x + y - (xy + xy);
-        };
-        auto limb = [&](int which, int col0, int h) -> F {  // sum_i 2^i x_i over the 32 cells of one limb
-            if constexpr (is_device_field<F>::value) {
-                // device: the low and high halves of the 32 cells accumulate as plain integers (each sum < 2^64),
-                // one multiply-add by 2^i per half; a single reduction at the end
-                uint64_t lo[F::LANES], hi[F::LANES];
-#pragma unroll
-                for (int j = 0; j < F::LANES; ++j) lo[j] = hi[j] = 0;
-#pragma unroll 8
-                for (int i = 0; i < 32; ++i) {
-                    const F x = at(which, col0 + 32 * h + i);
-#pragma unroll
-                    for (int j = 0; j < F::LANES; ++j) {
-                        lo[j] += (uint64_t)(uint32_t)x.v[j] * (uint32_t)(1u << i);
-                        hi[j] += (x.v[j] >> 32) * (uint32_t)(1u << i);
-                    }
-                }
-                // lo + hi 2^32 = (lo + (hi << 32) mod 2^64) + ((hi >> 32) + carry) 2^64
-                F r;
-#pragma unroll
-                for (int j = 0; j < F::LANES; ++j) {
-                    uint64_t low;
-                    const bool cy = __builtin_add_overflow(lo[j], hi[j] << 32, &low);
-                    r.v[j] = gl_reduce128((hi[j] >> 32) + (cy ? 1 : 0), low);
-                }
-                return r;
-            } else {
-                F acc = at(which, col0 + 32 * h + 31);
-                for (int i = 30; i >= 0; --i) acc = acc + acc + at(which, col0 + 32 * h + i);
-                return acc;
+        // byte j of out-state word v[w] (the diagonal-step outputs) of the local (which = 0) / next row
+        auto out_byte = [&](int which, int w, int j) -> F {
+            const int m = w & 3;
+            if (w < 4) return at(which, GC(4 + w, S_A2, j));
+            if (w < 8) {
+                const int k = 4 + (m + 3) % 4;
+                const F l = at(which, GC(k, S_L, j));
+                return l + l + at(which, GC(k, S_T, (j + 7) & 7));
             }
+            if (w < 12) return at(which, GC(4 + (m + 2) % 4, S_C2, j));
+            return at(which, GC(4 + (m + 1) % 4, S_D2, j));
+        };
+        // byte j of operand op (0 a, 1 b, 2 c, 3 d) of G number k of the round held in the next row
+        auto in_byte = [&](int k, int op, int j) -> F {
+            if (k < 4) return out_byte(0, 4 * op + k, j);
+            const int j0 = k - 4;
+            if (op == 0) return nxt[GC(j0, S_A2, j)];
+            if (op == 1) {
+                const int kb = (j0 + 1) & 3;
+                const F l = nxt[GC(kb, S_L, j)];
+                return l + l + nxt[GC(kb, S_T, (j + 7) & 7)];
+            }
+            if (op == 2) return nxt[GC((j0 + 2) & 3, S_C2, j)];
+            return nxt[GC((j0 + 3) & 3, S_D2, j)];
+        };
+        auto limb_in = [&](int k, int op, int h) -> F { return limb4(in_byte(k, op, 4 * h), in_byte(k, op, 4 * h + 1), in_byte(k, op, 4 * h + 2), in_byte(k, op, 4 * h + 3)); };
+        auto limb_cells = [&](int which, int k, int slot, int h) -> F {
+            return limb4(at(which, GC(k, slot, 4 * h)), at(which, GC(k, slot, 4 * h + 1)), at(which, GC(k, slot, 4 * h + 2)), at(which, GC(k, slot, 4 * h + 3)));
         };
         auto boolean = [&](int col) {
-            F x = loc[col];
+            const F x = loc[col];
             c.constraint(x * (x - one));
         };
         // ---- 1. booleans
-#ifndef VX_Q_UNROLL
-#define VX_Q_UNROLL 4
-#endif
-#pragma unroll VX_Q_UNROLL
-        for (int col = 0; col < 4096; ++col) boolean(col);
-#pragma unroll 1
-        for (int col = MB0; col < MB0 + 64; ++col) boolean(col);
 #pragma unroll 1
         for (int col = TB0; col < TB0 + 32; ++col) boolean(col);
 #pragma unroll 1
         for (int col = IB0; col < IB0 + 8; ++col) boolean(col);
+#pragma unroll 1
+        for (int col = MK0; col < MK0 + 8; ++col) boolean(col);
         boolean(ACT);
         boolean(FIN);
         boolean(FIRST);
         boolean(CAP);
         boolean(FA);
-        // ---- 2. carries
+        // ---- 2. carries of the three-operand additions
 #pragma unroll 1
-        for (int k = 0; k < 8; ++k)
+        for (int col = CAR0; col < CAR0 + 32; ++col) {
+            const F x = loc[col];
+            c.constraint(x * (x - one) * (x - two));
+        }
+        // ---- 3. additions of the eight G functions of the round held in the next row (gated by g_on)
+        {
+            auto GON = c.open(g_on);
 #pragma unroll 1
-            for (int j = 0; j < 8; ++j) {
-                F x = loc[CAR(k, j)];
-                if ((j & 2) == 0) c.constraint(x * (x - one) * (x - two));
-                else c.constraint(x * (x - one));
-            }
-        // ---- 3. the eight G functions of the round held in the next row (every constraint gated by g_on)
-        auto GON = c.open(g_on);
-#pragma unroll 1
-        for (int k = 0; k < 8; ++k) {
-            int wa, ca, wb, cb, wc, cc, wd, cd, xs, ys;  // (row selector, first bit column) of the inputs
-            if (k < 4) {
-                wa = wb = wc = wd = 0;
-                ca = OUT(k), cb = OUT(4 + k), cc = OUT(8 + k), cd = OUT(12 + k);
-                xs = 2 * k, ys = 2 * k + 1;
-            } else {
-                const int j = k - 4;
-                wa = wb = wc = wd = 1;
-                ca = GB(j, W_A2, 0), cb = GB((j + 1) % 4, W_B2, 0), cc = GB((j + 2) % 4, W_C2, 0), cd = GB((j + 3) % 4, W_D2, 0);
-                xs = 8 + 2 * j, ys = 8 + 2 * j + 1;
-            }
-            auto add3 = [&](int w1, int c1, int w2, int c2, int msg_slot, int res_slot, int car_j) {
-                F cin = F::from(0);
+            for (int k = 0; k < 8; ++k) {
+                const int xs = k < 4 ? 2 * k : 8 + 2 * (k - 4), ys = xs + 1;
+                // add3: o1 + o2 + message word -> res, explicit carry cells
+                F cin = one;
+                // A1 = a + b + x
 #pragma unroll 1
                 for (int h = 0; h < 2; ++h) {
-                    F lhs = limb(w1, c1, h) + limb(w2, c2, h);
-                    if (msg_slot >= 0) lhs = lhs + nxt[MS(msg_slot, h)];
+                    F lhs = limb_in(k, 0, h) + limb_in(k, 1, h) + nxt[MS(xs, h)];
                     if (h) lhs = lhs + cin;
-                    F car = nxt[CAR(k, car_j + h)];
-                    c.gated(GON, lhs - limb(1, GB(k, res_slot, 0), h) - two32 * car);
+                    const F car = nxt[CAR(k, h)];
+                    c.gated(GON, lhs - limb_cells(1, k, S_A1, h) - car * two32);
                     cin = car;
                 }
-            };
-            auto xorrot = [&](int w1, int c1, int w2, int c2, int res_slot, int rot) {
-#pragma unroll VX_Q_UNROLL
-                for (int i = 0; i < 64; ++i) {
-                    const int s = (i + rot) & 63;
-                    c.gated(GON, nxt[GB(k, res_slot, i)] - xorf(at(w1, c1 + s), at(w2, c2 + s)));
+                // C1 = c + D1 (carry = a linear expression that must be 0 or 1)
+#pragma unroll 1
+                for (int h = 0; h < 2; ++h) {
+                    F t = limb_in(k, 2, h) + limb_cells(1, k, S_D1, h) - limb_cells(1, k, S_C1, h);
+                    if (h) t = t + cin;
+                    const F cy = t * inv32;
+                    c.gated(GON, cy * (cy - one));
+                    cin = cy;
                 }
-            };
-            add3(wa, ca, wb, cb, xs, W_A1, 0);
-            xorrot(wd, cd, 1, GB(k, W_A1, 0), W_D1, 32);
-            add3(wc, cc, 1, GB(k, W_D1, 0), -1, W_C1, 2);
-            xorrot(wb, cb, 1, GB(k, W_C1, 0), W_B1, 24);
-            add3(1, GB(k, W_A1, 0), 1, GB(k, W_B1, 0), ys, W_A2, 4);
-            xorrot(1, GB(k, W_D1, 0), 1, GB(k, W_A2, 0), W_D2, 16);
-            add3(1, GB(k, W_C1, 0), 1, GB(k, W_D2, 0), -1, W_C2, 6);
-            xorrot(1, GB(k, W_B1, 0), 1, GB(k, W_C2, 0), W_B2, 63);
+                // A2 = A1 + B1 + y
+#pragma unroll 1
+                for (int h = 0; h < 2; ++h) {
+                    F lhs = limb_cells(1, k, S_A1, h) + limb_cells(1, k, S_B1, h) + nxt[MS(ys, h)];
+                    if (h) lhs = lhs + cin;
+                    const F car = nxt[CAR(k, 2 + h)];
+                    c.gated(GON, lhs - limb_cells(1, k, S_A2, h) - car * two32);
+                    cin = car;
+                }
+                // C2 = C1 + D2
+#pragma unroll 1
+                for (int h = 0; h < 2; ++h) {
+                    F t = limb_cells(1, k, S_C1, h) + limb_cells(1, k, S_D2, h) - limb_cells(1, k, S_C2, h);
+                    if (h) t = t + cin;
+                    const F cy = t * inv32;
+                    c.gated(GON, cy * (cy - one));
+                    cin = cy;
+                }
+            }
+            c.close(GON);
         }
-        c.close(GON);
-        // ---- 4. INIT row (gated by sel[0])
+        // ---- 4. INIT row (gated by sel[0]): out-state = (H, IV[0..4), IV4 ^ t, IV5, IV6 ^ f, IV7), limb-wise
         const F fin = loc[FIN];
-        auto S0 = c.open(sel[0]);
+        {
+            auto S0 = c.open(sel[0]);
 #pragma unroll 1
-        for (int wd = 0; wd < 16; ++wd) {
-            const int col0 = OUT(wd);
-            if (wd < 8) {  // v[0..8) = h_in: compared limb-wise with the H register
+            for (int w = 0; w < 16; ++w)
 #pragma unroll 1
-                for (int h = 0; h < 2; ++h) c.gated(S0, limb(0, col0, h) - loc[HL(wd, h)]);
-                continue;
-            }
+                for (int h = 0; h < 2; ++h) {
+                    const F got = limb4(out_byte(0, w, 4 * h), out_byte(0, w, 4 * h + 1), out_byte(0, w, 4 * h + 2), out_byte(0, w, 4 * h + 3));
+                    F want;
+                    if (w < 8) want = loc[HL(w, h)];
+                    else {
+                        const uint64_t ivl = (iv(w - 8) >> (32 * h)) & 0xFFFFFFFFULL;
+                        if (w == 12 && h == 0) {
+                            // (IV4 ^ t) low limb: sum_i 2^i (iv_i xor tb_i), linear in the bits of t
+                            want = F::from(0);
 #pragma unroll 1
-            for (int i = 0; i < 64; ++i) {
-                F cell = loc[col0 + i], want;
-                const int bit = (int)((iv(wd - 8) >> i) & 1);
-                if (wd == 12 && i < 32) want = bit ? one - loc[TB0 + i] : loc[TB0 + i];
-                else if (wd == 14) want = bit ? one - fin : fin;
-                else want = F::from((uint64_t)bit);
-                c.gated(S0, cell - want);
+                            for (int i = 0; i < 32; ++i) {
+                                const F tb = loc[TB0 + i];
+                                want = want + (((ivl >> i) & 1) ? one - tb : tb) * F::from(1ULL << i);
+                            }
+                        } else if (w == 14) {
+                            // fin ? ~iv : iv
+                            want = fin * (F::from(0xFFFFFFFFULL - ivl) - F::from(ivl)) + F::from(ivl);
+                        } else want = F::from(ivl);
+                    }
+                    c.gated(S0, got - want);
+                }
+            c.close(S0);
+        }
+        // ---- 5. finalisation through the same-row D2 lookups of rows 13 / 14
+        {
+            F keep_h = sel[15];
+            for (int r = 0; r < 13; ++r) keep_h = keep_h + sel[r];
+#pragma unroll 1
+            for (int w = 0; w < 8; ++w) {
+                const uint64_t ivp = w == 0 ? (iv(0) ^ 0x01010020ULL) : iv(w);
+#pragma unroll 1
+                for (int i = 0; i < 8; ++i) {
+                    c.constraint(sel[12] * (nxt[GC(w, S_D1, i)] - out_byte(0, w, i)));
+                    c.constraint(sel[12] * (nxt[GC(w, S_A2, i)] - out_byte(0, 8 + w, i)));
+                    c.constraint(sel[13] * (nxt[GC(w, S_D1, i)] - loc[GC(w, S_D2, (i + 6) & 7)]));
+                }
+#pragma unroll 1
+                for (int h = 0; h < 2; ++h) {
+                    const F hl = loc[HL(w, h)], hn = nxt[HL(w, h)];
+                    const F ivl = F::from((ivp >> (32 * h)) & 0xFFFFFFFFULL);
+                    // h_out byte i = D2[(i + 6) mod 8] of the local row
+                    const F hout = limb4(loc[GC(w, S_D2, (4 * h + 6) & 7)], loc[GC(w, S_D2, (4 * h + 7) & 7)], loc[GC(w, S_D2, (4 * h + 8) & 7)],
+                                         loc[GC(w, S_D2, (4 * h + 9) & 7)]);
+                    c.constraint(sel[13] * (limb_cells(1, w, S_A2, h) - hl));
+                    c.constraint(sel[14] * (hl - hout));
+                    c.constraint(sel[14] * (hn - (fin * ivl + (one - fin) * hl)));
+                    c.constraint(keep_h * (hn - hl));
+                }
             }
         }
-        c.close(S0);
-        // ---- 5. finalisation
-        F keep_h = sel[15];
-        for (int r = 0; r < 13; ++r) keep_h = keep_h + sel[r];
-        auto S12 = c.open(sel[12]);
-        auto S13 = c.open(sel[13]);
-#pragma unroll 1
-        for (int wd = 0; wd < 8; ++wd) {
-            const int lo0 = OUT(wd), hi0 = OUT(8 + wd);
-            const uint64_t ivp = wd == 0 ? (iv(0) ^ 0x01010020ULL) : iv(wd);
-#pragma unroll 1
-            for (int i = 0; i < 64; ++i) {
-                c.gated(S12, nxt[FT(wd, i)] - xorf(nxt[FH(wd, i)], loc[lo0 + i]));
-                c.gated(S12, nxt[FV(wd, i)] - loc[hi0 + i]);
-                c.gated(S13, nxt[FT(wd, i)] - xorf(loc[FT(wd, i)], loc[FV(wd, i)]));
-            }
-#pragma unroll 1
-            for (int h = 0; h < 2; ++h) {
-                const F hl = loc[HL(wd, h)], hn = nxt[HL(wd, h)];
-                const F ivl = F::from((ivp >> (32 * h)) & 0xFFFFFFFFULL);
-                c.gated(S13, hl - limb(0, FH(wd, 0), h));
-                c.constraint(sel[14] * (hl - limb(0, FT(wd, 0), h)));
-                c.constraint(sel[14] * (hn - (fin * ivl + (one - fin) * hl)));
-                c.constraint(keep_h * (hn - hl));
-            }
-        }
-        c.close(S12);
-        c.close(S13);
-        // ---- 6. message schedule, range check, link
+        // ---- 6. message schedule, bytes of the natural word, link to the previous digest
 #pragma unroll 1
         for (int s = 0; s < 16; ++s)
 #pragma unroll 1
@@ -243,14 +257,11 @@ struct BlakeAir {
             F acc = sel[0] * loc[MS(rc_slot(0), h)];
 #pragma unroll 1
             for (int r = 1; r < 16; ++r) acc = acc + sel[r] * loc[MS(rc_slot(r), h)];
-            c.constraint(acc - limb(0, MB0, h));
+            c.constraint(acc - limb4(loc[MB0 + 4 * h], loc[MB0 + 4 * h + 1], loc[MB0 + 4 * h + 2], loc[MB0 + 4 * h + 3]));
         }
-        // ---- 6b. bytes at positions >= inc are zero (RFC 7693 zero padding of the last chunk): row r sees
-        // word r's bits (MB); MK is a monotone mask over the 128 byte positions with popcount inc
+        // ---- 6b. bytes at positions >= inc are zero (RFC 7693 zero padding of the last chunk)
+        const F in_blk = one - sel[15];
         {
-            const F in_blk = one - sel[15];
-#pragma unroll 1
-            for (int b = 0; b < 8; ++b) boolean(MK0 + b);
 #pragma unroll 1
             for (int b = 0; b < 7; ++b) c.constraint(loc[MK0 + b + 1] * (one - loc[MK0 + b]));
             c.constraint(in_blk * nxt[MK0] * (one - loc[MK0 + 7]));
@@ -264,12 +275,7 @@ struct BlakeAir {
             c.constraint(in_blk * (nxt[CNT] - loc[CNT] - msum_n));
             c.constraint(sel[15] * (loc[CNT] - loc[INC]));
 #pragma unroll 1
-            for (int b = 0; b < 8; ++b) {
-                F byte = loc[MB0 + 8 * b + 7];
-#pragma unroll 1
-                for (int i = 6; i >= 0; --i) byte = byte + byte + loc[MB0 + 8 * b + i];
-                c.constraint((one - loc[MK0 + b]) * byte);
-            }
+            for (int b = 0; b < 8; ++b) c.constraint((one - loc[MK0 + b]) * loc[MB0 + b]);
         }
         const F first = loc[FIRST];
 #pragma unroll 1
@@ -279,20 +285,16 @@ struct BlakeAir {
         // block number: bytes 32..36 = SCALE compact int, 4-byte mode: 4 * number + 2 (decoder.rs:64-66)
         c.constraint(sel[0] * first * (loc[MS(4, 0)] - (F::from(4) * loc[NUM] + two)));
         // ---- 7. per-block registers
-        const F in_block = one - sel[15];
         {
             const int regs[8] = {ACT, FIN, FIRST, CAP, T, INC, NUM, FA};
 #pragma unroll 1
-            for (int q = 0; q < 8; ++q) c.constraint(in_block * (nxt[regs[q]] - loc[regs[q]]));
+            for (int q = 0; q < 8; ++q) c.constraint(in_blk * (nxt[regs[q]] - loc[regs[q]]));
         }
         c.constraint(loc[CAP] - loc[ACT] * fin);
         c.constraint(loc[FA] - first * loc[ACT]);
         c.transition(sel[15] * (nxt[NUM] - loc[NUM] - nxt[FA]));  // sequential numbers (subchain_verification.rs:166-168)
-        // ACT is a property of a whole MESSAGE, not of a block: it may not change between the chunks of one message
-        // (else a junk message could bump NUM through FA on its first chunk and skip the digest capture on its last),
-        // and once the chain has gone inactive (padding) it stays inactive
-        c.constraint(sel[15] * (one - fin) * (nxt[ACT] - loc[ACT]));
-        c.transition(nxt[ACT] * (one - loc[ACT]));
+        c.constraint(sel[15] * (one - fin) * (nxt[ACT] - loc[ACT]));  // ACT belongs to a whole message ...
+        c.transition(nxt[ACT] * (one - loc[ACT]));                    // ... and padding stays padding
         c.constraint(sel[15] * (nxt[FIRST] - fin));
         c.constraint(sel[15] * (nxt[T] - (one - fin) * loc[T] - nxt[INC]));
         {
@@ -324,5 +326,48 @@ struct BlakeAir {
         c.last_row(fin - one);
         c.first_row(loc[NUM] - pub[16]);
         c.last_row(loc[NUM] - pub[17]);
+        // ---- 10. lookups (logUp): helpers live in the next row, the table side in the local row, Z closes cyclically
+        {
+            const X2<F> beta{chal[0], chal[1]}, gamma{chal[2], chal[3]}, g2 = gamma * gamma, g3 = g2 * gamma, g4 = g2 * g2;
+            const X2<F> bt2 = beta + g4;  // table-2 tuples carry the tag gamma^4
+            const F m3 = g_on + sel[12] + sel[13];
+            // denominator beta + fingerprint of lookup i (a byte position) of group grp of G number k
+            auto denom = [&](int k, int grp, int i) -> X2<F> {
+                if (grp == 0) return beta + in_byte(k, 3, i) + gamma * nxt[GC(k, S_A1, i)] + g2 * nxt[GC(k, S_D1, (i + 4) & 7)];
+                if (grp == 1) return beta + in_byte(k, 1, i) + gamma * nxt[GC(k, S_C1, i)] + g2 * nxt[GC(k, S_B1, (i + 5) & 7)];
+                if (grp == 2) return beta + nxt[GC(k, S_D1, i)] + gamma * nxt[GC(k, S_A2, i)] + g2 * nxt[GC(k, S_D2, (i + 6) & 7)];
+                return bt2 + nxt[GC(k, S_B1, i)] + gamma * nxt[GC(k, S_C2, i)] + g2 * nxt[GC(k, S_L, i)] + g3 * nxt[GC(k, S_T, i)];
+            };
+            X2<F> hsum{F::from(0), F::from(0)};
+#pragma unroll 1
+            for (int k = 0; k < 8; ++k)
+#pragma unroll 1
+                for (int grp = 0; grp < 4; ++grp)
+#pragma unroll 1
+                    for (int pair = 0; pair < 4; ++pair) {
+                        const int e = (k * 4 + grp) * 4 + pair;
+                        const X2<F> du = denom(k, grp, 2 * pair), dv = denom(k, grp, 2 * pair + 1);
+                        const X2<F> h{nxt[AX(e, 0)], nxt[AX(e, 1)]};
+                        c.constraint_x2(h * du * dv - (du + dv) * (grp == 2 ? m3 : g_on));
+                        hsum = hsum + h;
+                    }
+            // the 8 bytes of the row's natural message word are range checked as (byte, 0, byte) in T1: always active
+#pragma unroll 1
+            for (int pair = 0; pair < 4; ++pair) {
+                const int e = HM0 + pair;
+                const F b0 = nxt[MB0 + 2 * pair], b1 = nxt[MB0 + 2 * pair + 1];
+                const X2<F> du = beta + b0 + g2 * b0, dv = beta + b1 + g2 * b1;
+                const X2<F> h{nxt[AX(e, 0)], nxt[AX(e, 1)]};
+                c.constraint_x2(h * du * dv - (du + dv));
+                hsum = hsum + h;
+            }
+            const F ta = per[16], tb_ = per[17], tl = per[18], tt = per[19];
+            const X2<F> dt1 = beta + ta + gamma * tb_ + g2 * (tl + tt * F::from(128));
+            const X2<F> dt2 = bt2 + ta + gamma * tb_ + g2 * tl + g3 * tt;
+            const X2<F> ht{loc[AX(HT, 0)], loc[AX(HT, 1)]};
+            c.constraint_x2(ht * dt1 * dt2 - dt2 * loc[M1] - dt1 * loc[M2]);
+            const X2<F> z{loc[AX(ZZ, 0)], loc[AX(ZZ, 1)]}, zn{nxt[AX(ZZ, 0)], nxt[AX(ZZ, 1)]};
+            c.constraint_x2(zn - z - hsum + ht);
+        }
     }
 };

@@ -2,9 +2,10 @@
 //   kernel A  k_blake_chain: one lane per header -- digest + the chaining value before every
 //             128-byte chunk (the only sequential part of BLAKE2b);
 //   kernel B  k_blake_trace: one lane per TRACE ROW (block b, r = row mod 16): recomputes
-//             the <= 12 rounds it needs from the chunk's chaining value and writes its 4822
+//             the <= 12 rounds it needs from the chunk's chaining value and writes its 729
 //             cells; lanes of a wave write 64 consecutive rows of a column, so every store
-//             instruction is a coalesced 512-byte segment of the column-major trace.
+//             instruction is a coalesced 512-byte segment of the column-major trace;
+//   kernel C  k_blake_aux: the logUp helper columns once the lookup challenges are known.
 // Replaces the curta Blake2b witness generation behind hash_encoded_header
 // (/root/reference circuits/builder/header.rs:14-19) for the synthetic header chain.
 #include <string.h>
@@ -27,6 +28,7 @@ __device__ __forceinline__ uint64_t b_rotr(uint64_t x, int n) { return (x >> n) 
 
 struct GRec {
     uint64_t w[8];  // a1 d1 c1 b1 a2 d2 c2 b2
+    uint64_t in_b, in_d;  // the operands that enter an XOR lookup
     uint8_t car[8];
 };
 __device__ __forceinline__ void carries(uint64_t o1, uint64_t o2, uint64_t o3, uint8_t* out) {
@@ -42,6 +44,7 @@ __device__ __forceinline__ void g_mix(uint64_t* v, int ia, int ib, int ic, int i
     uint64_t a2 = a1 + b1 + y, d2 = b_rotr(d1 ^ a2, 16), c2 = c1 + d2, b2 = b_rotr(b1 ^ c2, 63);
     if (rec) {
         rec->w[0] = a1, rec->w[1] = d1, rec->w[2] = c1, rec->w[3] = b1, rec->w[4] = a2, rec->w[5] = d2, rec->w[6] = c2, rec->w[7] = b2;
+        rec->in_b = b, rec->in_d = d;
         carries(a, b, x, rec->car);
         carries(c, d1, 0, rec->car + 2);
         carries(a1, b1, y, rec->car + 4);
@@ -94,39 +97,13 @@ __global__ __launch_bounds__(64) void k_blake_chain(const uint8_t* msgs, size_t 
     d[0] = h[0], d[1] = h[1], d[2] = h[2], d[3] = h[3];
 }
 
-__device__ __forceinline__ void put_bits(uint64_t* tr, size_t n, size_t row, int col0, uint64_t val, int nbits = 64) {
-    for (int i = 0; i < nbits; ++i) tr[(size_t)(col0 + i) * n + row] = (val >> i) & 1;
-}
-
-// The 4096 bit columns of the G area and the 64 of MB0 are not stored bit by bit from the row lane: a lane would
-// walk 4337 columns 8n bytes apart, one 512-byte store each, and the address translation of that walk -- not the
-// bytes -- set the kernel's time (22 ms for 18 GB).  k_blake_trace writes the 65 WORDS per row instead
-// (words[wc * n + row]) and k_expand_bits turns each word column into its 64 bit columns, a block writing 16 KB
-// runs of 64 columns only.
-constexpr int N_WORD_COLS = 65, EXP_RPL = 8;
-__global__ __launch_bounds__(256) void k_expand_bits(const uint64_t* __restrict__ words, uint64_t* __restrict__ tr, size_t n) {
-    const int wc = blockIdx.y;
-    const size_t col0 = wc < 64 ? (size_t)wc * 64 : (size_t)blk::MB0;
-    const size_t row0 = (size_t)blockIdx.x * (256 * EXP_RPL) + threadIdx.x;
-    uint64_t w[EXP_RPL];
-#pragma unroll
-    for (int rr = 0; rr < EXP_RPL; ++rr) {
-        const size_t row = row0 + 256 * (size_t)rr;
-        w[rr] = row < n ? words[(size_t)wc * n + row] : 0;
-    }
-    for (int i = 0; i < 64; ++i) {
-        uint64_t* c = tr + (col0 + i) * n;
-#pragma unroll
-        for (int rr = 0; rr < EXP_RPL; ++rr) {
-            const size_t row = row0 + 256 * (size_t)rr;
-            if (row < n) c[row] = (w[rr] >> i) & 1;
-        }
-    }
-}
-
-// one lane per trace row
+// ---- trace rows ---------------------------------------------------------------------------------------------------
+// One lane per trace row (block b, r = row mod 16): recomputes the <= 12 rounds it needs from the chunk's chaining value
+// and stores its 729 cells byte by byte (lanes of a wave write 64 consecutive rows of a column: every store instruction
+// is one coalesced 512-byte segment of the column-major trace).  The same lane knows every XOR its row looks up, so it
+// also bumps the multiplicity histograms of the two tables (hist[0 .. 2^16) for T1, hist[2^16 .. 2^17) for T2).
 __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const BlockDesc* descs, const uint64_t* hchain, size_t n_real,
-                                                     uint64_t* tr, uint64_t* __restrict__ words, size_t n) {
+                                                     uint64_t* __restrict__ tr, uint32_t* __restrict__ hist, size_t n) {
     using namespace blk;
     const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (row >= n) return;
@@ -146,81 +123,243 @@ __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const 
             }
             m[k] = w;
         }
-    } else {  // padding block: the 32-byte message D
+    } else {  // padding block: the 36-byte message D || compact(number)
         for (int k = 0; k < 8; ++k) h[k] = IV[k];
         h[0] ^= 0x01010020ULL;
         for (int k = 0; k < 16; ++k) m[k] = k < 4 ? ((uint64_t)d.D[2 * k] | ((uint64_t)d.D[2 * k + 1] << 32)) : 0;
         m[4] = 4ULL * d.num + 2;  // bytes 32..36: SCALE compact (4-byte mode) of the last block number
     }
-    // ---- G area (columns 0 .. 4159): zero unless this row uses it
-    GRec rec[8];
-    bool have_rec = false;
-    uint64_t vfin[16];
+    auto cell = [&](int col) -> uint64_t& { return tr[(size_t)col * n + row]; };
+    auto put = [&](int k, int slot, uint64_t word) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cell(GC(k, slot, j)) = (word >> (8 * j)) & 0xFF;
+    };
+    auto put_lt = [&](int k, uint64_t x) {  // (low 7 bits, top bit) of every byte of x
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t bv = (uint32_t)(x >> (8 * j)) & 0xFF;
+            cell(GC(k, S_L, j)) = bv & 127;
+            cell(GC(k, S_T, j)) = bv >> 7;
+        }
+    };
+    auto look1 = [&](uint64_t a, uint64_t bq) {  // 8 byte lookups (a_i, b_i, .) into T1
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(&hist[((a >> (8 * j)) & 0xFF) | (((bq >> (8 * j)) & 0xFF) << 8)], 1u);
+    };
+    auto look2 = [&](uint64_t a, uint64_t bq) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(&hist[65536 + (((a >> (8 * j)) & 0xFF) | (((bq >> (8 * j)) & 0xFF) << 8))], 1u);
+    };
+    // ---- G area + carries: zero unless this row uses the cell
+    for (int col = 0; col < MS0; ++col) cell(col) = 0;  // (a lane's later store to the same address wins)
     blake_init_v(v, h, d.t, d.fin);
-    uint64_t v0[16];
-    for (int k = 0; k < 16; ++k) v0[k] = v[k];
-    if (r >= 1) {
+    if (r == 0) {
+        for (int w = 0; w < 16; ++w) {
+            const int mm = w & 3;
+            if (w < 4) put(4 + w, S_A2, v[w]);
+            else if (w < 8) put_lt(4 + (mm + 3) % 4, b_rotr(v[w], 1));  // 2 L[j] + T[j-1] = byte j of v[w]
+            else if (w < 12) put(4 + (mm + 2) % 4, S_C2, v[w]);
+            else put(4 + (mm + 1) % 4, S_D2, v[w]);
+        }
+    } else {
+        GRec rec[8];
+        uint64_t vin[16];
         const int last = r <= 12 ? r - 1 : 11;  // rounds 0 .. last
-        for (int q = 0; q <= last; ++q) blake_round(v, m, q, q == last && r <= 12 ? rec : nullptr);
-        have_rec = r <= 12;
-        for (int k = 0; k < 16; ++k) vfin[k] = v[k];
+        for (int q = 0; q <= last; ++q) {
+            if (q == last)
+                for (int k = 0; k < 16; ++k) vin[k] = v[k];
+            blake_round(v, m, q, q == last && r <= 12 ? rec : nullptr);
+        }
+        if (r <= 12) {
+            for (int k = 0; k < 8; ++k) {
+                const uint64_t *w = rec[k].w;  // a1 d1 c1 b1 a2 d2 c2 b2
+                put(k, S_A1, w[0]), put(k, S_D1, w[1]), put(k, S_C1, w[2]), put(k, S_B1, w[3]), put(k, S_A2, w[4]), put(k, S_D2, w[5]), put(k, S_C2, w[6]);
+                put_lt(k, w[3] ^ w[6]);
+                cell(CAR(k, 0)) = rec[k].car[0], cell(CAR(k, 1)) = rec[k].car[1], cell(CAR(k, 2)) = rec[k].car[4], cell(CAR(k, 3)) = rec[k].car[5];
+                // the row's lookups: (d, A1), (b, C1), (D1, A2) into T1 and (B1, C2) into T2
+                look1(rec[k].in_d, w[0]);
+                look1(rec[k].in_b, w[2]);
+                look1(w[1], w[4]);
+                look2(w[3], w[6]);
+            }
+        } else if (r == 13 || r == 14) {
+            for (int w = 0; w < 8; ++w) {
+                const uint64_t u = v[w] ^ v[8 + w];
+                const uint64_t x = r == 13 ? v[w] : u, y = r == 13 ? v[8 + w] : h[w];
+                put(w, S_D1, x), put(w, S_A2, y), put(w, S_D2, b_rotr(x ^ y, 16));
+                look1(x, y);
+            }
+        }
+        (void)vin;
     }
     uint64_t h_out[8];
     if (r >= 13)
-        for (int k = 0; k < 8; ++k) h_out[k] = h[k] ^ vfin[k] ^ vfin[k + 8];
-    auto put_word = [&](int bit_col0, uint64_t val) { words[(size_t)(bit_col0 >> 6) * n + row] = val; };  // G-area cells are word aligned
-    if (have_rec) {
-        for (int k = 0; k < 8; ++k) {
-            for (int w = 0; w < 8; ++w) put_word(GB(k, w, 0), rec[k].w[w]);
-            for (int j = 0; j < 8; ++j) tr[(size_t)CAR(k, j) * n + row] = rec[k].car[j];
-        }
-    } else {
-        for (int wc = 0; wc < 64; ++wc) words[(size_t)wc * n + row] = 0;
-        for (int col = 4096; col < 4160; ++col) tr[(size_t)col * n + row] = 0;
-        if (r == 0) {  // (a lane's later store to the same address wins)
-            for (int w = 0; w < 16; ++w) put_word(OUT(w), v0[w]);
-        } else if (r == 13) {
-            for (int w = 0; w < 8; ++w) {
-                put_word(FT(w, 0), h[w] ^ vfin[w]);
-                put_word(FV(w, 0), vfin[8 + w]);
-                put_word(FH(w, 0), h[w]);
-            }
-        } else if (r == 14) {
-            for (int w = 0; w < 8; ++w) put_word(FT(w, 0), h_out[w]);
-        }
-    }
-    // ---- message schedule + range check of natural word r
+        for (int k = 0; k < 8; ++k) h_out[k] = h[k] ^ v[k] ^ v[k + 8];
+    // ---- message schedule + bytes of natural word r (range checked as (byte, 0, byte) in T1)
     for (int s = 0; s < 16; ++s) {
         const uint64_t w = m[ORDER[r][s]];
-        tr[(size_t)MS(s, 0) * n + row] = w & 0xFFFFFFFFULL;
-        tr[(size_t)MS(s, 1) * n + row] = w >> 32;
+        cell(MS(s, 0)) = w & 0xFFFFFFFFULL;
+        cell(MS(s, 1)) = w >> 32;
     }
-    words[(size_t)64 * n + row] = m[r];  // MB0 .. MB0+63
-    for (int b = 0; b < 8; ++b) tr[(size_t)(MK0 + b) * n + row] = (uint32_t)(8 * r + b) < d.inc ? 1 : 0;
-    tr[(size_t)CNT * n + row] = d.inc < (uint32_t)(8 * (r + 1)) ? d.inc : (uint32_t)(8 * (r + 1));
+    for (int j = 0; j < 8; ++j) cell(MB0 + j) = (m[r] >> (8 * j)) & 0xFF;
+    look1(m[r], 0);
+    for (int bq = 0; bq < 8; ++bq) cell(MK0 + bq) = (uint32_t)(8 * r + bq) < d.inc ? 1 : 0;
+    cell(CNT) = d.inc < (uint32_t)(8 * (r + 1)) ? d.inc : (uint32_t)(8 * (r + 1));
     // ---- H register
     for (int w = 0; w < 8; ++w) {
         const uint64_t hv = r <= 13 ? h[w] : (r == 14 ? h_out[w] : (d.fin ? (w == 0 ? IV[0] ^ 0x01010020ULL : IV[w]) : h_out[w]));
-        tr[(size_t)HL(w, 0) * n + row] = hv & 0xFFFFFFFFULL;
-        tr[(size_t)HL(w, 1) * n + row] = hv >> 32;
+        cell(HL(w, 0)) = hv & 0xFFFFFFFFULL;
+        cell(HL(w, 1)) = hv >> 32;
     }
     // ---- digest register, flags, counters
     const bool cap = d.act && d.fin;
     for (int j = 0; j < 8; ++j) {
         uint32_t dv = d.D[j];
         if (r == 15 && cap) dv = (uint32_t)(h_out[j / 2] >> (32 * (j & 1)));
-        tr[(size_t)(D0 + j) * n + row] = dv;
+        cell(D0 + j) = dv;
     }
-    tr[(size_t)ACT * n + row] = d.act;
-    tr[(size_t)FIN * n + row] = d.fin;
-    tr[(size_t)FIRST * n + row] = d.first;
-    tr[(size_t)CAP * n + row] = cap ? 1 : 0;
-    tr[(size_t)T * n + row] = d.t;
-    tr[(size_t)INC * n + row] = d.inc;
-    tr[(size_t)NUM * n + row] = d.num;
-    tr[(size_t)FA * n + row] = (d.first && d.act) ? 1 : 0;
-    put_bits(tr, n, row, TB0, d.t, 32);
-    put_bits(tr, n, row, IB0, d.inc, 8);
+    cell(ACT) = d.act, cell(FIN) = d.fin, cell(FIRST) = d.first, cell(CAP) = cap ? 1 : 0;
+    cell(T) = d.t, cell(INC) = d.inc, cell(NUM) = d.num, cell(FA) = (d.first && d.act) ? 1 : 0;
+    for (int i = 0; i < 32; ++i) cell(TB0 + i) = (d.t >> i) & 1;
+    for (int i = 0; i < 8; ++i) cell(IB0 + i) = (d.inc >> i) & 1;
+}
+// the multiplicity columns: all counts in the first copy of the periodic tables
+__global__ __launch_bounds__(256) void k_blake_mult(const uint32_t* hist, uint64_t* tr, size_t n) {
+    const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    tr[(size_t)blk::M1 * n + row] = row < 65536 ? hist[row] : 0;
+    tr[(size_t)blk::M2 * n + row] = row < 65536 ? hist[65536 + row] : 0;
+}
+
+// ---- auxiliary columns (logUp) --------------------------------------------------------------------------------------
+// One lane per row i (as the "next" row of the pair (i-1, i)): the 132 helper elements of row i (two lookups each,
+// h = m (1/D_u + 1/D_v); the four pairs of a group share ONE extension-field inversion, Montgomery's trick), the table
+// helper of row i, and the running-sum increment Z(i) - Z(i-1) = sum_e h_e(i) - ht(i-1), stored at row i-1 and turned
+// into Z by an exclusive scan.
+struct AuxArgs {
+    const uint64_t* tr;
+    uint64_t* aux;
+    size_t n;
+    gl2 beta, gamma;
+};
+__device__ __forceinline__ gl2 gl2_from(uint64_t x) { return {x, 0}; }
+__global__ __launch_bounds__(256) void k_blake_aux(AuxArgs a) {
+    using namespace blk;
+    const size_t n = a.n, i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t ip = (i + n - 1) & (n - 1);
+    const int rl = (int)(ip & 15);  // row index (mod 16) of the LOCAL row: selectors are taken there
+    const bool g_on = rl <= 11, m3 = rl <= 13;
+    const gl2 beta = a.beta, gamma = a.gamma, g2 = gl2_mul(gamma, gamma), g3 = gl2_mul(g2, gamma), g4 = gl2_mul(g2, g2);
+    const gl2 bt2 = gl2_add(beta, g4);
+    auto N = [&](int col) -> uint64_t { return a.tr[(size_t)col * n + i]; };
+    auto L = [&](int col) -> uint64_t { return a.tr[(size_t)col * n + ip]; };
+    auto out_byte_loc = [&](int w, int j) -> uint64_t {
+        const int m = w & 3;
+        if (w < 4) return L(GC(4 + w, S_A2, j));
+        if (w < 8) {
+            const int k = 4 + (m + 3) % 4;
+            return 2 * L(GC(k, S_L, j)) + L(GC(k, S_T, (j + 7) & 7));
+        }
+        if (w < 12) return L(GC(4 + (m + 2) % 4, S_C2, j));
+        return L(GC(4 + (m + 1) % 4, S_D2, j));
+    };
+    auto in_byte = [&](int k, int op, int j) -> uint64_t {
+        if (k < 4) return out_byte_loc(4 * op + k, j);
+        const int j0 = k - 4;
+        if (op == 1) {
+            const int kb = (j0 + 1) & 3;
+            return 2 * N(GC(kb, S_L, j)) + N(GC(kb, S_T, (j + 7) & 7));
+        }
+        return N(GC((j0 + 3) & 3, S_D2, j));  // op == 3 (a and c never enter a lookup)
+    };
+    auto fp1 = [&](uint64_t x, uint64_t y, uint64_t z) -> gl2 {  // small operands: products by < 2^9 stay cheap but exact
+        gl2 d = gl2_add(beta, gl2_add(gl2_scale(gamma, y), gl2_scale(g2, z)));
+        d.a = gl_add(d.a, x);
+        return d;
+    };
+    auto denom = [&](int k, int grp, int q) -> gl2 {
+        if (grp == 0) return fp1(in_byte(k, 3, q), N(GC(k, S_A1, q)), N(GC(k, S_D1, (q + 4) & 7)));
+        if (grp == 1) return fp1(in_byte(k, 1, q), N(GC(k, S_C1, q)), N(GC(k, S_B1, (q + 5) & 7)));
+        if (grp == 2) return fp1(N(GC(k, S_D1, q)), N(GC(k, S_A2, q)), N(GC(k, S_D2, (q + 6) & 7)));
+        gl2 d = gl2_add(bt2, gl2_add(gl2_scale(gamma, N(GC(k, S_C2, q))), gl2_add(gl2_scale(g2, N(GC(k, S_L, q))), gl2_scale(g3, N(GC(k, S_T, q))))));
+        d.a = gl_add(d.a, N(GC(k, S_B1, q)));
+        return d;
+    };
+    auto store = [&](int e, gl2 h) {
+        a.aux[(size_t)(2 * e) * n + i] = h.a;
+        a.aux[(size_t)(2 * e + 1) * n + i] = h.b;
+    };
+    gl2 hsum{0, 0};
+    // four pairs (p_q = D_u D_v, s_q = D_u + D_v) -> h_q = s_q / p_q with one inversion
+    auto four = [&](gl2* p, gl2* s, int e0) {
+        const gl2 c1 = gl2_mul(p[0], p[1]), c2 = gl2_mul(c1, p[2]), c3 = gl2_mul(c2, p[3]);
+        gl2 inv = gl2_inv(c3);
+        const gl2 i3 = gl2_mul(inv, c2);
+        inv = gl2_mul(inv, p[3]);
+        const gl2 i2 = gl2_mul(inv, c1);
+        inv = gl2_mul(inv, p[2]);
+        const gl2 i1 = gl2_mul(inv, p[0]), i0 = gl2_mul(inv, p[1]);
+        const gl2 iq[4] = {i0, i1, i2, i3};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const gl2 h = gl2_mul(s[q], iq[q]);
+            store(e0 + q, h);
+            hsum = gl2_add(hsum, h);
+        }
+    };
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k)
+#pragma unroll 1
+        for (int grp = 0; grp < 4; ++grp) {
+            const int e0 = (k * 4 + grp) * 4;
+            if (grp == 2 ? m3 : g_on) {
+                gl2 p[4], s[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const gl2 du = denom(k, grp, 2 * q), dv = denom(k, grp, 2 * q + 1);
+                    p[q] = gl2_mul(du, dv), s[q] = gl2_add(du, dv);
+                }
+                four(p, s, e0);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) store(e0 + q, gl2{0, 0});
+            }
+        }
+    {
+        gl2 p[4], s[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint64_t b0 = N(MB0 + 2 * q), b1 = N(MB0 + 2 * q + 1);
+            const gl2 du = fp1(b0, 0, b0), dv = fp1(b1, 0, b1);
+            p[q] = gl2_mul(du, dv), s[q] = gl2_add(du, dv);
+        }
+        four(p, s, HM0);
+    }
+    // table helper of this row and of the local row: ht = M1 / D_t1 + M2 / D_t2
+    auto table_h = [&](size_t row, uint64_t m1, uint64_t m2) -> gl2 {
+        const uint64_t ti = row & 65535, ta = ti & 255, tb = ti >> 8, x = ta ^ tb;
+        const gl2 d1 = fp1(ta, tb, x);
+        gl2 d2 = gl2_add(bt2, gl2_add(gl2_scale(gamma, tb), gl2_add(gl2_scale(g2, x & 127), gl2_scale(g3, x >> 7))));
+        d2.a = gl_add(d2.a, ta);
+        if ((m1 | m2) == 0) return gl2{0, 0};
+        const gl2 num = gl2_add(gl2_scale(d2, m1), gl2_scale(d1, m2));
+        return gl2_mul(num, gl2_inv(gl2_mul(d1, d2)));
+    };
+    const gl2 ht = table_h(i, N(M1), N(M2));
+    store(HT, ht);
+    const gl2 dz = gl2_sub(hsum, table_h(ip, L(M1), L(M2)));
+    a.aux[(size_t)(2 * ZZ) * n + ip] = dz.a;
+    a.aux[(size_t)(2 * ZZ + 1) * n + ip] = dz.b;
+}
+
+int32_t vx_blake_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, uint64_t* aux, uint64_t* aux_pub) {
+    (void)aux_pub;
+    const size_t n = (size_t)1 << log_n;
+    AuxArgs a{trace, aux, n, gl2{chal[0], chal[1]}, gl2{chal[2], chal[3]}};
+    hipLaunchKernelGGL(k_blake_aux, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    VX_HIP(hipGetLastError());
+    return vx_scan_cols_dev(ctx, aux + (size_t)(2 * blk::ZZ) * n, log_n, 2, nullptr);
 }
 
 extern "C" {
@@ -231,7 +370,7 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
     if (!ctx || !headers || !sizes || !trusted_hash || !trace_out || !public_inputs_out) return VX_ERR_ARG;
     VX_CHECK(stride % 128 == 0 && stride > 0, "blake trace: stride %zu must be a positive multiple of 128", stride);
     VX_CHECK(n_headers >= 1 && n_headers * stride <= headers->n * 8, "blake trace: headers exceed the buffer");
-    VX_CHECK(log_n >= 4 && log_n <= 24, "blake trace: log_n %d out of range", log_n);
+    VX_CHECK(log_n >= blk::TABLE_LOG && log_n <= 24, "blake trace: log_n %d out of range [16, 24] (the trace holds one copy of the 2^16-row lookup tables)", log_n);
     VX_CHECK(first_block_number >= (1u << 14) && (uint64_t)first_block_number + n_headers <= (1u << 30),
              "blake trace: block numbers %u.. are outside the 4-byte SCALE compact range [2^14, 2^30) this AIR covers", first_block_number);
     const size_t n = (size_t)1 << log_n, n_blocks = n >> 4;
@@ -247,15 +386,15 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
     // device scratch: sizes | block_base | digests | hchain | descs
     const size_t w_sizes = (n_headers * 4 + 7) / 8, w_dig = n_headers * 4, w_hc = n_real * 8;
     const size_t w_desc = (n_blocks * sizeof(BlockDesc) + 7) / 8;
-    const size_t w_words = (size_t)N_WORD_COLS * n;
+    const size_t w_hist = 65536;  // two tables x 2^16 uint32 counters
     uint64_t* sc;
-    VX_TRY(vx_scratch(ctx, 2 * w_sizes + w_dig + w_hc + w_desc + w_words, &sc));
+    VX_TRY(vx_scratch(ctx, 2 * w_sizes + w_dig + w_hc + w_desc + w_hist, &sc));
     uint32_t* d_sizes = (uint32_t*)sc;
     uint32_t* d_base = (uint32_t*)(sc + w_sizes);
     uint8_t* d_dig = (uint8_t*)(sc + 2 * w_sizes);
     uint64_t* d_hc = sc + 2 * w_sizes + w_dig;
     BlockDesc* d_desc = (BlockDesc*)(d_hc + w_hc);
-    uint64_t* d_words = d_hc + w_hc + w_desc;
+    uint32_t* d_hist = (uint32_t*)(d_hc + w_hc + w_desc);
     VX_HIP(hipMemcpyAsync(d_sizes, sizes, n_headers * 4, hipMemcpyHostToDevice, ctx->stream));
     VX_HIP(hipMemcpyAsync(d_base, base.data(), n_headers * 4, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_blake_chain, dim3((unsigned)((n_headers + 63) / 64)), dim3(64), 0, ctx->stream, (const uint8_t*)headers->d,
@@ -296,11 +435,11 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
         memcpy(d.D, D, 32);
     }
     VX_HIP(hipMemcpyAsync(d_desc, descs.data(), n_blocks * sizeof(BlockDesc), hipMemcpyHostToDevice, ctx->stream));
+    VX_HIP(hipMemsetAsync(d_hist, 0, w_hist * 8, ctx->stream));
     hipLaunchKernelGGL(k_blake_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t*)headers->d,
-                       (const BlockDesc*)d_desc, (const uint64_t*)d_hc, n_real, trace_out->d, d_words, n);
+                       (const BlockDesc*)d_desc, (const uint64_t*)d_hc, n_real, trace_out->d, d_hist, n);
     VX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_expand_bits, dim3((unsigned)((n + 256 * EXP_RPL - 1) / (256 * EXP_RPL)), N_WORD_COLS), dim3(256), 0, ctx->stream,
-                       (const uint64_t*)d_words, trace_out->d, n);
+    hipLaunchKernelGGL(k_blake_mult, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_hist, trace_out->d, n);
     VX_HIP(hipGetLastError());
     VX_HIP(hipStreamSynchronize(ctx->stream));  // descs must outlive the kernel
     for (int j = 0; j < 8; ++j) {
@@ -316,7 +455,7 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
     return VX_OK;
 }
 
-static const uint64_t VX_HR_MAGIC = 0x3245474e41525248ULL;  // "HRRANGE2"
+static const uint64_t VX_HR_MAGIC = 0x3345474e41525248ULL;  // "HRRANGE3"
 static const size_t VX_HR_HDR = 18;  // magic, max_headers, trusted, target, out96 (12), len(blake proof), len(sha proof)
 
 static int sha_log_n(size_t n_keys) {
@@ -327,7 +466,7 @@ static int sha_log_n(size_t n_keys) {
 
 int32_t vx_header_range_proof_bound(const vx_stark_config* cfg, size_t n_chunks, size_t n_authorities, size_t* n_words) {
     if (!cfg || !n_words || n_chunks == 0) return VX_ERR_ARG;
-    int log_n = 4;
+    int log_n = blk::TABLE_LOG;
     while (((size_t)1 << log_n) < 16 * n_chunks) ++log_n;
     size_t w1 = 0, w2 = 0;
     int32_t rc = vx_stark_proof_bound(VX_AIR_BLAKE_CHAIN, cfg, log_n, &w1);
@@ -385,7 +524,7 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
     // 2. Blake2b parent-hash-chain STARK over every compression of every header
     size_t chunks = 0;
     for (size_t i = 0; i < n_fetched; ++i) chunks += (sizes[i] + 127) / 128;
-    int log_n = 4;
+    int log_n = blk::TABLE_LOG;  // at least one copy of the lookup tables
     while (((size_t)1 << log_n) < 16 * chunks) ++log_n;
     vx_buf* trace = nullptr;
     int32_t rc = vx_alloc(ctx, ((size_t)blk::COLS) << log_n, &trace);

@@ -131,5 +131,6 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg,
 int32_t vx_lde_keep_dev(vx_ctx* ctx, const uint64_t* values, int log_n, size_t n_cols, int rate_bits, uint64_t shift, uint64_t* coef_brev,
                         uint64_t* dst);
 int32_t vx_scan_cols_dev(vx_ctx* ctx, uint64_t* data, int log_n, size_t n_cols, uint64_t* totals_host);
+int32_t vx_blake_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, uint64_t* aux, uint64_t* aux_pub);
 int32_t vx_lookup_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, uint64_t* aux, uint64_t* aux_pub);
 void vx_merkle_levels_launch(vx_ctx* ctx, uint64_t* levels, size_t n_leaves, size_t cap);

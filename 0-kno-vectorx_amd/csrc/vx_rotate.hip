@@ -75,7 +75,7 @@ int sha_rows_log(size_t n_keys) {
     return log_n;
 }
 int blake_rows_log(size_t chunks) {
-    int log_n = 4;
+    int log_n = 16;  // one copy of the 2^16-row XOR tables (BlakeChainAir)
     while (((size_t)1 << log_n) < 16 * chunks) ++log_n;
     return log_n;
 }

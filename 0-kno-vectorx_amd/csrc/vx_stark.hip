@@ -345,8 +345,12 @@ static void launch_q(QuotArgs& a, hipStream_t s) {
 static void no_periodic(std::vector<uint64_t>& v) { v.clear(); }
 static void mix_periodic(std::vector<uint64_t>& v) { v = {0, 0, 0, 1, 3, 5, 7, 11}; }
 static void blake_periodic(std::vector<uint64_t>& v) {
-    v.assign(16 * 16, 0);
+    v.assign(16 * 16 + 4 * 65536, 0);
     for (int k = 0; k < 16; ++k) v[k * 16 + k] = 1;  // sel_k: one-hot on row k of every 16-row block
+    for (uint64_t i = 0; i < 65536; ++i) {           // the XOR tables: row i = (a = i & 255, b = i >> 8)
+        const uint64_t a = i & 255, b = i >> 8;
+        v[256 + i] = a, v[256 + 65536 + i] = b, v[256 + 2 * 65536 + i] = (a ^ b) & 127, v[256 + 3 * 65536 + i] = (a ^ b) >> 7;
+    }
 }
 static void sha_periodic(std::vector<uint64_t>& v) {
     v.assign(4 * 64, 0);
@@ -364,7 +368,7 @@ static AirDesc desc(void (*pv)(std::vector<uint64_t>&), gen_aux_fn ga = nullptr)
     return {Air::ID, Air::COLS, Air::PUB, Air::PERIODIC, Air::PERIOD_LOG, pv, launch_q<Air>, count_q<Air>, Air::AUX, Air::CHAL, Air::AUXPUB, Air::plog, ga};
 }
 static const AirDesc AIRS[] = {
-    desc<ShaAir>(sha_periodic), desc<BlakeAir>(blake_periodic), desc<FibAir>(no_periodic), desc<MixAir>(mix_periodic),
+    desc<ShaAir>(sha_periodic), desc<BlakeAir>(blake_periodic, vx_blake_air_gen_aux), desc<FibAir>(no_periodic), desc<MixAir>(mix_periodic),
     desc<LookupAir>(lookup_periodic, vx_lookup_air_gen_aux),
 };
 static const AirDesc* find_air(int id) {
@@ -483,6 +487,23 @@ int32_t vx_quotient_eval(vx_ctx* ctx, int air_id, int rate_bits, const vx_buf* t
     VX_CHECK(alphas[0] < glh::P && alphas[1] < glh::P, "quotient eval: non-canonical challenge");
     DevMem mem{ctx};
     return quotient_eval_dev(ctx, air, log_n, rate_bits, trace_lde->d, alphas, public_inputs, n_public, nullptr, nullptr, out->d, mem);
+}
+
+int32_t vx_stark_aux_trace(vx_ctx* ctx, int air_id, const vx_buf* trace, int log_n, const uint64_t* challenges, size_t n_challenges, vx_buf* aux_out,
+                           uint64_t* aux_public_out) {
+    if (!ctx || !trace || !challenges || !aux_out) return VX_ERR_ARG;
+    const AirDesc* air = find_air(air_id);
+    VX_CHECK(air && air->aux > 0 && air->gen_aux, "aux trace: AIR %d has no auxiliary round", air_id);
+    VX_CHECK((int)n_challenges == air->chal, "aux trace: AIR %d takes %d challenges", air_id, air->chal);
+    VX_CHECK(log_n >= air->period_log && log_n <= 26, "aux trace: log_n %d out of range", log_n);
+    const size_t n = (size_t)1 << log_n;
+    VX_CHECK(trace->n >= n * (size_t)air->cols && aux_out->n >= n * (size_t)air->aux, "aux trace: buffers too small");
+    for (size_t i = 0; i < n_challenges; ++i) VX_CHECK(challenges[i] < glh::P, "aux trace: non-canonical challenge");
+    uint64_t apub[8] = {0};
+    VX_TRY(air->gen_aux(ctx, trace->d, log_n, challenges, aux_out->d, apub));
+    if (aux_public_out)
+        for (int q = 0; q < 2 * air->auxpub; ++q) aux_public_out[q] = apub[q];
+    return VX_OK;
 }
 
 int32_t vx_stark_prove(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_in, const vx_buf* trace, int log_n,

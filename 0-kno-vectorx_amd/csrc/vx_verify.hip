@@ -154,8 +154,12 @@ void host_intt(std::vector<uint64_t>& a) {
 void v_no_periodic(std::vector<uint64_t>& v) { v.clear(); }
 void v_mix_periodic(std::vector<uint64_t>& v) { v = {0, 0, 0, 1, 3, 5, 7, 11}; }
 void v_blake_periodic(std::vector<uint64_t>& v) {
-    v.assign(256, 0);
+    v.assign(16 * 16 + 4 * 65536, 0);
     for (int k = 0; k < 16; ++k) v[k * 16 + k] = 1;
+    for (uint64_t i = 0; i < 65536; ++i) {
+        const uint64_t a = i & 255, b = i >> 8;
+        v[256 + i] = a, v[256 + 65536 + i] = b, v[256 + 2 * 65536 + i] = (a ^ b) & 127, v[256 + 3 * 65536 + i] = (a ^ b) >> 7;
+    }
 }
 void v_sha_periodic(std::vector<uint64_t>& v) {
     v.assign(4 * 64, 0);
@@ -444,7 +448,7 @@ int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob,
                                uint32_t trusted_block, const uint8_t trusted_hash[32], const uint8_t* authority_set_hash,
                                uint32_t target_block, const uint8_t out96[96], char* err, size_t errlen) {
     if (!cfg || !blob || !trusted_hash || !out96) return VX_ERR_ARG;
-    NEED(len > 18 && blob[0] == 0x3245474e41525248ULL, "bad header_range blob");
+    NEED(len > 18 && blob[0] == 0x3345474e41525248ULL, "bad header_range blob");
     NEED(blob[1] == max_headers && blob[2] == trusted_block && blob[3] == target_block, "blob is for a different request");
     NEED(memcmp(blob + 4, out96, 96) == 0, "public outputs differ from the blob");
     NEED(target_block > trusted_block, "empty block range");

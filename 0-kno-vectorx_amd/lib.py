@@ -26,11 +26,11 @@ SYMBOLS = [
     "vx_blake2b_256_batch", "vx_sha256_pairs", "vx_verify_subchain", "vx_blake_chain_trace",
     "vx_ed25519_verify_batch", "vx_verify_simple_justification", "vx_sha_chain_trace",
     "vx_verify_epoch_end_header", "vx_rotate_proof_bound", "vx_rotate_prove", "vx_rotate_verify",
-    "vx_gather_proofs", "vx_quotient_eval", "vx_decode_header_batch", "vx_decode_precommit_batch",
+    "vx_gather_proofs", "vx_quotient_eval", "vx_decode_header_batch", "vx_decode_precommit_batch", "vx_stark_aux_trace",
 ]
 
-VX_AIR_FIBONACCI, VX_AIR_MIX, VX_AIR_BLAKE_CHAIN = 1, 2, 3
-VX_BLAKE_AIR_COLS = 4337
+VX_AIR_FIBONACCI, VX_AIR_MIX, VX_AIR_BLAKE_CHAIN, VX_AIR_LOOKUP = 1, 2, 6, 5
+VX_BLAKE_AIR_COLS, VX_BLAKE_AIR_AUX_COLS = 731, 268
 VX_AIR_SHA_CHAIN, VX_SHA_AIR_COLS = 4, 1444
 
 
@@ -125,6 +125,7 @@ def load_library():
         "vx_quotient_eval": [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, sz, vp],
         "vx_decode_header_batch": [vp, vp, sz, vp, sz, vp, vp, vp, vp, vp, vp],
         "vx_decode_precommit_batch": [vp, vp, sz, vp, vp, vp, vp, vp],
+        "vx_stark_aux_trace": [vp, C.c_int, vp, C.c_int, vp, sz, vp, vp],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -380,6 +381,13 @@ class Context:
         out = np.empty(need.value, dtype=np.uint64)
         self._ck(self.L.vx_stark_prove(self.h, air_id, C.byref(cfg), trace_buf.h, log_n, _ptr(pub), pub.size, _ptr(out), out.size, C.byref(need)))
         return out[: need.value]
+
+    def stark_aux_trace(self, air_id, trace_buf, log_n, challenges, n_aux_cols):
+        """The auxiliary (logUp) columns of an AIR for given lookup challenges -> Buffer [n_aux_cols][2^log_n]."""
+        ch = np.ascontiguousarray(challenges, dtype=np.uint64)
+        out = self.alloc(n_aux_cols << log_n)
+        self._ck(self.L.vx_stark_aux_trace(self.h, air_id, trace_buf.h, log_n, _ptr(ch), ch.size, out.h, None))
+        return out
 
     def header_range_prove(self, headers_buf, stride, sizes, max_headers, trusted_block, trusted_hash, target_block, cfg=None, out=None, just=None):
         """HeaderRangeCircuit::prove for a chain resident in HBM -> (96-byte output, proof blob words).

@@ -168,6 +168,12 @@ int32_t vx_stark_default_config(vx_stark_config* cfg);
  * 7 * <w_N>.  out[k*N + i] = (sum_j alpha_k^(K-1-j) c_j(x_i)) / Z_H(x_i) for the two challenges k = 0, 1. */
 int32_t vx_quotient_eval(vx_ctx* ctx, int air_id, int rate_bits, const vx_buf* trace_lde, int log_n, const uint64_t alphas[2],
                          const uint64_t* public_inputs, size_t n_public, vx_buf* out);
+/* The auxiliary (lookup / logUp) columns an AIR derives from its trace once the lookup challenges are known -- the step
+ * vx_stark_prove runs between the trace cap and the constraint challenges, exposed on its own as a test surface.
+ * trace: the AIR's main columns [cols][2^log_n]; challenges: the AIR's CHAL base-field elements (canonical);
+ * aux_out: [aux cols][2^log_n]; aux_public_out (may be NULL): the values published with the auxiliary cap. */
+int32_t vx_stark_aux_trace(vx_ctx* ctx, int air_id, const vx_buf* trace, int log_n, const uint64_t* challenges, size_t n_challenges,
+                           vx_buf* aux_out, uint64_t* aux_public_out);
 /* upper bound on the proof length (uint64 words) for buffer sizing */
 int32_t vx_stark_proof_bound(int air_id, const vx_stark_config* cfg, int log_n, size_t* n_words);
 int32_t vx_stark_prove(vx_ctx* ctx, int air_id, const vx_stark_config* cfg, const vx_buf* trace, int log_n,
@@ -192,13 +198,18 @@ int32_t vx_sha256_pairs(vx_ctx* ctx, const uint8_t* pairs64, size_t n, uint8_t* 
 /* ---- K8: BlakeChainAir trace generation (the Blake2b witness behind hash_encoded_header,
  * circuits/builder/header.rs:14-19, and the parent-hash links of
  * circuits/builder/subchain_verification.rs:163-177).  headers as for vx_verify_subchain (stride a
- * multiple of 128).  Writes the column-major trace (4337 columns x 2^log_n rows, 16 rows per
- * compression, padded with inactive blocks) into trace_out, the 18 public inputs (trusted hash,
- * target hash as 32-bit little-endian limbs, first and last block number) and optionally the
- * digests (host).  The AIR also proves that header i carries block number first_block_number + i
- * as a 4-byte SCALE compact int (numbers in [2^14, 2^30); decoder.rs:64-66, subchain_verification.rs:166-168).
+ * multiple of 128).  Writes the column-major MAIN trace (731 columns x 2^log_n rows, 16 rows per
+ * compression, padded with inactive blocks; byte cells + the multiplicities of the two 2^16-row XOR
+ * lookup tables, so log_n >= 16) into trace_out, the 18 public inputs (trusted hash, target hash as
+ * 32-bit little-endian limbs, first and last block number) and optionally the digests (host).  The 268
+ * auxiliary (logUp) columns are derived inside vx_stark_prove once the lookup challenges exist.
+ * KNOWN DEVIATION from decoder.rs:39-92 (which decodes all four SCALE compact modes): the AIR proves
+ * that header i carries block number first_block_number + i as a 4-byte (mode 2) compact int, i.e.
+ * block numbers in [2^14, 2^30) -- every Avail height since block 16,384; other ranges are refused with
+ * VX_ERR_ARG (tests/test_gpu_decoders.py pins the code).  The native path (vx_verify_subchain,
+ * vx_decode_header_batch) handles all four modes.
  * Prove it with vx_stark_prove(ctx, VX_AIR_BLAKE_CHAIN, ...). */
-enum { VX_AIR_BLAKE_CHAIN = 3, VX_BLAKE_AIR_COLS = 4337 };
+enum { VX_AIR_BLAKE_CHAIN = 6, VX_BLAKE_AIR_COLS = 731, VX_BLAKE_AIR_AUX_COLS = 268 };
 int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_headers,
                              const uint8_t trusted_hash[32], uint32_t first_block_number, int log_n, vx_buf* trace_out,
                              uint64_t public_inputs_out[18], uint8_t* digests_out);
@@ -252,7 +263,7 @@ int32_t vx_verify_simple_justification(vx_ctx* ctx, uint32_t block_number, const
                                        const uint8_t* validator_signed, uint32_t num_authorities, uint32_t max_authorities);
 
 /* ---- top level: HeaderRangeCircuit::prove (circuits/header_range.rs:26-59 via Circuit::prove, :167).
- * Inputs as vx_verify_subchain.  Output blob (uint64 words): "HRRANGE2", max_headers, trusted_block,
+ * Inputs as vx_verify_subchain.  Output blob (uint64 words): "HRRANGE3", max_headers, trusted_block,
  * target_block, the 96 public output bytes (12 words), the two proof lengths, then the BlakeChainAir
  * STARK proof and (when a justification was given) the ShaChainAir proof of the authority-set commitment.
  * What the blob proves today is listed in DESIGN.md section 2 (the justification / Merkle-root /

@@ -1,47 +1,46 @@
-"""BlakeChainAir (AIR id 3), restated for the oracle -- TEST INFRASTRUCTURE.
+"""BlakeChainAir (AIR id 6), restated for the oracle -- TEST INFRASTRUCTURE.
 
-Statement: "there is a sequence of byte strings (encoded headers) whose BLAKE2b-256 digests
-form a parent-hash chain: the first 32 bytes of each string are the digest of the previous
-one, the first parent is `trusted_header_hash`, the last digest is `target_header_hash`" --
-the hash-chain core of verify_subchain (/root/reference
-circuits/builder/subchain_verification.rs:150-177: hash_encoded_header + parent-hash link) with
-BLAKE2b per circuits/builder/header.rs:14-19 (curta_blake2b_variable) and RFC 7693.
-The reference's own Blake2b AIR (starkyx v1.0.0, byte lookups) is not in /root/reference; this
-AIR is ours (bit-decomposed ARX, degree <= 3), so trace layout parity with the reference is
-not claimed -- parity here is GPU trace/proof == this restatement, digests == hashlib.
+Same statement as the bit-decomposed BlakeChainAir it replaces ("a sequence of byte strings, numbered first..last
+in their SCALE block-number field, whose BLAKE2b-256 digests chain from trusted_header_hash to target_header_hash
+through the parent-hash field" -- /root/reference circuits/builder/subchain_verification.rs:150-177,
+circuits/builder/header.rs:14-19, decoder.rs:64-66), but arithmetised the way the reference's own Blake2b STARK is
+(curta, starkyx v1.0.0 -- byte lookups; not vendored, so this is a from-scratch design, not a restatement of it):
+every 64-bit word is 8 BYTE cells, XORs are lookups into a 2^16-row table through a logUp argument in an auxiliary
+commitment round, additions are 32-bit limb identities.  731 main + 268 auxiliary columns instead of 4337.
 
-Layout: 16 rows per compression ("block"), r = row mod 16:
-  r = 0      INIT  : the out-state columns hold the initial work vector v
-  r = 1..12  ROUND : row r holds the 8 G evaluations of round r-1 (column step then diagonal)
-  r = 13     FIN1  : T = H ^ v[0..8), V' = v[8..16), HB = bits of H   (in free G columns)
-  r = 14     FIN2  : HO = T ^ V' = h_out bits (free G columns), H limbs = h_out
-  r = 15     PAD   : H = next block's h_in (IV^param after a final block), D updated
-The chaining value H is carried as 16 limb columns; its bits exist only where an XOR needs them.
-Also enforced: zero padding of the final chunk beyond `inc` bytes (mask columns MK, counter CNT)
-and sequential SCALE block numbers.  Not covered: state & data roots (future AIRs).
+Layout: 16 rows per compression, r = row mod 16 (as before): 0 INIT, 1..12 ROUND (row r = round r-1), 13 FIN1,
+14 FIN2, 15 PAD.  A ROUND row holds the eight G evaluations of its round; per G nine groups of 8 cells:
+  A1 = a + b + x      D1 = (d ^ A1) >>> 32     C1 = c + D1       B1 = (b ^ C1) >>> 24
+  A2 = A1 + B1 + y    D2 = (D1 ^ A2) >>> 16    C2 = C1 + D2      (L, T) = low 7 bits / top bit of each byte of B1 ^ C2
+and B2 = (B1 ^ C2) >>> 63 is never stored: its byte j is the linear expression 2 L[j] + T[j-1].  Rotations by 32, 24,
+16 are byte re-indexings.  Lookup tables (periodic columns, period 2^16, row i = (a = i & 255, b = i >> 8)):
+  T1: (a, b, a ^ b)                       T2: (a, b, (a ^ b) & 127, (a ^ b) >> 7)
+Each lookup contributes 1/(beta + fingerprint(tuple)); two lookups share one extension-field helper column
+(h D_u D_v = m (D_u + D_v), degree 3), the table side contributes -(M1/D_t1 + M2/D_t2) through one more helper, and a
+running sum Z closes cyclically: the sum over all rows is zero iff every looked-up tuple is in its table.
+Finalisation reuses the same-row D2 lookups of rows 13 and 14:  U = v_lo ^ v_hi, then h_out = U ^ h.
+The trace must have at least 2^16 rows (one copy of the tables).
 """
+import hashlib
+
 import numpy as np
 
+from . import oracle as O
+from . import stark_ref as S
+
 P = 2**64 - 2**32 + 1
-ID = 3
-# ---- column layout
-N_G = 8
-GB0 = 0  # GB(k, w, i) = ((k*8 + w)*64 + i)
-W_A1, W_D1, W_C1, W_B1, W_A2, W_D2, W_C2, W_B2 = range(8)
-CAR0 = 4096  # CAR(k, j)
-MS0 = 4160  # MS(s, h)
-MB0 = 4192
-HL0 = 4256  # chaining value H as 16 x 32-bit limbs: HL(w, h); its bits appear only in free G cells of rows 13/14
-D0 = 4272
-ACT, FIN, FIRST, CAP, T, INC = 4280, 4281, 4282, 4283, 4284, 4285
-TB0 = 4286
-IB0 = 4318
-NUM, FA = 4326, 4327  # block number of the current header; FA = FIRST * ACT
-MK0, CNT = 4328, 4336  # MK[b]: byte 8r+b of the chunk lies below `inc`; CNT: running count of such bytes
-COLS = 4337
-PUB = 18
-PERIODIC = 16
-PERIOD_LOG = 4
+ID = 6
+S_A1, S_D1, S_C1, S_B1, S_A2, S_D2, S_C2, S_L, S_T = range(9)
+CAR0, MS0, MB0, HL0, D0 = 576, 608, 640, 648, 664
+ACT, FIN, FIRST, CAP, T, INC, NUM, FA = range(672, 680)
+TB0, IB0, MK0, CNT, M1, M2, COLS = 680, 712, 720, 728, 729, 730, 731
+N_HELP = 134  # 128 G helpers, 4 message-byte range checks, table helper, running sum Z
+HM0, HT, ZZ = 128, 132, 133
+AUX, CHAL, AUXPUB = 2 * N_HELP, 4, 0
+PUB, PERIODIC, PERIOD_LOG = 18, 20, 16
+PERIOD_LOGS = [4] * 16 + [16] * 4
+TABLE_LOG = 16
+INV32 = pow(1 << 32, P - 2, P)
 
 IV = [0x6A09E667F3BCC908, 0xBB67AE8584CAA73B, 0x3C6EF372FE94F82B, 0xA54FF53A5F1D36F1,
       0x510E527FADE682D1, 0x9B05688C2B3E6C1F, 0x1F83D9ABFB41BD6B, 0x5BE0CD19137E2179]
@@ -57,12 +56,12 @@ SIGMA = [
 M64 = (1 << 64) - 1
 
 
-def GB(k, w, i):
-    return (k * 8 + w) * 64 + i
+def GC(k, slot, j):
+    return (k * 9 + slot) * 8 + j
 
 
-def CAR(k, j):
-    return CAR0 + k * 8 + j
+def CAR(k, q):
+    return CAR0 + 4 * k + q
 
 
 def MS(s, h):
@@ -73,28 +72,12 @@ def HL(w, h):
     return HL0 + 2 * w + h
 
 
-def FT(w, i):  # row 13: T = H ^ v_lo;  row 14: HO = h_out bits
-    return GB(w % 4, w // 4, i)
+def HG(k, grp, pair):
+    return (k * 4 + grp) * 4 + pair
 
 
-def FV(w, i):  # row 13: V' = v_hi
-    return GB(w % 4, 2 + w // 4, i)
-
-
-def FH(w, i):  # row 13: HB = bits of h_in
-    return GB(w % 4, 4 + w // 4, i)
-
-
-def out_word(w):
-    """(G index, word slot) holding out-state word v[w] (diagonal-step outputs)."""
-    if w < 4:
-        return 4 + w, W_A2
-    m = w % 4
-    if w < 8:
-        return 4 + (m + 3) % 4, W_B2
-    if w < 12:
-        return 4 + (m + 2) % 4, W_C2
-    return 4 + (m + 1) % 4, W_D2
+def AX(e, comp):  # column of component `comp` of auxiliary extension element e (row index space: main ++ aux)
+    return COLS + 2 * e + comp
 
 
 def ms_order(r):
@@ -115,7 +98,72 @@ def rc_slot(r):
 
 
 def periodic_values():
-    return [[1 if r == k else 0 for r in range(16)] for k in range(16)]
+    idx = np.arange(1 << TABLE_LOG)
+    a, b = idx & 255, idx >> 8
+    sel = [[1 if r == k else 0 for r in range(16)] for k in range(16)]
+    return sel + [a.tolist(), b.tolist(), ((a ^ b) & 127).tolist(), ((a ^ b) >> 7).tolist()]
+
+
+# ----------------------------------------------------------------------------- shared cell expressions
+def out_byte(row, w, j):
+    """Byte j of out-state word v[w] (the diagonal-step outputs of `row`)."""
+    m = w % 4
+    if w < 4:
+        return row[GC(4 + w, S_A2, j)]
+    if w < 8:
+        k = 4 + (m + 3) % 4
+        l = row[GC(k, S_L, j)]
+        return l + l + row[GC(k, S_T, (j + 7) % 8)]
+    if w < 12:
+        return row[GC(4 + (m + 2) % 4, S_C2, j)]
+    return row[GC(4 + (m + 1) % 4, S_D2, j)]
+
+
+def g_inputs(loc, nxt, k):
+    """Byte lists (a, b, c, d) feeding G number k of the round held in `nxt`."""
+    if k < 4:
+        return [[out_byte(loc, w, j) for j in range(8)] for w in (k, 4 + k, 8 + k, 12 + k)]
+    j0 = k - 4
+    kb = (j0 + 1) % 4
+    b = []
+    for j in range(8):
+        l = nxt[GC(kb, S_L, j)]
+        b.append(l + l + nxt[GC(kb, S_T, (j + 7) % 8)])
+    return [[nxt[GC(j0, S_A2, j)] for j in range(8)], b, [nxt[GC((j0 + 2) % 4, S_C2, j)] for j in range(8)],
+            [nxt[GC((j0 + 3) % 4, S_D2, j)] for j in range(8)]]
+
+
+def cells(row, k, slot):
+    return [row[GC(k, slot, j)] for j in range(8)]
+
+
+def limb(bytes8, h):
+    acc = bytes8[4 * h + 3]
+    for j in (2, 1, 0):
+        acc = acc * 256 + bytes8[4 * h + j]
+    return acc
+
+
+def lookups(loc, nxt, sel):
+    """The 264 lookups of the row pair in protocol order: (multiplicity, table, tuple).  Works on any backend
+    (field vectors, extension scalars, plain numpy integers)."""
+    g_on = sel[0]
+    for r in range(1, 12):
+        g_on = g_on + sel[r]
+    m3 = g_on + sel[12] + sel[13]
+    out = []
+    for k in range(8):
+        a, b, c, d = g_inputs(loc, nxt, k)
+        A1, D1, C1, B1, A2, D2, C2, L, Tt = (cells(nxt, k, s) for s in range(9))
+        out += [(g_on, 1, (d[i], A1[i], D1[(i + 4) % 8])) for i in range(8)]
+        out += [(g_on, 1, (b[i], C1[i], B1[(i + 5) % 8])) for i in range(8)]
+        out += [(m3, 1, (D1[i], A2[i], D2[(i + 6) % 8])) for i in range(8)]
+        out += [(g_on, 2, (B1[i], C2[i], L[i], Tt[i])) for i in range(8)]
+    one = sel[0]
+    for r in range(1, 16):
+        one = one + sel[r]
+    out += [(one, 1, (nxt[MB0 + i], 0, nxt[MB0 + i])) for i in range(8)]
+    return out
 
 
 # ----------------------------------------------------------------------------- witness
@@ -187,198 +235,257 @@ def compress(h, m_bytes, t, fin):
     return h_out, recs, v0, m
 
 
-def gen_trace(messages, log_n, trusted_hash, first_number=None, forge=None):
-    """Full trace [COLS][n] (uint64) + public inputs (trusted / target hash limbs, first / last number).
-    forge(blocks, target, last_number) -> (blocks, target, last_number) lets a negative test edit the block list."""
-    n = 1 << log_n
-    if first_number is None:
-        first_number = (int.from_bytes(messages[0][32:36], "little") - 2) // 4
-    blocks, target, last_number = gen_blocks(messages, n // 16, trusted_hash, first_number)
-    if forge is not None:
-        blocks, target, last_number = forge(blocks, target, last_number)
-    tr = np.zeros((COLS, n), dtype=np.uint64)
+def bytes_of(x):
+    return [(x >> (8 * j)) & 0xFF for j in range(8)]
 
-    def put_bits(row, col0, val, nbits=64):
-        for i in range(nbits):
-            tr[col0 + i, row] = (val >> i) & 1
+
+def block_rows(blk):
+    """The 16 rows [COLS][16] of one compression (multiplicities left zero)."""
+    t = np.zeros((COLS, 16), dtype=np.uint64)
+    h_out, recs, v0, m = compress(blk["h"], blk["m"], blk["t"], blk["fin"])
+    h_next = list(IVP) if blk["fin"] else h_out
+    cap = blk["act"] and blk["fin"]
 
     def limbs32(b):
         return [int.from_bytes(b[4 * j: 4 * j + 4], "little") for j in range(len(b) // 4)]
 
-    for bi, blk in enumerate(blocks):
-        base = 16 * bi
-        h_out, recs, v0, m = compress(blk["h"], blk["m"], blk["t"], blk["fin"])
-        h_next = list(IVP) if blk["fin"] else h_out
-        d_limbs = limbs32(blk["D"])
-        digest_limbs = limbs32(b"".join(x.to_bytes(8, "little") for x in h_out[:4]))
-        cap = blk["act"] and blk["fin"]
-        for r in range(16):
-            row = base + r
-            # flags / registers
-            tr[ACT, row], tr[FIN, row], tr[FIRST, row], tr[CAP, row] = blk["act"], int(blk["fin"]), int(blk["first"]), int(cap)
-            tr[T, row], tr[INC, row] = blk["t"], blk["inc"]
-            tr[NUM, row], tr[FA, row] = blk["num"], int(blk["first"] and blk["act"])
-            put_bits(row, TB0, blk["t"], 32)
-            put_bits(row, IB0, blk["inc"], 8)
-            dl = digest_limbs if (r == 15 and cap) else d_limbs
-            for j in range(8):
-                tr[D0 + j, row] = dl[j]
-            hv = blk["h"] if r <= 13 else (h_out if r == 14 else h_next)
+    d_limbs = limbs32(blk["D"])
+    digest_limbs = limbs32(b"".join(x.to_bytes(8, "little") for x in h_out[:4]))
+
+    def put(row, k, slot, word):
+        for j, bv in enumerate(bytes_of(word)):
+            t[GC(k, slot, j), row] = bv
+
+    def put_b2(row, k, word):  # cells (L, T) such that 2 L[j] + T[j-1] are the bytes of `word`
+        x = rotr(word, 1)
+        for j, bv in enumerate(bytes_of(x)):
+            t[GC(k, S_L, j), row], t[GC(k, S_T, j), row] = bv & 127, bv >> 7
+
+    def put_out(row, w, word):
+        mm = w % 4
+        if w < 4:
+            put(row, 4 + w, S_A2, word)
+        elif w < 8:
+            put_b2(row, 4 + (mm + 3) % 4, word)
+        elif w < 12:
+            put(row, 4 + (mm + 2) % 4, S_C2, word)
+        else:
+            put(row, 4 + (mm + 1) % 4, S_D2, word)
+
+    vfin = recs[11]["v"]
+    for r in range(16):
+        t[ACT, r], t[FIN, r], t[FIRST, r], t[CAP, r] = blk["act"], int(blk["fin"]), int(blk["first"]), int(cap)
+        t[T, r], t[INC, r], t[NUM, r], t[FA, r] = blk["t"], blk["inc"], blk["num"], int(blk["first"] and blk["act"])
+        for i in range(32):
+            t[TB0 + i, r] = (blk["t"] >> i) & 1
+        for i in range(8):
+            t[IB0 + i, r] = (blk["inc"] >> i) & 1
+        dl = digest_limbs if (r == 15 and cap) else d_limbs
+        for j in range(8):
+            t[D0 + j, r] = dl[j]
+        hv = blk["h"] if r <= 13 else (h_out if r == 14 else h_next)
+        for w in range(8):
+            t[HL(w, 0), r], t[HL(w, 1), r] = hv[w] & 0xFFFFFFFF, hv[w] >> 32
+        order = ms_order(r)
+        for s in range(16):
+            t[MS(s, 0), r], t[MS(s, 1), r] = m[order[s]] & 0xFFFFFFFF, m[order[s]] >> 32
+        for j, bv in enumerate(bytes_of(m[r])):
+            t[MB0 + j, r] = bv
+        for b in range(8):
+            t[MK0 + b, r] = 1 if 8 * r + b < blk["inc"] else 0
+        t[CNT, r] = min(blk["inc"], 8 * (r + 1))
+        if r == 0:
+            for w in range(16):
+                put_out(r, w, v0[w])
+        elif r <= 12:
+            rec = recs[r - 1]["words"]
+            for k in range(8):
+                a1, d1, c1, b1, a2, d2, c2, _b2 = rec[k]["w"]
+                for slot, word in ((S_A1, a1), (S_D1, d1), (S_C1, c1), (S_B1, b1), (S_A2, a2), (S_D2, d2), (S_C2, c2)):
+                    put(r, k, slot, word)
+                x = b1 ^ c2
+                for j, bv in enumerate(bytes_of(x)):
+                    t[GC(k, S_L, j), r], t[GC(k, S_T, j), r] = bv & 127, bv >> 7
+                a, b, _c, _d = rec[k]["ins"]
+
+                def carries(ops):
+                    lo = sum(o & 0xFFFFFFFF for o in ops)
+                    hi = sum(o >> 32 for o in ops) + (lo >> 32)
+                    return lo >> 32, hi >> 32
+
+                cs = carries([a, b, rec[k]["x"]]) + carries([a1, b1, rec[k]["y"]])
+                for q in range(4):
+                    t[CAR(k, q), r] = cs[q]
+        elif r == 13:
             for w in range(8):
-                tr[HL(w, 0), row], tr[HL(w, 1), row] = hv[w] & 0xFFFFFFFF, hv[w] >> 32
-            # message schedule + range check of natural word r
-            order = ms_order(r)
-            for s in range(16):
-                tr[MS(s, 0), row] = m[order[s]] & 0xFFFFFFFF
-                tr[MS(s, 1), row] = m[order[s]] >> 32
-            put_bits(row, MB0, m[r])
-            for b in range(8):
-                tr[MK0 + b, row] = 1 if 8 * r + b < blk["inc"] else 0
-            tr[CNT, row] = min(blk["inc"], 8 * (r + 1))
-            # G area
-            if r == 0:
-                for w in range(16):
-                    k, slot = out_word(w)
-                    put_bits(row, GB(k, slot, 0), v0[w])
-            elif r <= 12:
-                rec = recs[r - 1]["words"]
-                for k in range(8):
-                    for slot in range(8):
-                        put_bits(row, GB(k, slot, 0), rec[k]["w"][slot])
-                    a, b, c, d = rec[k]["ins"]
-                    a1, d1, c1, b1, a2, d2, c2, b2 = rec[k]["w"]
-                    x, y = rec[k]["x"], rec[k]["y"]
+                put(r, w, S_D1, vfin[w])
+                put(r, w, S_A2, vfin[8 + w])
+                put(r, w, S_D2, rotr(vfin[w] ^ vfin[8 + w], 16))
+        elif r == 14:
+            for w in range(8):
+                u = vfin[w] ^ vfin[8 + w]
+                put(r, w, S_D1, u)
+                put(r, w, S_A2, blk["h"][w])
+                put(r, w, S_D2, rotr(u ^ blk["h"][w], 16))
+    return t
 
-                    def carries(ops, res):
-                        lo = sum(o & 0xFFFFFFFF for o in ops)
-                        klo = lo >> 32
-                        hi = sum(o >> 32 for o in ops) + klo
-                        assert (lo & 0xFFFFFFFF) == (res & 0xFFFFFFFF) and (hi & 0xFFFFFFFF) == res >> 32
-                        return klo, hi >> 32
 
-                    cs = carries([a, b, x], a1) + carries([c, d1], c1) + carries([a1, b1, y], a2) + carries([c1, d2], c2)
-                    for j in range(8):
-                        tr[CAR(k, j), row] = cs[j]
-            elif r == 13:
-                vfin = recs[11]["v"]
-                for w in range(8):
-                    put_bits(row, FT(w, 0), blk["h"][w] ^ vfin[w])
-                    put_bits(row, FV(w, 0), vfin[8 + w])
-                    put_bits(row, FH(w, 0), blk["h"][w])
-            elif r == 14:
-                for w in range(8):
-                    put_bits(row, FT(w, 0), h_out[w])
-    lt, lg = [int.from_bytes(trusted_hash[4 * j: 4 * j + 4], "little") for j in range(8)], [int.from_bytes(target[4 * j: 4 * j + 4], "little") for j in range(8)]
+def int_rows(tr):
+    """(loc, nxt, sel) views of a trace as plain integer arrays (for counting lookups)."""
+    n = tr.shape[1]
+    loc = [tr[j].astype(np.int64) for j in range(tr.shape[0])]
+    nxt = [np.roll(x, -1) for x in loc]
+    r = np.arange(n) % 16
+    return loc, nxt, [(r == k).astype(np.int64) for k in range(16)]
+
+
+def multiplicities(tr):
+    n = tr.shape[1]
+    loc, nxt, sel = int_rows(tr)
+    m1, m2 = np.zeros(1 << TABLE_LOG, dtype=np.int64), np.zeros(1 << TABLE_LOG, dtype=np.int64)
+    for m, table, tup in lookups(loc, nxt, sel):
+        a, b = np.broadcast_to(tup[0], (n,)), np.broadcast_to(tup[1], (n,))
+        idx = (a + 256 * b)[np.asarray(m) != 0]
+        assert idx.size == 0 or (0 <= idx.min() and idx.max() < (1 << TABLE_LOG)), "lookup input is not a byte"
+        np.add.at(m1 if table == 1 else m2, idx, 1)
+    return m1, m2
+
+
+def gen_trace(messages, log_n, trusted_hash, first_number=None, forge=None):
+    """Full main trace [COLS][n] + public inputs (trusted / target hash limbs, first / last block number)."""
+    n = 1 << log_n
+    assert log_n >= TABLE_LOG, "the trace must hold one copy of the 2^16-row lookup tables"
+    if first_number is None:
+        first_number = (int.from_bytes(messages[0][32:36], "little") - 2) // 4
+    # padding blocks are identical: generate each distinct block once
+    real_blocks, target, last_number = gen_blocks(messages, sum(max(1, (len(m) + 127) // 128) for m in messages), trusted_hash, first_number)
+    pad = dict(m=target + (4 * last_number + 2).to_bytes(4, "little") + bytes(92), h=list(IVP), t=36, inc=36, fin=True, first=True, act=0, D=target, num=last_number)
+    blocks = real_blocks + [pad]
+    if forge is not None:
+        blocks, target, last_number = forge(real_blocks, pad, target, last_number)
+    assert len(blocks) - 1 <= n // 16
+    tr = np.zeros((COLS, n), dtype=np.uint64)
+    for bi, blk in enumerate(blocks[:-1]):
+        tr[:, 16 * bi: 16 * bi + 16] = block_rows(blk)
+    n_pad = n // 16 - (len(blocks) - 1)
+    if n_pad:
+        tr[:, 16 * (len(blocks) - 1):] = np.tile(block_rows(blocks[-1]), n_pad)
+    m1, m2 = multiplicities(tr)
+    tr[M1, : 1 << TABLE_LOG], tr[M2, : 1 << TABLE_LOG] = m1.astype(np.uint64), m2.astype(np.uint64)
+    lt = [int.from_bytes(trusted_hash[4 * j: 4 * j + 4], "little") for j in range(8)]
+    lg = [int.from_bytes(target[4 * j: 4 * j + 4], "little") for j in range(8)]
     return tr, lt + lg + [first_number, last_number], target
 
 
 # ----------------------------------------------------------------------------- constraints
+def fingerprints(loc, nxt, sel, per, chal):
+    """-> (list of (m, D) for the 264 lookups, D_t1, D_t2) with D = beta + fingerprint, extension valued."""
+    X2 = S.X2
+    beta, gamma = X2(chal[0], chal[1]), X2(chal[2], chal[3])
+    g2 = gamma * gamma
+    g3 = g2 * gamma
+    g4 = g2 * g2
+
+    def fp1(a, b, c):
+        return beta + a + gamma * b + g2 * c
+
+    def fp2(a, b, l, t):
+        return beta + a + gamma * b + g2 * l + g3 * t + g4
+
+    ds = [(m, fp1(*tup) if table == 1 else fp2(*tup)) for m, table, tup in lookups(loc, nxt, sel)]
+    ta, tb, tl, tt = per[16], per[17], per[18], per[19]
+    return ds, fp1(ta, tb, tl + tt * 128), fp2(ta, tb, tl, tt)
+
+
 class BlakeChainAir:
-    ID, COLS, PUB, PERIODIC, PERIOD_LOG = ID, COLS, PUB, PERIODIC, PERIOD_LOG
+    ID, COLS, PUB, PERIODIC, PERIOD_LOG, PERIOD_LOGS = ID, COLS, PUB, PERIODIC, PERIOD_LOG, PERIOD_LOGS
+    AUX, CHAL, AUXPUB = AUX, CHAL, AUXPUB
     periodic_values = staticmethod(periodic_values)
 
     @staticmethod
-    def eval(loc, nxt, per, pub, c):
+    def eval(loc, nxt, per, pub, c, chal, aux_pub):
+        X2 = S.X2
         sel = per
         g_on = sel[0]
         for r in range(1, 12):
             g_on = g_on + sel[r]
-
-        def xor(x, y):
-            return x + y - 2 * (x * y)
-
-        def limb(row, col0, h):
-            acc = row[col0 + 32 * h + 31]
-            for i in range(30, -1, -1):
-                acc = acc + acc + row[col0 + 32 * h + i]
-            return acc
-
         two32 = 1 << 32
 
         # ---- 1. booleans
-        for col in range(0, 4096):
+        for col in list(range(TB0, TB0 + 32)) + list(range(IB0, IB0 + 8)) + list(range(MK0, MK0 + 8)) + [ACT, FIN, FIRST, CAP, FA]:
             c.constraint(loc[col] * (loc[col] - 1))
-        for col in list(range(MB0, MB0 + 64)) + list(range(TB0, TB0 + 32)) + list(range(IB0, IB0 + 8)) + [ACT, FIN, FIRST, CAP, FA]:
-            c.constraint(loc[col] * (loc[col] - 1))
-        # ---- 2. carries
+        # ---- 2. carries of the three-operand additions
         for k in range(8):
-            for j in range(8):
-                x = loc[CAR(k, j)]
-                if j in (0, 1, 4, 5):
-                    c.constraint(x * (x - 1) * (x - 2))
-                else:
-                    c.constraint(x * (x - 1))
-        # ---- 3. the 8 G functions of the round in row `nxt` (gated by g_on of the local row)
+            for q in range(4):
+                x = loc[CAR(k, q)]
+                c.constraint(x * (x - 1) * (x - 2))
+        # ---- 3. additions of the eight G functions of the round in `nxt` (gated by g_on of the local row)
         for k in range(8):
-            if k < 4:  # column step: inputs = out-state of the local row
-                ins = [(loc, GB(*out_word(w), 0)) for w in (k, 4 + k, 8 + k, 12 + k)]
-            else:  # diagonal step: inputs = column-step outputs in the same (next) row
-                j = k - 4
-                ins = [(nxt, GB(j, W_A2, 0)), (nxt, GB((j + 1) % 4, W_B2, 0)), (nxt, GB((j + 2) % 4, W_C2, 0)), (nxt, GB((j + 3) % 4, W_D2, 0))]
-            (ra, ca), (rb, cb), (rc, cc), (rd, cd) = ins
+            a, b, cc, _d = g_inputs(loc, nxt, k)
+            A1, D1, C1, B1, A2, D2, C2 = (cells(nxt, k, s) for s in range(7))
             xs, ys = (2 * k, 2 * k + 1) if k < 4 else (8 + 2 * (k - 4), 8 + 2 * (k - 4) + 1)
-            w = lambda slot: GB(k, slot, 0)  # noqa: E731
 
-            def add3(r1, c1_, r2, c2_, msg_slot, res_slot, car_j):
+            def add3(o1, o2, slot, res, q0):
                 cin = None
                 for h in range(2):
-                    lhs = limb(r1, c1_, h) + limb(r2, c2_, h)
-                    if msg_slot is not None:
-                        lhs = lhs + nxt[MS(msg_slot, h)]
+                    lhs = limb(o1, h) + limb(o2, h) + nxt[MS(slot, h)]
                     if cin is not None:
                         lhs = lhs + cin
-                    car = nxt[CAR(k, car_j + h)]
-                    c.constraint(g_on * (lhs - limb(nxt, w(res_slot), h) - two32 * car))
+                    car = nxt[CAR(k, q0 + h)]
+                    c.constraint(g_on * (lhs - limb(res, h) - car * two32))
                     cin = car
 
-            def xorrot(r1, c1_, r2, c2_, res_slot, rot):
-                for i in range(64):
-                    s = (i + rot) % 64
-                    c.constraint(g_on * (nxt[w(res_slot) + i] - xor(r1[c1_ + s], r2[c2_ + s])))
-
-            add3(ra, ca, rb, cb, xs, W_A1, 0)
-            xorrot(rd, cd, nxt, w(W_A1), W_D1, 32)
-            add3(rc, cc, nxt, w(W_D1), None, W_C1, 2)
-            xorrot(rb, cb, nxt, w(W_C1), W_B1, 24)
-            add3(nxt, w(W_A1), nxt, w(W_B1), ys, W_A2, 4)
-            xorrot(nxt, w(W_D1), nxt, w(W_A2), W_D2, 16)
-            add3(nxt, w(W_C1), nxt, w(W_D2), None, W_C2, 6)
-            xorrot(nxt, w(W_B1), nxt, w(W_C2), W_B2, 63)
-        # ---- 4. INIT row: out-state = (H, IV[0..4), IV4 ^ t, IV5, IV6 ^ f, IV7)
-        for wd in range(16):
-            k, slot = out_word(wd)
-            if wd < 8:  # v[0..8) = h_in: compared limb-wise with the H register
+            def add2(o1, o2, res):
+                cin = None
                 for h in range(2):
-                    c.constraint(sel[0] * (limb(loc, GB(k, slot, 0), h) - loc[HL(wd, h)]))
-                continue
-            for i in range(64):
-                cell = loc[GB(k, slot, i)]
-                bit = (IV[wd - 8] >> i) & 1
-                if wd == 12 and i < 32:
-                    want = loc[TB0 + i] if bit == 0 else 1 - loc[TB0 + i]
-                elif wd == 14:
-                    want = loc[FIN] if bit == 0 else 1 - loc[FIN]
+                    tt_ = limb(o1, h) + limb(o2, h) - limb(res, h)
+                    if cin is not None:
+                        tt_ = tt_ + cin
+                    cy = tt_ * INV32  # the carry as a linear expression: 0 or 1
+                    c.constraint(g_on * (cy * (cy - 1)))
+                    cin = cy
+
+            add3(a, b, xs, A1, 0)
+            add2(cc, D1, C1)
+            add3(A1, B1, ys, A2, 2)
+            add2(C1, D2, C2)
+        # ---- 4. INIT row: out-state = (H, IV[0..4), IV4 ^ t, IV5, IV6 ^ f, IV7), limb-wise
+        for w in range(16):
+            ob = [out_byte(loc, w, j) for j in range(8)]
+            for h in range(2):
+                if w < 8:
+                    want = loc[HL(w, h)]
                 else:
-                    want = bit
-                c.constraint(sel[0] * (cell - want))
-        # ---- 5. finalisation: FIN1 (T = H ^ vlo, V' = vhi), FIN2 (H' = T ^ V'), PAD (H' = f ? IVP : H)
+                    iv = (IV[w - 8] >> (32 * h)) & 0xFFFFFFFF
+                    if w == 12 and h == 0:
+                        want = None
+                        for i in range(32):
+                            bit = (iv >> i) & 1
+                            term = (loc[TB0 + i] if bit == 0 else 1 - loc[TB0 + i]) * (1 << i)
+                            want = term if want is None else want + term
+                    elif w == 14:
+                        want = loc[FIN] * ((0xFFFFFFFF - iv) - iv) + iv
+                    else:
+                        want = iv
+                c.constraint(sel[0] * (limb(ob, h) - want))
+        # ---- 5. finalisation: FIN1 (U = v_lo ^ v_hi), FIN2 (h_out = U ^ h) through the D2 lookups of rows 13 / 14
         keep_h = sel[15]
         for r in range(0, 13):
             keep_h = keep_h + sel[r]
-        for wd in range(8):
-            klo, slo = out_word(wd)
-            khi, shi = out_word(8 + wd)
-            for i in range(64):
-                c.constraint(sel[12] * (nxt[FT(wd, i)] - xor(nxt[FH(wd, i)], loc[GB(klo, slo, i)])))
-                c.constraint(sel[12] * (nxt[FV(wd, i)] - loc[GB(khi, shi, i)]))
-                c.constraint(sel[13] * (nxt[FT(wd, i)] - xor(loc[FT(wd, i)], loc[FV(wd, i)])))
+        for w in range(8):
+            nD1, nA2, lD2 = cells(nxt, w, S_D1), cells(nxt, w, S_A2), cells(loc, w, S_D2)
+            for i in range(8):
+                c.constraint(sel[12] * (nD1[i] - out_byte(loc, w, i)))
+                c.constraint(sel[12] * (nA2[i] - out_byte(loc, 8 + w, i)))
+                c.constraint(sel[13] * (nD1[i] - lD2[(i + 6) % 8]))
+            hout = [lD2[(i + 6) % 8] for i in range(8)]
             for h in range(2):
-                ivp = (IVP[wd] >> (32 * h)) & 0xFFFFFFFF
-                c.constraint(sel[13] * (loc[HL(wd, h)] - limb(loc, FH(wd, 0), h)))
-                c.constraint(sel[14] * (loc[HL(wd, h)] - limb(loc, FT(wd, 0), h)))
-                c.constraint(sel[14] * (nxt[HL(wd, h)] - (loc[FIN] * ivp + (1 - loc[FIN]) * loc[HL(wd, h)])))
-                c.constraint(keep_h * (nxt[HL(wd, h)] - loc[HL(wd, h)]))
-        # ---- 6. message schedule, range check, link to the previous digest
+                ivp = (IVP[w] >> (32 * h)) & 0xFFFFFFFF
+                c.constraint(sel[13] * (limb(nA2, h) - loc[HL(w, h)]))
+                c.constraint(sel[14] * (loc[HL(w, h)] - limb(hout, h)))
+                c.constraint(sel[14] * (nxt[HL(w, h)] - (loc[FIN] * ivp + (1 - loc[FIN]) * loc[HL(w, h)])))
+                c.constraint(keep_h * (nxt[HL(w, h)] - loc[HL(w, h)]))
+        # ---- 6. message schedule, bytes of the natural word, link to the previous digest
         for s in range(16):
             for h in range(2):
                 acc = None
@@ -386,17 +493,15 @@ class BlakeChainAir:
                     term = sel[r] * (nxt[MS(s, h)] - loc[MS(ms_src(r)[s], h)])
                     acc = term if acc is None else acc + term
                 c.constraint(acc)
+        mb = [loc[MB0 + j] for j in range(8)]
         for h in range(2):
             acc = None
             for r in range(16):
                 term = sel[r] * loc[MS(rc_slot(r), h)]
                 acc = term if acc is None else acc + term
-            c.constraint(acc - limb(loc, MB0, h))
-        # ---- 6b. bytes at positions >= inc are zero (RFC 7693 zero padding of the last chunk): row r sees
-        # word r's bits (MB); MK is a monotone mask over the 128 byte positions with popcount inc
+            c.constraint(acc - limb(mb, h))
+        # ---- 6b. bytes at positions >= inc are zero (RFC 7693 padding): MK = monotone mask with popcount inc
         in_blk = 1 - sel[15]
-        for b in range(8):
-            c.constraint(loc[MK0 + b] * (loc[MK0 + b] - 1))
         for b in range(7):
             c.constraint(loc[MK0 + b + 1] * (1 - loc[MK0 + b]))
         c.constraint(in_blk * nxt[MK0] * (1 - loc[MK0 + 7]))
@@ -407,26 +512,19 @@ class BlakeChainAir:
         c.constraint(in_blk * (nxt[CNT] - loc[CNT] - msum_n))
         c.constraint(sel[15] * (loc[CNT] - loc[INC]))
         for b in range(8):
-            byte = loc[MB0 + 8 * b + 7]
-            for i in range(6, -1, -1):
-                byte = byte + byte + loc[MB0 + 8 * b + i]
-            c.constraint((1 - loc[MK0 + b]) * byte)
+            c.constraint((1 - loc[MK0 + b]) * mb[b])
         for s in range(4):
             for h in range(2):
                 c.constraint(sel[0] * loc[FIRST] * (loc[MS(s, h)] - loc[D0 + 2 * s + h]))
-        # block number: bytes 32..36 of a header = SCALE compact, 4-byte mode: 4 * number + 2 (decoder.rs:64-66)
-        c.constraint(sel[0] * loc[FIRST] * (loc[MS(4, 0)] - (4 * loc[NUM] + 2)))
+        c.constraint(sel[0] * loc[FIRST] * (loc[MS(4, 0)] - (4 * loc[NUM] + 2)))  # decoder.rs:64-66, 4-byte compact mode
         # ---- 7. per-block registers
-        in_block = 1 - sel[15]
         for col in (ACT, FIN, FIRST, CAP, T, INC, NUM, FA):
-            c.constraint(in_block * (nxt[col] - loc[col]))
+            c.constraint(in_blk * (nxt[col] - loc[col]))
         c.constraint(loc[CAP] - loc[ACT] * loc[FIN])
         c.constraint(loc[FA] - loc[FIRST] * loc[ACT])
-        c.transition(sel[15] * (nxt[NUM] - loc[NUM] - nxt[FA]))  # numbers are sequential (subchain_verification.rs:166-168)
-        # ACT belongs to a whole message: constant across its chunks (a junk message must not bump NUM on its first
-        # chunk and dodge the digest capture on its last), and monotone (padding stays padding)
-        c.constraint(sel[15] * (1 - loc[FIN]) * (nxt[ACT] - loc[ACT]))
-        c.transition(nxt[ACT] * (1 - loc[ACT]))
+        c.transition(sel[15] * (nxt[NUM] - loc[NUM] - nxt[FA]))  # sequential numbers (subchain_verification.rs:166-168)
+        c.constraint(sel[15] * (1 - loc[FIN]) * (nxt[ACT] - loc[ACT]))  # ACT belongs to a whole message ...
+        c.transition(nxt[ACT] * (1 - loc[ACT]))  # ... and padding stays padding
         c.constraint(sel[15] * (nxt[FIRST] - loc[FIN]))
         c.constraint(sel[15] * (nxt[T] - (1 - loc[FIN]) * loc[T] - nxt[INC]))
         tb = loc[TB0 + 31]
@@ -443,7 +541,7 @@ class BlakeChainAir:
         for j in range(8):
             c.transition((1 - sel[14]) * (nxt[D0 + j] - loc[D0 + j]))
             c.constraint(sel[14] * (nxt[D0 + j] - (loc[CAP] * loc[HL(j // 2, j % 2)] + (1 - loc[CAP]) * loc[D0 + j])))
-        # ---- 9. boundary: chain starts at the trusted hash, ends at the target hash with a final block
+        # ---- 9. boundary
         for j in range(8):
             c.first_row(loc[D0 + j] - pub[j])
         for j in range(8):
@@ -451,71 +549,56 @@ class BlakeChainAir:
         c.last_row(loc[FIN] - 1)
         c.first_row(loc[NUM] - pub[16])
         c.last_row(loc[NUM] - pub[17])
+        # ---- 10. lookups (logUp): helpers of the row `nxt`, table side of the row `loc`, cyclic running sum
+        ds, dt1, dt2 = fingerprints(loc, nxt, sel, per, chal)
+        hsum = None
+        for e in range(N_HELP - 2):
+            (m, du), (_m2, dv) = ds[2 * e], ds[2 * e + 1]
+            h = X2(nxt[AX(e, 0)], nxt[AX(e, 1)])
+            c.constraint_x2(h * du * dv - (du + dv) * m)
+            hsum = h if hsum is None else hsum + h
+        ht = X2(loc[AX(HT, 0)], loc[AX(HT, 1)])
+        c.constraint_x2(ht * dt1 * dt2 - dt2 * loc[M1] - dt1 * loc[M2])
+        z, zn = X2(loc[AX(ZZ, 0)], loc[AX(ZZ, 1)]), X2(nxt[AX(ZZ, 0)], nxt[AX(ZZ, 1)])
+        c.constraint_x2(zn - z - hsum + ht)
 
+    @staticmethod
+    def gen_aux(trace, chal):
+        """Auxiliary columns [AUX][n] for the challenges (vectorised: field vectors through the C oracle)."""
+        tr = np.ascontiguousarray(trace, dtype=np.uint64)
+        n = tr.shape[1]
+        VecF = S.VecF
+        loc = [VecF(tr[j]) for j in range(COLS)]
+        nxt = [VecF(np.roll(tr[j], -1)) for j in range(COLS)]
+        per = [VecF(np.tile(np.array(v, dtype=np.uint64), n // len(v))) for v in periodic_values()]
+        cv = [VecF.const(x, loc[0]) for x in chal]
+        ds, dt1, dt2 = fingerprints(loc, nxt, per[:16], per, cv)
+        aux = np.zeros((AUX, n), dtype=np.uint64)
 
-def first_violation(tr, pub, rows=None):
-    """Direct row-by-row check of every constraint on the trace domain (python ints, slow).
-    Returns (row, constraint index) of the first violation or None."""
-    n = tr.shape[1]
+        def inv(x):  # extension inverse, vectorised
+            buf = np.empty(2 * n, dtype=np.uint64)
+            buf[0::2], buf[1::2] = x.a.v, x.b.v
+            out = O.ext_inv(buf)
+            return S.X2(VecF(out[0::2].copy()), VecF(out[1::2].copy()))
 
-    class S:
-        __slots__ = ("v",)
-
-        def __init__(self, v):
-            self.v = v % P
-
-        def _c(self, o):
-            return o if isinstance(o, S) else S(int(o))
-
-        def __add__(self, o):
-            return S(self.v + self._c(o).v)
-
-        __radd__ = __add__
-
-        def __sub__(self, o):
-            return S(self.v - self._c(o).v)
-
-        def __rsub__(self, o):
-            return S(self._c(o).v - self.v)
-
-        def __mul__(self, o):
-            return S(self.v * self._c(o).v)
-
-        __rmul__ = __mul__
-
-    class Row:
-        def __init__(self, col):
-            self.col = col
-
-        def __getitem__(self, c):
-            return S(self.col[c])
-
-    class Cons:
-        def __init__(self, first, last):
-            self.first, self.last, self.idx, self.bad = first, last, 0, None
-
-        def _push(self, c, active):
-            if active and c.v != 0 and self.bad is None:
-                self.bad = self.idx
-            self.idx += 1
-
-        def constraint(self, c):
-            self._push(c, True)
-
-        def transition(self, c):
-            self._push(c, not self.last)
-
-        def first_row(self, c):
-            self._push(c, self.first)
-
-        def last_row(self, c):
-            self._push(c, self.last)
-
-    cols = [[int(x) for x in tr[:, i]] for i in range(n)]
-    for i in (range(n) if rows is None else rows):
-        cons = Cons(i == 0, i == n - 1)
-        per = [S(1 if i % 16 == k else 0) for k in range(16)]
-        BlakeChainAir.eval(Row(cols[i]), Row(cols[(i + 1) % n]), per, [S(x) for x in pub], cons)
-        if cons.bad is not None:
-            return i, cons.bad
-    return None
+        hsum_a, hsum_b = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        for e in range(N_HELP - 2):
+            (m, du), (_m2, dv) = ds[2 * e], ds[2 * e + 1]
+            h = (du + dv) * inv(du * dv) * m  # values of the pair (loc = row i, nxt = row i+1): they belong to row i+1
+            ha, hb = np.roll(h.a.v, 1), np.roll(h.b.v, 1)
+            aux[2 * e], aux[2 * e + 1] = ha, hb
+            hsum_a, hsum_b = O.batch_op("add", hsum_a, ha), O.batch_op("add", hsum_b, hb)
+        ht = (dt2 * loc[M1] + dt1 * loc[M2]) * inv(dt1 * dt2)
+        aux[2 * HT], aux[2 * HT + 1] = ht.a.v, ht.b.v
+        # Z(i+1) = Z(i) + sum_e h_e(i+1) - ht(i), Z(0) = 0
+        da = O.batch_op("sub", np.roll(hsum_a, -1), ht.a.v)
+        db = O.batch_op("sub", np.roll(hsum_b, -1), ht.b.v)
+        for comp, d in ((0, da), (1, db)):
+            z = np.zeros(n, dtype=np.uint64)
+            acc = 0
+            dl = d.tolist()
+            for i in range(n - 1):
+                acc = (acc + dl[i]) % P
+                z[i + 1] = acc
+            aux[2 * ZZ + comp] = z
+        return aux, []

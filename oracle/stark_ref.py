@@ -187,24 +187,27 @@ def period_logs(air):
     return list(getattr(air, "PERIOD_LOGS", [air.PERIOD_LOG] * air.PERIODIC))
 
 
-def check_trace(air, trace, pub, chal=None, aux=None, aux_pub=None):
+def check_trace(air, trace, pub, chal=None, aux=None, aux_pub=None, rows=None):
     """Every constraint on every row of the trace domain, vectorised (the AIR's eval over VecF with x = w^i).
+    rows = (lo, hi) restricts the check to the row pairs (i, i+1), lo <= i < hi.
     Returns None or (constraint index, first violating row)."""
     tr = np.ascontiguousarray(trace, dtype=np.uint64)
     if aux is not None:
         tr = np.concatenate([tr, np.ascontiguousarray(aux, dtype=np.uint64)])
-    c, n = tr.shape
-    L = n.bit_length() - 1
+    c, n_full = tr.shape
+    L = n_full.bit_length() - 1
     w = O.root(L)
+    lo, hi = (0, n_full) if rows is None else rows
+    idx = np.arange(lo, hi)
+    n = hi - lo
     xs = np.empty(n, dtype=np.uint64)
-    acc = 1
+    acc = pow(w, lo, P)
     for i in range(n):
         xs[i] = acc
         acc = acc * w % P
     X = VecF(xs)
-    first = np.zeros(n, dtype=np.uint64)
-    last = np.zeros(n, dtype=np.uint64)
-    first[0] = last[n - 1] = 1
+    first = (idx == 0).astype(np.uint64)
+    last = (idx == n_full - 1).astype(np.uint64)
 
     class Check(Consumer):
         def __init__(self):
@@ -216,13 +219,13 @@ def check_trace(air, trace, pub, chal=None, aux=None, aux_pub=None):
                 v = cc.v if isinstance(cc, VecF) else np.full(n, int(cc) % P, dtype=np.uint64)
                 nz = np.flatnonzero(v)
                 if nz.size:
-                    self.bad = (self.k, int(nz[0]))
+                    self.bad = (self.k, lo + int(nz[0]))
             self.k += 1
 
     cons = Check()
-    per = [VecF(np.tile(np.array(v, dtype=np.uint64), n // len(v))) for v in air.periodic_values()]
-    loc = [VecF(tr[j]) for j in range(c)]
-    nxt = [VecF(np.roll(tr[j], -1)) for j in range(c)]
+    per = [VecF(np.array(v, dtype=np.uint64)[idx % len(v)]) for v in air.periodic_values()]
+    loc = [VecF(tr[j][idx]) for j in range(c)]
+    nxt = [VecF(tr[j][(idx + 1) % n_full]) for j in range(c)]
     air_eval(air, loc, nxt, per, [VecF.const(x, X) for x in pub], cons,
              None if chal is None else [VecF.const(x, X) for x in chal], None if aux_pub is None else [VecF.const(x, X) for x in aux_pub])
     return cons.bad

@@ -51,3 +51,21 @@ def rand_field(rng, shape):
 @pytest.fixture
 def rng():
     return np.random.default_rng(42)
+
+
+@pytest.fixture(scope="session")
+def blake_proof(oracle):
+    """ONE BlakeChainAir proof by the coefficient-space reference prover (2^16 rows x 999 columns: about a minute of
+    CPU), shared by the CPU-tier tests that need one: (proof words, public inputs, config dict, trace)."""
+    import hashlib
+
+    from oracle import blake_air as B
+    from oracle import stark_ref as S
+
+    S.register_air(B.BlakeChainAir)
+    trusted = hashlib.sha256(b"v").digest()
+    m1 = trusted + (4 * 123456 + 2).to_bytes(4, "little") + bytes(range(200))
+    m2 = hashlib.blake2b(m1, digest_size=32).digest() + (4 * 123457 + 2).to_bytes(4, "little") + b"y" * 70
+    tr, pub, _ = B.gen_trace([m1, m2], 16, trusted)
+    cfg = dict(S.DEFAULT_CFG, num_queries=6)
+    return S.prove(B.BlakeChainAir, tr, pub, cfg), pub, cfg, tr

@@ -56,14 +56,16 @@ def test_gpu_reproduces_selfcheck_fixtures(ctx, vx):
     assert dig(ctx.stark_prove(1, ctx.from_host(tr), 8, pub)) == VEC["proof_fib_2^8"]
     tr, pub = G.S.MixAir.trace(6)
     assert dig(ctx.stark_prove(2, ctx.from_host(tr), 6, pub)) == VEC["proof_mix_2^6"]
-    # Blake chain: headers -> GPU trace -> GPU proof
+    tr, pub = G.S.LookupAir.trace(9)
+    assert dig(ctx.stark_prove(5, ctx.from_host(tr), 9, pub, ctx.stark_config(num_queries=6))) == VEC["proof_lookup_2^9_q6"]
+    # Blake chain: headers -> GPU main trace -> GPU auxiliary columns
     msgs, trusted = G.blake_messages()
     hdr = np.zeros((len(msgs), 256), dtype=np.uint8)
     for i, m in enumerate(msgs):
         hdr[i, : len(m)] = np.frombuffer(m, dtype=np.uint8)
-    buf, pub, _ = ctx.blake_chain_trace(ctx.from_host(hdr), 256, [len(m) for m in msgs], trusted, 65536, 6)
-    assert dig(buf.download()) == VEC["trace_blake_chain_2^6"]
-    assert dig(ctx.stark_prove(3, buf, 6, pub, ctx.stark_config(num_queries=6))) == VEC["proof_blake_chain_2^6_q6"]
+    buf, pub, _ = ctx.blake_chain_trace(ctx.from_host(hdr), 256, [len(m) for m in msgs], trusted, 65536, 16)
+    assert dig(buf.download()) == VEC["trace_blake_chain_2^16"]
+    assert dig(ctx.stark_aux_trace(6, buf, 16, G.BLAKE_CHAL, 268).download()) == VEC["aux_blake_chain_2^16"]
     buf, pub, _ = ctx.sha_chain_trace(G.sha_keys(), 8)
     assert dig(buf.download()) == VEC["trace_sha_chain_2^8"]
     assert dig(ctx.stark_prove(4, buf, 8, pub, ctx.stark_config(num_queries=6))) == VEC["proof_sha_chain_2^8_q6"]

@@ -1,5 +1,6 @@
-"""BlakeChainAir on the GPU: trace == the oracle's restatement cell by cell, proof bytes == the
-coefficient-space reference prover, and the reference verifier accepts / rejects."""
+"""BlakeChainAir (byte-lookup AIR, id 6) on the GPU: main trace == the oracle's restatement cell by cell, auxiliary
+(logUp) columns == the oracle's for the same challenges, proof bytes == the coefficient-space reference prover, and the
+reference verifier accepts / rejects.  The trace holds one copy of the 2^16-row XOR tables, so every case has >= 2^16 rows."""
 import hashlib
 
 import numpy as np
@@ -10,26 +11,38 @@ from oracle import stark_ref as S
 
 pytestmark = pytest.mark.gpu
 S.register_air(B.BlakeChainAir)
+L0 = 16
 
 
 def chain_msgs(ch):
     return [ch.headers[i, : ch.sizes[i]].tobytes() for i in range(ch.n)]
 
 
-@pytest.mark.parametrize("n_headers,log_n", [(1, 6), (2, 7), (5, 9)])
-def test_trace_matches_oracle(ctx, vx, n_headers, log_n):
+def limbs(b):
+    return [int.from_bytes(b[4 * j: 4 * j + 4], "little") for j in range(8)]
+
+
+@pytest.mark.parametrize("n_headers", [1, 5])
+def test_trace_and_aux_columns_match_oracle(ctx, vx, oracle, n_headers):
     ch = vx.synth.Chain(n_headers, profile="Ptiny", stride=512)
-    buf, pub, dig = ctx.blake_chain_trace(ctx.from_host(ch.headers), 512, ch.sizes, ch.trusted_hash, ch.trusted_block + 1, log_n)
-    want, wpub, target = B.gen_trace(chain_msgs(ch), log_n, ch.trusted_hash)
-    got = buf.download().reshape(B.COLS, 1 << log_n)
+    buf, pub, dig = ctx.blake_chain_trace(ctx.from_host(ch.headers), 512, ch.sizes, ch.trusted_hash, ch.trusted_block + 1, L0)
+    want, wpub, target = B.gen_trace(chain_msgs(ch), L0, ch.trusted_hash)
+    got = buf.download().reshape(B.COLS, 1 << L0)
     bad = np.argwhere(got != want)
     assert bad.size == 0, f"first differing cells (col,row): {bad[:5].tolist()}"
     assert [int(x) for x in pub] == wpub and target == ch.target_hash
     assert [d.tobytes() for d in dig] == ch.hashes == [hashlib.blake2b(m, digest_size=32).digest() for m in chain_msgs(ch)]
+    # the auxiliary round for fixed challenges: helper columns, table helper and running sum, cell by cell
+    chal = [0x0123456789ABCDEF, 0x0FEDCBA987654321, 0x1111111122222222, 0x3333333344444444]
+    aux = ctx.stark_aux_trace(B.ID, buf, L0, chal, B.AUX).download().reshape(B.AUX, 1 << L0)
+    waux, _ = B.BlakeChainAir.gen_aux(want, chal)
+    bad = np.argwhere(aux != waux)
+    assert bad.size == 0, f"first differing auxiliary cells (col,row): {bad[:5].tolist()}"
+    assert S.check_trace(B.BlakeChainAir, got, wpub, chal, aux, []) is None  # every constraint, every row, on the GPU's columns
 
 
-def test_edge_sizes_trace(ctx, vx):
-    """Chunk-boundary lengths: 128 (one full final chunk), 129, 255, 256, 257 and the 32-byte minimum."""
+def test_edge_sizes_trace(ctx, vx, oracle):
+    """Chunk-boundary lengths: 128 (one full final chunk), 129, 255, 256, 257 and the 36-byte minimum."""
     trusted = hashlib.sha256(b"edge").digest()
     msgs, d = [], trusted
     for k, n in enumerate((128, 129, 255, 256, 257, 36, 37)):
@@ -40,44 +53,63 @@ def test_edge_sizes_trace(ctx, vx):
     for i, m in enumerate(msgs):
         hdr[i, : len(m)] = np.frombuffer(m, dtype=np.uint8)
     sizes = [len(m) for m in msgs]
-    buf, pub, dig = ctx.blake_chain_trace(ctx.from_host(hdr), 384, sizes, trusted, 50000, 8)
-    want, wpub, target = B.gen_trace(msgs, 8, trusted)
-    assert (buf.download().reshape(B.COLS, 256) == want).all() and dig[-1].tobytes() == d == target
+    buf, pub, dig = ctx.blake_chain_trace(ctx.from_host(hdr), 384, sizes, trusted, 50000, L0)
+    want, wpub, target = B.gen_trace(msgs, L0, trusted)
+    assert (buf.download().reshape(B.COLS, 1 << L0) == want).all() and dig[-1].tobytes() == d == target
 
 
 def test_proof_bytes_and_verification(ctx, vx, oracle):
     ch = vx.synth.Chain(2, profile="Ptiny", stride=512)
-    log_n = 7
-    buf, pub, _ = ctx.blake_chain_trace(ctx.from_host(ch.headers), 512, ch.sizes, ch.trusted_hash, ch.trusted_block + 1, log_n)
-    got = ctx.stark_prove(B.ID, buf, log_n, pub)
-    trace, wpub, _ = B.gen_trace(chain_msgs(ch), log_n, ch.trusted_hash)
-    want = S.prove(B.BlakeChainAir, trace, wpub)
-    assert got.size == want.size and (got == want).all()
-    S.verify(got, expect_air=B.ID, expect_public=wpub)
+    buf, pub, _ = ctx.blake_chain_trace(ctx.from_host(ch.headers), 512, ch.sizes, ch.trusted_hash, ch.trusted_block + 1, L0)
+    pcfg, cfg = ctx.stark_config(num_queries=10), dict(S.DEFAULT_CFG, num_queries=10)
+    got = ctx.stark_prove(B.ID, buf, L0, pub, pcfg)
+    trace, wpub, _ = B.gen_trace(chain_msgs(ch), L0, ch.trusted_hash)
+    want = S.prove(B.BlakeChainAir, trace, wpub, cfg)
+    assert got.size == want.size
+    diff = np.nonzero(got != want)[0]
+    assert diff.size == 0, f"first differing words {diff[:5]} of {got.size}"
+    S.verify(got, cfg, expect_air=B.ID, expect_public=wpub)
+    vx.lib.stark_verify(got, pcfg, expect_air=B.ID, expect_public=wpub)
 
 
 def test_larger_chain_verifies_and_forgeries_fail(ctx, vx, oracle):
     ch = vx.synth.Chain(16, profile="Ptiny", stride=512)
-    log_n = 10
     hb = ctx.from_host(ch.headers)
-    buf, pub, _ = ctx.blake_chain_trace(hb, 512, ch.sizes, ch.trusted_hash, ch.trusted_block + 1, log_n)
-    proof = ctx.stark_prove(B.ID, buf, log_n, pub, ctx.stark_config(num_queries=20))
-    cfg = dict(S.DEFAULT_CFG, num_queries=20)
+    buf, pub, _ = ctx.blake_chain_trace(hb, 512, ch.sizes, ch.trusted_hash, ch.trusted_block + 1, L0)
+    pcfg, cfg = ctx.stark_config(num_queries=20), dict(S.DEFAULT_CFG, num_queries=20)
+    proof = ctx.stark_prove(B.ID, buf, L0, pub, pcfg)
     info = S.verify(proof, cfg, expect_air=B.ID)
-    limbs = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "little") for j in range(8)]  # noqa: E731
     assert info["public_inputs"] == limbs(ch.trusted_hash) + limbs(ch.target_hash) + [ch.trusted_block + 1, ch.target_block]
-    # a trace with one flipped witness bit must not verify
-    tr = buf.download().reshape(B.COLS, 1 << log_n)
-    tr[B.GB(3, 2, 5), 100] ^= np.uint64(1)
-    bad = ctx.stark_prove(B.ID, ctx.from_host(tr), log_n, pub, ctx.stark_config(num_queries=20))
-    with pytest.raises(S.VerifyError):
-        S.verify(bad, cfg)
+    # a trace with one wrong witness byte, a wrong lookup output, or a wrong multiplicity must not verify
+    tr = buf.download().reshape(B.COLS, 1 << L0)
+    for col, row in ((B.GC(3, B.S_C1, 5), 100), (B.GC(6, B.S_D2, 1), 37), (B.GC(2, B.S_T, 7), 21), (B.M1, 4660), (B.M2, 77)):
+        bad_tr = tr.copy()
+        bad_tr[col, row] ^= np.uint64(1)
+        bad = ctx.stark_prove(B.ID, ctx.from_host(bad_tr), L0, pub, pcfg)
+        with pytest.raises(S.VerifyError):
+            S.verify(bad, cfg)
+        with pytest.raises(vx.VxError):
+            vx.lib.stark_verify(bad, pcfg)
     # claiming a different target hash must not verify
     pub2 = pub.copy()
     pub2[9] ^= np.uint64(1)
-    bad = ctx.stark_prove(B.ID, buf, log_n, pub2, ctx.stark_config(num_queries=20))
+    bad = ctx.stark_prove(B.ID, buf, L0, pub2, pcfg)
     with pytest.raises(S.VerifyError):
         S.verify(bad, cfg)
+
+
+def test_forged_act_flag_cannot_be_proven(ctx, vx, oracle):
+    """ADVICE r1 (high), GPU side: the forged trace (a junk message whose ACT flips inside the message, bumping the block
+    number without capturing a digest) yields a proof both verifiers reject."""
+    from tests.test_oracle_blake_air import forged_trace
+
+    tr, pub = forged_trace(L0)
+    pcfg, cfg = ctx.stark_config(num_queries=8), dict(S.DEFAULT_CFG, num_queries=8)
+    pr = ctx.stark_prove(B.ID, ctx.from_host(tr), L0, pub, pcfg)
+    with pytest.raises(S.VerifyError):
+        S.verify(pr, cfg)
+    with pytest.raises(vx.VxError):
+        vx.lib.stark_verify(pr, pcfg)
 
 
 def test_header_range_prove_end_to_end(ctx, vx, oracle):
@@ -86,11 +118,10 @@ def test_header_range_prove_end_to_end(ctx, vx, oracle):
     cfg = ctx.stark_config(num_queries=12)
     out96, blob = ctx.header_range_prove(ctx.from_host(ch.headers), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
     assert out96 == ch.expected_outputs(16)
-    assert int(blob[0]) == 0x3245474E41525248 and [int(x) for x in blob[1:4]] == [16, ch.trusted_block, ch.target_block]
+    assert int(blob[0]) == 0x3345474E41525248 and [int(x) for x in blob[1:4]] == [16, ch.trusted_block, ch.target_block]
     assert blob[4:16].tobytes() == out96
     info = S.verify(vx.lib.split_blob(blob)[0], dict(S.DEFAULT_CFG, num_queries=12), expect_air=B.ID)
     assert vx.lib.split_blob(blob)[1].size == 0
-    limbs = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "little") for j in range(8)]  # noqa: E731
     assert info["public_inputs"] == limbs(ch.trusted_hash) + limbs(out96[:32]) + [ch.trusted_block + 1, ch.target_block]
     # with a justification: accepted when > 2/3 signed the target, refused otherwise
     good = vx.lib.PackedJustification(vx.synth.Justification(ch.target_block, ch.target_hash, n_auth=9, n_signed=7), 12)

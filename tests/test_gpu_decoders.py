@@ -106,5 +106,5 @@ def test_blake_chain_air_number_range_is_pinned(ctx, vx):
     decoder.rs:39-92 accepts all four modes natively.  The error is an argument error, not a wrong proof."""
     ch = vx.synth.Chain(8, profile="Ptiny", stride=STRIDE, trusted_block=60)
     with pytest.raises(vx.VxError) as e:
-        ctx.blake_chain_trace(ctx.from_host(ch.headers), STRIDE, ch.sizes, ch.trusted_hash, ch.trusted_block + 1, 9)
+        ctx.blake_chain_trace(ctx.from_host(ch.headers), STRIDE, ch.sizes, ch.trusted_hash, ch.trusted_block + 1, 16)
     assert e.value.code == -1 and "4-byte SCALE compact range" in str(e.value)
