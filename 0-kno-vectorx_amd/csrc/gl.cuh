@@ -170,7 +170,27 @@ __device__ __forceinline__ uint64_t gl_pow(uint64_t a, uint64_t e) {
     }
     return r;
 }
-__device__ __forceinline__ uint64_t gl_inv(uint64_t a) { return gl_pow(a, GL_P - 2); }
+// a^(p-2) by an addition chain (p - 2 = (2^32 - 2) 2^32 + (2^32 - 1)): 65 squarings + 10 multiplications instead of the
+// 64 + 63 of square-and-multiply -- the exponent is all ones.  Intermediates stay non-canonical.
+__device__ __forceinline__ uint64_t gl_sqr_n(uint64_t x, int n) {
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) x = gl_mul_nc(x, x);
+    return x;
+}
+// (not inlined: a kernel that inverts at several places -- the FRI combination does 8 times per lane -- would otherwise
+// carry eight copies of the chain and spill)
+__device__ __noinline__ static uint64_t gl_inv(uint64_t a) {
+    const uint64_t x2 = gl_mul_nc(gl_mul_nc(a, a), a);       // a^(2^2 - 1)
+    const uint64_t x4 = gl_mul_nc(gl_sqr_n(x2, 2), x2);      // 2^4 - 1
+    const uint64_t x6 = gl_mul_nc(gl_sqr_n(x4, 2), x2);      // 2^6 - 1
+    const uint64_t x8 = gl_mul_nc(gl_sqr_n(x4, 4), x4);      // 2^8 - 1
+    const uint64_t x16 = gl_mul_nc(gl_sqr_n(x8, 8), x8);     // 2^16 - 1
+    const uint64_t x24 = gl_mul_nc(gl_sqr_n(x16, 8), x8);    // 2^24 - 1
+    const uint64_t x30 = gl_mul_nc(gl_sqr_n(x24, 6), x6);    // 2^30 - 1
+    const uint64_t x31 = gl_mul_nc(gl_mul_nc(x30, x30), a);  // 2^31 - 1
+    const uint64_t t2 = gl_mul_nc(x31, x31);                 // a^(2^32 - 2)
+    return gl_mul(gl_sqr_n(t2, 32), gl_mul_nc(t2, a));       // (a^(2^32-2))^(2^32) * a^(2^32-1)
+}
 
 __device__ __forceinline__ gl2 gl2_add(gl2 x, gl2 y) { return {gl_add(x.a, y.a), gl_add(x.b, y.b)}; }
 __device__ __forceinline__ gl2 gl2_sub(gl2 x, gl2 y) { return {gl_sub(x.a, y.a), gl_sub(x.b, y.b)}; }

@@ -2,9 +2,9 @@
 //   kernel A  k_blake_chain: one lane per header -- digest + the chaining value before every
 //             128-byte chunk (the only sequential part of BLAKE2b);
 //   kernel B  k_blake_trace: one lane per TRACE ROW (block b, r = row mod 16): recomputes
-//             the <= 12 rounds it needs from the chunk's chaining value and writes its 729
-//             cells; lanes of a wave write 64 consecutive rows of a column, so every store
-//             instruction is a coalesced 512-byte segment of the column-major trace;
+//             the <= 12 rounds it needs from the chunk's chaining value and writes the row
+//             packed as 96 words; k_blake_expand unpacks words into the 729 byte / limb / bit
+//             cells, a block writing 16 KB runs of one column at a time;
 //   kernel C  k_blake_aux: the logUp helper columns once the lookup challenges are known.
 // Replaces the curta Blake2b witness generation behind hash_encoded_header
 // (/root/reference circuits/builder/header.rs:14-19) for the synthetic header chain.
@@ -26,11 +26,6 @@ struct BlockDesc {
 
 __device__ __forceinline__ uint64_t b_rotr(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
 
-struct GRec {
-    uint64_t w[8];  // a1 d1 c1 b1 a2 d2 c2 b2
-    uint64_t in_b, in_d;  // the operands that enter an XOR lookup
-    uint8_t car[8];
-};
 __device__ __forceinline__ void carries(uint64_t o1, uint64_t o2, uint64_t o3, uint8_t* out) {
     uint64_t lo = (o1 & 0xFFFFFFFFULL) + (o2 & 0xFFFFFFFFULL) + (o3 & 0xFFFFFFFFULL);
     uint64_t klo = lo >> 32;
@@ -38,25 +33,16 @@ __device__ __forceinline__ void carries(uint64_t o1, uint64_t o2, uint64_t o3, u
     out[0] = (uint8_t)klo;
     out[1] = (uint8_t)(hi >> 32);
 }
-__device__ __forceinline__ void g_mix(uint64_t* v, int ia, int ib, int ic, int id, uint64_t x, uint64_t y, GRec* rec) {
+__device__ __forceinline__ void g_mix(uint64_t* v, int ia, int ib, int ic, int id, uint64_t x, uint64_t y) {
     uint64_t a = v[ia], b = v[ib], c = v[ic], d = v[id];
     uint64_t a1 = a + b + x, d1 = b_rotr(d ^ a1, 32), c1 = c + d1, b1 = b_rotr(b ^ c1, 24);
     uint64_t a2 = a1 + b1 + y, d2 = b_rotr(d1 ^ a2, 16), c2 = c1 + d2, b2 = b_rotr(b1 ^ c2, 63);
-    if (rec) {
-        rec->w[0] = a1, rec->w[1] = d1, rec->w[2] = c1, rec->w[3] = b1, rec->w[4] = a2, rec->w[5] = d2, rec->w[6] = c2, rec->w[7] = b2;
-        rec->in_b = b, rec->in_d = d;
-        carries(a, b, x, rec->car);
-        carries(c, d1, 0, rec->car + 2);
-        carries(a1, b1, y, rec->car + 4);
-        carries(c1, d2, 0, rec->car + 6);
-    }
     v[ia] = a2, v[ib] = b2, v[ic] = c2, v[id] = d2;
 }
-__device__ void blake_round(uint64_t* v, const uint64_t* m, int round, GRec* rec) {
+__device__ void blake_round(uint64_t* v, const uint64_t* m, int round) {
     const uint8_t* s = blk::ORDER[round + 1];  // ORDER[r] for r = 1..12 is sigma[r-1]
-    for (int k = 0; k < 4; ++k) g_mix(v, k, 4 + k, 8 + k, 12 + k, m[s[2 * k]], m[s[2 * k + 1]], rec ? rec + k : nullptr);
-    for (int j = 0; j < 4; ++j)
-        g_mix(v, j, 4 + (j + 1) % 4, 8 + (j + 2) % 4, 12 + (j + 3) % 4, m[s[8 + 2 * j]], m[s[8 + 2 * j + 1]], rec ? rec + 4 + j : nullptr);
+    for (int k = 0; k < 4; ++k) g_mix(v, k, 4 + k, 8 + k, 12 + k, m[s[2 * k]], m[s[2 * k + 1]]);
+    for (int j = 0; j < 4; ++j) g_mix(v, j, 4 + (j + 1) % 4, 8 + (j + 2) % 4, 12 + (j + 3) % 4, m[s[8 + 2 * j]], m[s[8 + 2 * j + 1]]);
 }
 __device__ void blake_init_v(uint64_t* v, const uint64_t* h, uint64_t t, bool fin) {
     for (int i = 0; i < 8; ++i) v[i] = h[i], v[8 + i] = blk::IV[i];
@@ -90,7 +76,7 @@ __global__ __launch_bounds__(64) void k_blake_chain(const uint8_t* msgs, size_t 
             m[k] = w;
         }
         blake_init_v(v, h, fin ? len : off + 128, fin);
-        for (int r = 0; r < 12; ++r) blake_round(v, m, r, nullptr);
+        for (int r = 0; r < 12; ++r) blake_round(v, m, r);
         for (int k = 0; k < 8; ++k) h[k] ^= v[k] ^ v[k + 8];
     }
     uint64_t* d = (uint64_t*)(digests + 32 * i);
@@ -98,15 +84,32 @@ __global__ __launch_bounds__(64) void k_blake_chain(const uint8_t* msgs, size_t 
 }
 
 // ---- trace rows ---------------------------------------------------------------------------------------------------
-// One lane per trace row (block b, r = row mod 16): recomputes the <= 12 rounds it needs from the chunk's chaining value
-// and stores its 729 cells byte by byte (lanes of a wave write 64 consecutive rows of a column: every store instruction
-// is one coalesced 512-byte segment of the column-major trace).  The same lane knows every XOR its row looks up, so it
-// also bumps the multiplicity histograms of the two tables (hist[0 .. 2^16) for T1, hist[2^16 .. 2^17) for T2).
+// A row lane that stored its 729 cells one column at a time walked 729 columns 8n bytes apart: the walk's address
+// translation, not its bytes, set the time (7.8 ms for 3 GB).  So the row is produced in two steps:
+//   k_blake_trace   one lane per trace row (block b, r = row mod 16): recomputes the <= 12 rounds it needs from the
+//                   chunk's chaining value and stores the row PACKED as 96 words (stage[w * n + row]); the same lane knows
+//                   every XOR its row looks up and bumps the multiplicity histograms of the two tables
+//                   (hist[0 .. 2^16) for T1, hist[2^16 .. 2^17) for T2);
+//   k_blake_expand  one block per (2048 rows, packed word): every cell is (word >> shift) & mask, and a block writes
+//                   16 KB runs of one column at a time.
+// Packed words: 8 per G (A1 D1 C1 B1 A2 D2 C2 X; L / T are the low 7 bits / top bit of X's bytes), then
+constexpr int SW_CAR = 64, SW_MS = 65, SW_MB = 81, SW_HL = 82, SW_D = 90, SW_FLAGS = 94, SW_TN = 95, N_STAGE = 96;
+// SW_CAR: 32 carries x 2 bits; SW_MS: the 16 message words in this row's order; SW_D: 4 words of two limbs;
+// SW_FLAGS: ACT FIN FIRST CAP FA (bits 0..4), INC (8..15), CNT (16..23), MK (24..31); SW_TN: T (low half), NUM (high half)
+struct ExpandEntry {
+    uint16_t col;
+    uint8_t shift, bits;
+};
 __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const BlockDesc* descs, const uint64_t* hchain, size_t n_real,
-                                                     uint64_t* __restrict__ tr, uint32_t* __restrict__ hist, size_t n) {
+                                                     uint64_t* __restrict__ stage, uint32_t* __restrict__ hist, uint32_t* __restrict__ rc_part, size_t n) {
     using namespace blk;
+    // the (byte, 0) range-check lookups of every row fall on 256 counters = 8 cache lines: as global atomics they
+    // serialise in L2 (the kernel took 7.5 ms for 0.4 GB of stores); they are counted per block in LDS instead and
+    // summed by k_blake_mult.  n is a multiple of the block size (n >= 2^16).
+    __shared__ uint32_t rc_lds[256];
+    rc_lds[threadIdx.x] = 0;
+    __syncthreads();
     const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (row >= n) return;
     const size_t b = row >> 4;
     const int r = (int)(row & 15);
     const BlockDesc d = descs[b];
@@ -129,19 +132,8 @@ __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const 
         for (int k = 0; k < 16; ++k) m[k] = k < 4 ? ((uint64_t)d.D[2 * k] | ((uint64_t)d.D[2 * k + 1] << 32)) : 0;
         m[4] = 4ULL * d.num + 2;  // bytes 32..36: SCALE compact (4-byte mode) of the last block number
     }
-    auto cell = [&](int col) -> uint64_t& { return tr[(size_t)col * n + row]; };
-    auto put = [&](int k, int slot, uint64_t word) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) cell(GC(k, slot, j)) = (word >> (8 * j)) & 0xFF;
-    };
-    auto put_lt = [&](int k, uint64_t x) {  // (low 7 bits, top bit) of every byte of x
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t bv = (uint32_t)(x >> (8 * j)) & 0xFF;
-            cell(GC(k, S_L, j)) = bv & 127;
-            cell(GC(k, S_T, j)) = bv >> 7;
-        }
-    };
+    auto st = [&](int w) -> uint64_t& { return stage[(size_t)w * n + row]; };
+    auto gw = [&](int k, int slot) -> uint64_t& { return st(8 * k + slot); };  // slot 7 = X (L / T)
     auto look1 = [&](uint64_t a, uint64_t bq) {  // 8 byte lookups (a_i, b_i, .) into T1
 #pragma unroll
         for (int j = 0; j < 8; ++j) atomicAdd(&hist[((a >> (8 * j)) & 0xFF) | (((bq >> (8 * j)) & 0xFF) << 8)], 1u);
@@ -150,140 +142,163 @@ __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const 
 #pragma unroll
         for (int j = 0; j < 8; ++j) atomicAdd(&hist[65536 + (((a >> (8 * j)) & 0xFF) | (((bq >> (8 * j)) & 0xFF) << 8))], 1u);
     };
-    // ---- G area + carries: zero unless this row uses the cell
-    for (int col = 0; col < MS0; ++col) cell(col) = 0;  // (a lane's later store to the same address wins)
+    // ---- G area + carries
     blake_init_v(v, h, d.t, d.fin);
-    if (r == 0) {
-        for (int w = 0; w < 16; ++w) {
-            const int mm = w & 3;
-            if (w < 4) put(4 + w, S_A2, v[w]);
-            else if (w < 8) put_lt(4 + (mm + 3) % 4, b_rotr(v[w], 1));  // 2 L[j] + T[j-1] = byte j of v[w]
-            else if (w < 12) put(4 + (mm + 2) % 4, S_C2, v[w]);
-            else put(4 + (mm + 1) % 4, S_D2, v[w]);
-        }
+    uint64_t carw = 0;
+    if (r >= 1 && r <= 12) {
+        for (int q = 0; q + 1 < r; ++q) blake_round(v, m, q);
+        const uint8_t* sg = ORDER[r];  // sigma of round r - 1
+        auto G = [&](int k, uint64_t& va, uint64_t& vb, uint64_t& vc, uint64_t& vd, uint64_t x, uint64_t y) {
+            const uint64_t a = va, bq = vb, c = vc, dd = vd;
+            const uint64_t a1 = a + bq + x, d1 = b_rotr(dd ^ a1, 32), c1 = c + d1, b1 = b_rotr(bq ^ c1, 24);
+            const uint64_t a2 = a1 + b1 + y, d2 = b_rotr(d1 ^ a2, 16), c2 = c1 + d2, b2 = b_rotr(b1 ^ c2, 63);
+            gw(k, S_A1) = a1, gw(k, S_D1) = d1, gw(k, S_C1) = c1, gw(k, S_B1) = b1, gw(k, S_A2) = a2, gw(k, S_D2) = d2, gw(k, S_C2) = c2, gw(k, 7) = b1 ^ c2;
+            uint8_t car[4];
+            carries(a, bq, x, car);
+            carries(a1, b1, y, car + 2);
+            carw |= ((uint64_t)car[0] | ((uint64_t)car[1] << 2) | ((uint64_t)car[2] << 4) | ((uint64_t)car[3] << 6)) << (8 * k);
+            // the row's lookups: (d, A1), (b, C1), (D1, A2) into T1 and (B1, C2) into T2
+            look1(dd, a1), look1(bq, c1), look1(d1, a2), look2(b1, c2);
+            va = a2, vb = b2, vc = c2, vd = d2;
+        };
+        G(0, v[0], v[4], v[8], v[12], m[sg[0]], m[sg[1]]);
+        G(1, v[1], v[5], v[9], v[13], m[sg[2]], m[sg[3]]);
+        G(2, v[2], v[6], v[10], v[14], m[sg[4]], m[sg[5]]);
+        G(3, v[3], v[7], v[11], v[15], m[sg[6]], m[sg[7]]);
+        G(4, v[0], v[5], v[10], v[15], m[sg[8]], m[sg[9]]);
+        G(5, v[1], v[6], v[11], v[12], m[sg[10]], m[sg[11]]);
+        G(6, v[2], v[7], v[8], v[13], m[sg[12]], m[sg[13]]);
+        G(7, v[3], v[4], v[9], v[14], m[sg[14]], m[sg[15]]);
     } else {
-        GRec rec[8];
-        uint64_t vin[16];
-        const int last = r <= 12 ? r - 1 : 11;  // rounds 0 .. last
-        for (int q = 0; q <= last; ++q) {
-            if (q == last)
-                for (int k = 0; k < 16; ++k) vin[k] = v[k];
-            blake_round(v, m, q, q == last && r <= 12 ? rec : nullptr);
-        }
-        if (r <= 12) {
-            for (int k = 0; k < 8; ++k) {
-                const uint64_t *w = rec[k].w;  // a1 d1 c1 b1 a2 d2 c2 b2
-                put(k, S_A1, w[0]), put(k, S_D1, w[1]), put(k, S_C1, w[2]), put(k, S_B1, w[3]), put(k, S_A2, w[4]), put(k, S_D2, w[5]), put(k, S_C2, w[6]);
-                put_lt(k, w[3] ^ w[6]);
-                cell(CAR(k, 0)) = rec[k].car[0], cell(CAR(k, 1)) = rec[k].car[1], cell(CAR(k, 2)) = rec[k].car[4], cell(CAR(k, 3)) = rec[k].car[5];
-                // the row's lookups: (d, A1), (b, C1), (D1, A2) into T1 and (B1, C2) into T2
-                look1(rec[k].in_d, w[0]);
-                look1(rec[k].in_b, w[2]);
-                look1(w[1], w[4]);
-                look2(w[3], w[6]);
+        for (int w = 0; w < 64; ++w) st(w) = 0;  // (a lane's later store to the same address wins)
+        if (r == 0) {
+            for (int w = 0; w < 16; ++w) {
+                const int mm = w & 3;
+                if (w < 4) gw(4 + w, S_A2) = v[w];
+                else if (w < 8) gw(4 + (mm + 3) % 4, 7) = b_rotr(v[w], 1);  // 2 L[j] + T[j-1] = byte j of v[w]
+                else if (w < 12) gw(4 + (mm + 2) % 4, S_C2) = v[w];
+                else gw(4 + (mm + 1) % 4, S_D2) = v[w];
             }
-        } else if (r == 13 || r == 14) {
-            for (int w = 0; w < 8; ++w) {
-                const uint64_t u = v[w] ^ v[8 + w];
-                const uint64_t x = r == 13 ? v[w] : u, y = r == 13 ? v[8 + w] : h[w];
-                put(w, S_D1, x), put(w, S_A2, y), put(w, S_D2, b_rotr(x ^ y, 16));
-                look1(x, y);
-            }
+        } else {
+            for (int q = 0; q < 12; ++q) blake_round(v, m, q);
+            if (r <= 14)
+                for (int w = 0; w < 8; ++w) {
+                    const uint64_t u = v[w] ^ v[8 + w];
+                    const uint64_t x = r == 13 ? v[w] : u, y = r == 13 ? v[8 + w] : h[w];
+                    gw(w, S_D1) = x, gw(w, S_A2) = y, gw(w, S_D2) = b_rotr(x ^ y, 16);
+                    look1(x, y);
+                }
         }
-        (void)vin;
     }
+    st(SW_CAR) = carw;
     uint64_t h_out[8];
     if (r >= 13)
         for (int k = 0; k < 8; ++k) h_out[k] = h[k] ^ v[k] ^ v[k + 8];
     // ---- message schedule + bytes of natural word r (range checked as (byte, 0, byte) in T1)
-    for (int s = 0; s < 16; ++s) {
-        const uint64_t w = m[ORDER[r][s]];
-        cell(MS(s, 0)) = w & 0xFFFFFFFFULL;
-        cell(MS(s, 1)) = w >> 32;
-    }
-    for (int j = 0; j < 8; ++j) cell(MB0 + j) = (m[r] >> (8 * j)) & 0xFF;
-    look1(m[r], 0);
-    for (int bq = 0; bq < 8; ++bq) cell(MK0 + bq) = (uint32_t)(8 * r + bq) < d.inc ? 1 : 0;
-    cell(CNT) = d.inc < (uint32_t)(8 * (r + 1)) ? d.inc : (uint32_t)(8 * (r + 1));
-    // ---- H register
-    for (int w = 0; w < 8; ++w) {
-        const uint64_t hv = r <= 13 ? h[w] : (r == 14 ? h_out[w] : (d.fin ? (w == 0 ? IV[0] ^ 0x01010020ULL : IV[w]) : h_out[w]));
-        cell(HL(w, 0)) = hv & 0xFFFFFFFFULL;
-        cell(HL(w, 1)) = hv >> 32;
-    }
-    // ---- digest register, flags, counters
+    for (int s = 0; s < 16; ++s) st(SW_MS + s) = m[ORDER[r][s]];
+    st(SW_MB) = m[r];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&rc_lds[(m[r] >> (8 * j)) & 0xFF], 1u);
+    // ---- H register, digest register
+    for (int w = 0; w < 8; ++w) st(SW_HL + w) = r <= 13 ? h[w] : (r == 14 ? h_out[w] : (d.fin ? (w == 0 ? IV[0] ^ 0x01010020ULL : IV[w]) : h_out[w]));
     const bool cap = d.act && d.fin;
-    for (int j = 0; j < 8; ++j) {
-        uint32_t dv = d.D[j];
-        if (r == 15 && cap) dv = (uint32_t)(h_out[j / 2] >> (32 * (j & 1)));
-        cell(D0 + j) = dv;
+    for (int j = 0; j < 4; ++j) st(SW_D + j) = (r == 15 && cap) ? h_out[j] : ((uint64_t)d.D[2 * j] | ((uint64_t)d.D[2 * j + 1] << 32));
+    // ---- flags, counters
+    uint64_t mk = 0;
+    for (int bq = 0; bq < 8; ++bq) mk |= (uint64_t)((uint32_t)(8 * r + bq) < d.inc ? 1 : 0) << bq;
+    const uint64_t cnt = d.inc < (uint32_t)(8 * (r + 1)) ? d.inc : (uint32_t)(8 * (r + 1));
+    st(SW_FLAGS) = (uint64_t)d.act | ((uint64_t)d.fin << 1) | ((uint64_t)d.first << 2) | ((uint64_t)(cap ? 1 : 0) << 3) | ((uint64_t)((d.first && d.act) ? 1 : 0) << 4) |
+                   ((uint64_t)d.inc << 8) | (cnt << 16) | (mk << 24);
+    st(SW_TN) = (uint64_t)d.t | ((uint64_t)d.num << 32);
+    __syncthreads();
+    rc_part[(size_t)blockIdx.x * 256 + threadIdx.x] = rc_lds[threadIdx.x];
+}
+constexpr int EXP_RPL = 8;  // rows per lane: a block writes 8 x 2 KB = 16 KB of a column per visit
+__global__ __launch_bounds__(256) void k_blake_expand(const uint64_t* __restrict__ stage, uint64_t* __restrict__ tr, size_t n, const ExpandEntry* __restrict__ ent,
+                                                      const uint32_t* __restrict__ off) {
+    const int w = blockIdx.y;
+    const size_t row0 = (size_t)blockIdx.x * (256 * EXP_RPL) + threadIdx.x;
+    uint64_t x[EXP_RPL];
+#pragma unroll
+    for (int rr = 0; rr < EXP_RPL; ++rr) {
+        const size_t row = row0 + 256 * (size_t)rr;
+        x[rr] = row < n ? stage[(size_t)w * n + row] : 0;
     }
-    cell(ACT) = d.act, cell(FIN) = d.fin, cell(FIRST) = d.first, cell(CAP) = cap ? 1 : 0;
-    cell(T) = d.t, cell(INC) = d.inc, cell(NUM) = d.num, cell(FA) = (d.first && d.act) ? 1 : 0;
-    for (int i = 0; i < 32; ++i) cell(TB0 + i) = (d.t >> i) & 1;
-    for (int i = 0; i < 8; ++i) cell(IB0 + i) = (d.inc >> i) & 1;
+    for (uint32_t e = off[w]; e < off[w + 1]; ++e) {
+        const ExpandEntry E = ent[e];
+        const uint64_t mask = E.bits == 64 ? ~0ULL : ((1ULL << E.bits) - 1);
+        uint64_t* c = tr + (size_t)E.col * n;
+#pragma unroll
+        for (int rr = 0; rr < EXP_RPL; ++rr) {
+            const size_t row = row0 + 256 * (size_t)rr;
+            if (row < n) c[row] = (x[rr] >> E.shift) & mask;
+        }
+    }
+}
+// cell <- (packed word, shift, width) for every main column except the two multiplicities
+static void blake_expand_table(std::vector<ExpandEntry>& ent, std::vector<uint32_t>& off) {
+    using namespace blk;
+    std::vector<std::vector<ExpandEntry>> per(N_STAGE);
+    auto add = [&](int w, int col, int shift, int bits) { per[w].push_back(ExpandEntry{(uint16_t)col, (uint8_t)shift, (uint8_t)bits}); };
+    for (int k = 0; k < 8; ++k) {
+        for (int slot = 0; slot < 7; ++slot)
+            for (int j = 0; j < 8; ++j) add(8 * k + slot, GC(k, slot, j), 8 * j, 8);
+        for (int j = 0; j < 8; ++j) add(8 * k + 7, GC(k, S_L, j), 8 * j, 7), add(8 * k + 7, GC(k, S_T, j), 8 * j + 7, 1);
+        for (int q = 0; q < 4; ++q) add(SW_CAR, CAR(k, q), 8 * k + 2 * q, 2);
+    }
+    for (int s = 0; s < 16; ++s) add(SW_MS + s, MS(s, 0), 0, 32), add(SW_MS + s, MS(s, 1), 32, 32);
+    for (int j = 0; j < 8; ++j) add(SW_MB, MB0 + j, 8 * j, 8);
+    for (int w = 0; w < 8; ++w) add(SW_HL + w, HL(w, 0), 0, 32), add(SW_HL + w, HL(w, 1), 32, 32);
+    for (int j = 0; j < 4; ++j) add(SW_D + j, D0 + 2 * j, 0, 32), add(SW_D + j, D0 + 2 * j + 1, 32, 32);
+    add(SW_FLAGS, ACT, 0, 1), add(SW_FLAGS, FIN, 1, 1), add(SW_FLAGS, FIRST, 2, 1), add(SW_FLAGS, CAP, 3, 1), add(SW_FLAGS, FA, 4, 1);
+    add(SW_FLAGS, INC, 8, 8), add(SW_FLAGS, CNT, 16, 8);
+    for (int i = 0; i < 8; ++i) add(SW_FLAGS, IB0 + i, 8 + i, 1), add(SW_FLAGS, MK0 + i, 24 + i, 1);
+    add(SW_TN, T, 0, 32), add(SW_TN, NUM, 32, 32);
+    for (int i = 0; i < 32; ++i) add(SW_TN, TB0 + i, i, 1);
+    off.assign(1, 0);
+    for (auto& v : per) {
+        ent.insert(ent.end(), v.begin(), v.end());
+        off.push_back((uint32_t)ent.size());
+    }
 }
 // the multiplicity columns: all counts in the first copy of the periodic tables
-__global__ __launch_bounds__(256) void k_blake_mult(const uint32_t* hist, uint64_t* tr, size_t n) {
+__global__ __launch_bounds__(256) void k_blake_mult(const uint32_t* hist, const uint32_t* rc_part, uint64_t* tr, size_t n) {
     const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (row >= n) return;
-    tr[(size_t)blk::M1 * n + row] = row < 65536 ? hist[row] : 0;
+    uint64_t m1 = row < 65536 ? hist[row] : 0;
+    if (row < 256)  // table rows (a, b = 0): plus the per-block range-check counts
+        for (size_t b = 0; b < n / 256; ++b) m1 += rc_part[b * 256 + row];
+    tr[(size_t)blk::M1 * n + row] = m1;
     tr[(size_t)blk::M2 * n + row] = row < 65536 ? hist[65536 + row] : 0;
 }
 
 // ---- auxiliary columns (logUp) --------------------------------------------------------------------------------------
-// One lane per row i (as the "next" row of the pair (i-1, i)): the 132 helper elements of row i (two lookups each,
-// h = m (1/D_u + 1/D_v); the four pairs of a group share ONE extension-field inversion, Montgomery's trick), the table
-// helper of row i, and the running-sum increment Z(i) - Z(i-1) = sum_e h_e(i) - ht(i-1), stored at row i-1 and turned
-// into Z by an exclusive scan.
+// k_blake_aux: one lane per (row i, unit u); i is the "next" row of the pair (i-1, i).  Units 0..7 = the 16 helper
+// elements of G number u (two lookups each, h = m (1/D_u + 1/D_v); the four pairs of a group share ONE extension-field
+// inversion, Montgomery's trick); unit 8 = the 4 message-byte range-check helpers and the table helper of row i.  Every
+// unit leaves the sum of its helpers in part[u]; k_blake_aux_z adds them up into the running-sum increment
+// Z(i) - Z(i-1) = sum_e h_e(i) - ht(i-1), stored at row i-1 and turned into Z by an exclusive scan.
 struct AuxArgs {
     const uint64_t* tr;
     uint64_t* aux;
+    uint64_t* part;  // [9][2][n]
     size_t n;
     gl2 beta, gamma;
 };
-__device__ __forceinline__ gl2 gl2_from(uint64_t x) { return {x, 0}; }
 __global__ __launch_bounds__(256) void k_blake_aux(AuxArgs a) {
     using namespace blk;
     const size_t n = a.n, i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const int unit = blockIdx.y;
     if (i >= n) return;
     const size_t ip = (i + n - 1) & (n - 1);
     const int rl = (int)(ip & 15);  // row index (mod 16) of the LOCAL row: selectors are taken there
     const bool g_on = rl <= 11, m3 = rl <= 13;
-    const gl2 beta = a.beta, gamma = a.gamma, g2 = gl2_mul(gamma, gamma), g3 = gl2_mul(g2, gamma), g4 = gl2_mul(g2, g2);
-    const gl2 bt2 = gl2_add(beta, g4);
+    const gl2 beta = a.beta, gamma = a.gamma, g2 = gl2_mul(gamma, gamma);
     auto N = [&](int col) -> uint64_t { return a.tr[(size_t)col * n + i]; };
     auto L = [&](int col) -> uint64_t { return a.tr[(size_t)col * n + ip]; };
-    auto out_byte_loc = [&](int w, int j) -> uint64_t {
-        const int m = w & 3;
-        if (w < 4) return L(GC(4 + w, S_A2, j));
-        if (w < 8) {
-            const int k = 4 + (m + 3) % 4;
-            return 2 * L(GC(k, S_L, j)) + L(GC(k, S_T, (j + 7) & 7));
-        }
-        if (w < 12) return L(GC(4 + (m + 2) % 4, S_C2, j));
-        return L(GC(4 + (m + 1) % 4, S_D2, j));
-    };
-    auto in_byte = [&](int k, int op, int j) -> uint64_t {
-        if (k < 4) return out_byte_loc(4 * op + k, j);
-        const int j0 = k - 4;
-        if (op == 1) {
-            const int kb = (j0 + 1) & 3;
-            return 2 * N(GC(kb, S_L, j)) + N(GC(kb, S_T, (j + 7) & 7));
-        }
-        return N(GC((j0 + 3) & 3, S_D2, j));  // op == 3 (a and c never enter a lookup)
-    };
-    auto fp1 = [&](uint64_t x, uint64_t y, uint64_t z) -> gl2 {  // small operands: products by < 2^9 stay cheap but exact
+    auto fp1 = [&](uint64_t x, uint64_t y, uint64_t z) -> gl2 {
         gl2 d = gl2_add(beta, gl2_add(gl2_scale(gamma, y), gl2_scale(g2, z)));
         d.a = gl_add(d.a, x);
-        return d;
-    };
-    auto denom = [&](int k, int grp, int q) -> gl2 {
-        if (grp == 0) return fp1(in_byte(k, 3, q), N(GC(k, S_A1, q)), N(GC(k, S_D1, (q + 4) & 7)));
-        if (grp == 1) return fp1(in_byte(k, 1, q), N(GC(k, S_C1, q)), N(GC(k, S_B1, (q + 5) & 7)));
-        if (grp == 2) return fp1(N(GC(k, S_D1, q)), N(GC(k, S_A2, q)), N(GC(k, S_D2, (q + 6) & 7)));
-        gl2 d = gl2_add(bt2, gl2_add(gl2_scale(gamma, N(GC(k, S_C2, q))), gl2_add(gl2_scale(g2, N(GC(k, S_L, q))), gl2_scale(g3, N(GC(k, S_T, q))))));
-        d.a = gl_add(d.a, N(GC(k, S_B1, q)));
         return d;
     };
     auto store = [&](int e, gl2 h) {
@@ -308,25 +323,87 @@ __global__ __launch_bounds__(256) void k_blake_aux(AuxArgs a) {
             hsum = gl2_add(hsum, h);
         }
     };
+    if (unit < 8) {
+        const int k = unit;
+        const gl2 g3 = gl2_mul(g2, gamma), bt2 = gl2_add(beta, gl2_mul(g2, g2));
+        auto out_byte_loc = [&](int w, int j) -> uint64_t {
+            const int m = w & 3;
+            if (w < 8) {  // only b (w = 4..7) and d (w = 12..15) operands enter a lookup
+                const int kk = 4 + (m + 3) % 4;
+                return 2 * L(GC(kk, S_L, j)) + L(GC(kk, S_T, (j + 7) & 7));
+            }
+            return L(GC(4 + (m + 1) % 4, S_D2, j));
+        };
+        auto in_byte = [&](int op, int j) -> uint64_t {
+            if (k < 4) return out_byte_loc(4 * op + k, j);
+            const int j0 = k - 4;
+            if (op == 1) {
+                const int kb = (j0 + 1) & 3;
+                return 2 * N(GC(kb, S_L, j)) + N(GC(kb, S_T, (j + 7) & 7));
+            }
+            return N(GC((j0 + 3) & 3, S_D2, j));
+        };
+        auto denoms = [&](int grp, gl2* dd) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (grp == 0) dd[q] = fp1(in_byte(3, q), N(GC(k, S_A1, q)), N(GC(k, S_D1, (q + 4) & 7)));
+                else if (grp == 1) dd[q] = fp1(in_byte(1, q), N(GC(k, S_C1, q)), N(GC(k, S_B1, (q + 5) & 7)));
+                else if (grp == 2) dd[q] = fp1(N(GC(k, S_D1, q)), N(GC(k, S_A2, q)), N(GC(k, S_D2, (q + 6) & 7)));
+                else {
+                    gl2 d = gl2_add(bt2, gl2_add(gl2_scale(gamma, N(GC(k, S_C2, q))), gl2_add(gl2_scale(g2, N(GC(k, S_L, q))), gl2_scale(g3, N(GC(k, S_T, q))))));
+                    d.a = gl_add(d.a, N(GC(k, S_B1, q)));
+                    dd[q] = d;
+                }
+            }
+        };
+        // ONE extension-field inversion per lane (Montgomery's trick on two levels): pass 1 multiplies the 8 denominators
+        // of every active group into c[grp]; the four c are inverted together; pass 2 recomputes the denominators (the
+        // cells come back from cache) and unwinds each group with its 1 / c[grp].
+        gl2 cg[4], tot{1, 0};
 #pragma unroll 1
-    for (int k = 0; k < 8; ++k)
+        for (int grp = 0; grp < 4; ++grp) {
+            cg[grp] = gl2{1, 0};
+            if (grp == 2 ? m3 : g_on) {
+                gl2 dd[8];
+                denoms(grp, dd);
+                gl2 c = gl2_mul(dd[0], dd[1]);
+#pragma unroll
+                for (int q = 2; q < 8; ++q) c = gl2_mul(c, dd[q]);
+                cg[grp] = c;
+            }
+        }
+        // prefix products of cg, one inversion, suffix unwinding -> icg[grp] = 1 / cg[grp]
+        const gl2 p01 = gl2_mul(cg[0], cg[1]), p012 = gl2_mul(p01, cg[2]);
+        tot = gl2_mul(p012, cg[3]);
+        gl2 inv = m3 ? gl2_inv(tot) : gl2{1, 0};
+        gl2 icg[4];
+        icg[3] = gl2_mul(inv, p012), inv = gl2_mul(inv, cg[3]);
+        icg[2] = gl2_mul(inv, p01), inv = gl2_mul(inv, cg[2]);
+        icg[1] = gl2_mul(inv, cg[0]), icg[0] = gl2_mul(inv, cg[1]);
 #pragma unroll 1
         for (int grp = 0; grp < 4; ++grp) {
             const int e0 = (k * 4 + grp) * 4;
             if (grp == 2 ? m3 : g_on) {
-                gl2 p[4], s[4];
+                gl2 dd[8], p[4];
+                denoms(grp, dd);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) p[q] = gl2_mul(dd[2 * q], dd[2 * q + 1]);
+                // 1 / p[q] = icg * (product of the other three pair products)
+                const gl2 p01_ = gl2_mul(p[0], p[1]), p23_ = gl2_mul(p[2], p[3]);
+                const gl2 a01 = gl2_mul(icg[grp], p23_), a23 = gl2_mul(icg[grp], p01_);  // 1 / (p0 p1), 1 / (p2 p3)
+                const gl2 ip[4] = {gl2_mul(a01, p[1]), gl2_mul(a01, p[0]), gl2_mul(a23, p[3]), gl2_mul(a23, p[2])};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const gl2 du = denom(k, grp, 2 * q), dv = denom(k, grp, 2 * q + 1);
-                    p[q] = gl2_mul(du, dv), s[q] = gl2_add(du, dv);
+                    const gl2 h = gl2_mul(gl2_add(dd[2 * q], dd[2 * q + 1]), ip[q]);
+                    store(e0 + q, h);
+                    hsum = gl2_add(hsum, h);
                 }
-                four(p, s, e0);
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) store(e0 + q, gl2{0, 0});
             }
         }
-    {
+    } else {
         gl2 p[4], s[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -335,30 +412,45 @@ __global__ __launch_bounds__(256) void k_blake_aux(AuxArgs a) {
             p[q] = gl2_mul(du, dv), s[q] = gl2_add(du, dv);
         }
         four(p, s, HM0);
+        // table helper of this row: ht = M1 / D_t1 + M2 / D_t2
+        const uint64_t m1 = N(M1), m2 = N(M2);
+        gl2 ht{0, 0};
+        if (m1 | m2) {
+            const gl2 g3 = gl2_mul(g2, gamma), bt2 = gl2_add(beta, gl2_mul(g2, g2));
+            const uint64_t ti = i & 65535, ta = ti & 255, tb = ti >> 8, x = ta ^ tb;
+            const gl2 d1 = fp1(ta, tb, x);
+            gl2 d2 = gl2_add(bt2, gl2_add(gl2_scale(gamma, tb), gl2_add(gl2_scale(g2, x & 127), gl2_scale(g3, x >> 7))));
+            d2.a = gl_add(d2.a, ta);
+            ht = gl2_mul(gl2_add(gl2_scale(d2, m1), gl2_scale(d1, m2)), gl2_inv(gl2_mul(d1, d2)));
+        }
+        store(HT, ht);
     }
-    // table helper of this row and of the local row: ht = M1 / D_t1 + M2 / D_t2
-    auto table_h = [&](size_t row, uint64_t m1, uint64_t m2) -> gl2 {
-        const uint64_t ti = row & 65535, ta = ti & 255, tb = ti >> 8, x = ta ^ tb;
-        const gl2 d1 = fp1(ta, tb, x);
-        gl2 d2 = gl2_add(bt2, gl2_add(gl2_scale(gamma, tb), gl2_add(gl2_scale(g2, x & 127), gl2_scale(g3, x >> 7))));
-        d2.a = gl_add(d2.a, ta);
-        if ((m1 | m2) == 0) return gl2{0, 0};
-        const gl2 num = gl2_add(gl2_scale(d2, m1), gl2_scale(d1, m2));
-        return gl2_mul(num, gl2_inv(gl2_mul(d1, d2)));
-    };
-    const gl2 ht = table_h(i, N(M1), N(M2));
-    store(HT, ht);
-    const gl2 dz = gl2_sub(hsum, table_h(ip, L(M1), L(M2)));
-    a.aux[(size_t)(2 * ZZ) * n + ip] = dz.a;
-    a.aux[(size_t)(2 * ZZ + 1) * n + ip] = dz.b;
+    a.part[(size_t)(2 * unit) * n + i] = hsum.a;
+    a.part[(size_t)(2 * unit + 1) * n + i] = hsum.b;
+}
+__global__ __launch_bounds__(256) void k_blake_aux_z(const uint64_t* part, uint64_t* aux, size_t n) {
+    using namespace blk;
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t ip = (i + n - 1) & (n - 1);
+    uint64_t sa = 0, sb = 0;
+#pragma unroll
+    for (int u = 0; u < 9; ++u) sa = gl_add(sa, part[(size_t)(2 * u) * n + i]), sb = gl_add(sb, part[(size_t)(2 * u + 1) * n + i]);
+    aux[(size_t)(2 * ZZ) * n + ip] = gl_sub(sa, aux[(size_t)(2 * HT) * n + ip]);
+    aux[(size_t)(2 * ZZ + 1) * n + ip] = gl_sub(sb, aux[(size_t)(2 * HT + 1) * n + ip]);
 }
 
 int32_t vx_blake_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, uint64_t* aux, uint64_t* aux_pub) {
     (void)aux_pub;
     const size_t n = (size_t)1 << log_n;
-    AuxArgs a{trace, aux, n, gl2{chal[0], chal[1]}, gl2{chal[2], chal[3]}};
-    hipLaunchKernelGGL(k_blake_aux, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);
-    VX_HIP(hipGetLastError());
+    uint64_t* part = (uint64_t*)vx_pool_alloc(ctx, 18 * n * 8);
+    if (!part) return vx_fail(ctx, VX_ERR_OOM, "blake aux: out of device memory");
+    AuxArgs a{trace, aux, part, n, gl2{chal[0], chal[1]}, gl2{chal[2], chal[3]}};
+    hipLaunchKernelGGL(k_blake_aux, dim3((unsigned)((n + 255) / 256), 9), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_blake_aux_z, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint64_t*)part, aux, n);
+    const hipError_t e = hipGetLastError();
+    vx_pool_free(ctx, part);  // recycled only by later work on the same stream
+    if (e != hipSuccess) return vx_fail(ctx, VX_ERR_DEVICE, "blake aux: %s", hipGetErrorString(e));
     return vx_scan_cols_dev(ctx, aux + (size_t)(2 * blk::ZZ) * n, log_n, 2, nullptr);
 }
 
@@ -386,15 +478,25 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
     // device scratch: sizes | block_base | digests | hchain | descs
     const size_t w_sizes = (n_headers * 4 + 7) / 8, w_dig = n_headers * 4, w_hc = n_real * 8;
     const size_t w_desc = (n_blocks * sizeof(BlockDesc) + 7) / 8;
-    const size_t w_hist = 65536;  // two tables x 2^16 uint32 counters
+    const size_t w_hist = 65536 + n / 2;  // two tables x 2^16 uint32 counters + 256 range-check counters per 256-row block
+    std::vector<ExpandEntry> ent;
+    std::vector<uint32_t> eoff;
+    blake_expand_table(ent, eoff);
+    VX_CHECK(ent.size() == (size_t)blk::COLS - 2, "blake trace: expansion table covers %zu of %d columns", ent.size(), blk::COLS - 2);
+    const size_t w_ent = (ent.size() * sizeof(ExpandEntry) + 7) / 8, w_eoff = (eoff.size() * 4 + 7) / 8, w_stage = (size_t)N_STAGE * n;
     uint64_t* sc;
-    VX_TRY(vx_scratch(ctx, 2 * w_sizes + w_dig + w_hc + w_desc + w_hist, &sc));
+    VX_TRY(vx_scratch(ctx, 2 * w_sizes + w_dig + w_hc + w_desc + w_hist + w_ent + w_eoff + w_stage, &sc));
     uint32_t* d_sizes = (uint32_t*)sc;
     uint32_t* d_base = (uint32_t*)(sc + w_sizes);
     uint8_t* d_dig = (uint8_t*)(sc + 2 * w_sizes);
     uint64_t* d_hc = sc + 2 * w_sizes + w_dig;
     BlockDesc* d_desc = (BlockDesc*)(d_hc + w_hc);
     uint32_t* d_hist = (uint32_t*)(d_hc + w_hc + w_desc);
+    ExpandEntry* d_ent = (ExpandEntry*)(d_hc + w_hc + w_desc + w_hist);
+    uint32_t* d_eoff = (uint32_t*)(d_hc + w_hc + w_desc + w_hist + w_ent);
+    uint64_t* d_stage = d_hc + w_hc + w_desc + w_hist + w_ent + w_eoff;
+    VX_HIP(hipMemcpyAsync(d_ent, ent.data(), ent.size() * sizeof(ExpandEntry), hipMemcpyHostToDevice, ctx->stream));
+    VX_HIP(hipMemcpyAsync(d_eoff, eoff.data(), eoff.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     VX_HIP(hipMemcpyAsync(d_sizes, sizes, n_headers * 4, hipMemcpyHostToDevice, ctx->stream));
     VX_HIP(hipMemcpyAsync(d_base, base.data(), n_headers * 4, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_blake_chain, dim3((unsigned)((n_headers + 63) / 64)), dim3(64), 0, ctx->stream, (const uint8_t*)headers->d,
@@ -435,11 +537,14 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
         memcpy(d.D, D, 32);
     }
     VX_HIP(hipMemcpyAsync(d_desc, descs.data(), n_blocks * sizeof(BlockDesc), hipMemcpyHostToDevice, ctx->stream));
-    VX_HIP(hipMemsetAsync(d_hist, 0, w_hist * 8, ctx->stream));
+    VX_HIP(hipMemsetAsync(d_hist, 0, 65536 * 8, ctx->stream));
     hipLaunchKernelGGL(k_blake_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t*)headers->d,
-                       (const BlockDesc*)d_desc, (const uint64_t*)d_hc, n_real, trace_out->d, d_hist, n);
+                       (const BlockDesc*)d_desc, (const uint64_t*)d_hc, n_real, d_stage, d_hist, d_hist + 131072, n);
     VX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_blake_mult, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_hist, trace_out->d, n);
+    hipLaunchKernelGGL(k_blake_expand, dim3((unsigned)((n + 256 * EXP_RPL - 1) / (256 * EXP_RPL)), N_STAGE), dim3(256), 0, ctx->stream,
+                       (const uint64_t*)d_stage, trace_out->d, n, (const ExpandEntry*)d_ent, (const uint32_t*)d_eoff);
+    VX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_blake_mult, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_hist, (const uint32_t*)(d_hist + 131072), trace_out->d, n);
     VX_HIP(hipGetLastError());
     VX_HIP(hipStreamSynchronize(ctx->stream));  // descs must outlive the kernel
     for (int j = 0; j < 8; ++j) {

@@ -123,9 +123,12 @@ struct QuotArgs {
 #ifndef VX_Q_WAVES
 #define VX_Q_WAVES 4
 #endif
+#ifndef VX_Q_WAVES_MAX
+#define VX_Q_WAVES_MAX 8
+#endif
 // one block = a tile of 256 * R consecutive LDE points, lane t holding points t, t + 256, ... of the tile
 template <class Air, int R>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_Q_WAVES, 8))) void k_quotient(QuotArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_Q_WAVES, VX_Q_WAVES_MAX))) void k_quotient(QuotArgs a) {
     using F = FpN<R>;
     const size_t N = (size_t)1 << a.log_N;
     const size_t i0 = blockIdx.x * (size_t)(256 * R) + threadIdx.x;
