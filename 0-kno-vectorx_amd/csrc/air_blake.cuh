@@ -5,7 +5,7 @@
 // vendored); this is a from-scratch byte-lookup arithmetisation of RFC 7693 in the same spirit: every 64-bit word is
 // 8 byte cells, XORs are lookups into 2^16-row tables through a logUp argument (auxiliary commitment round), additions
 // are 32-bit limb identities, rotations by 32 / 24 / 16 are byte re-indexings and the rotation by 63 is carried by a
-// (low 7 bits, top bit) split of the XOR bytes.  731 main + 268 auxiliary columns (the bit-decomposed AIR it replaces
+// (low 7 bits, top bit) split of the XOR bytes.  740 main + 278 auxiliary columns (the bit-decomposed AIR it replaces
 // had 4337), degree <= 3, 16 rows per compression:
 //   r = 0 INIT (out-state = initial work vector), r = 1..12 ROUND (row r holds round r-1's eight G evaluations),
 //   r = 13 FIN1 (U = v_lo ^ v_hi), r = 14 FIN2 (h_out = U ^ h), r = 15 PAD (H = next h_in, digest register D updated).
@@ -13,6 +13,11 @@
 //   A1 = a + b + x, D1 = (d ^ A1) >>> 32, C1 = c + D1, B1 = (b ^ C1) >>> 24, A2 = A1 + B1 + y, D2 = (D1 ^ A2) >>> 16,
 //   C2 = C1 + D2, (L, T) = (low 7 bits, top bit) of each byte of B1 ^ C2;  byte j of B2 = (B1 ^ C2) >>> 63 is 2 L[j] + T[j-1].
 // Tables (periodic, period 2^16, row i = (a = i & 255, b = i >> 8)): T1 (a, b, a ^ b), T2 (a, b, (a ^ b) & 127, (a ^ b) >> 7).
+// Bus to the SHA-256 Merkle AIR (air_sha_tree.cuh): the running sum also carries what decode_header extracts
+// (decoder.rs:104-157) -- the state root (bytes 36..68, eight big-endian words sent from rows 4..8 of a header's first
+// chunk as (tree 0, node id N + leaf, j, word)) and the data root (the last 32 bytes, sent byte by byte as
+// (leaf, k, byte) under a witness flag E per message byte; k comes from the byte counter and the size register SZ).
+// The table's net bus total is published as S / n (apub) and must cancel against the other table's.
 // Constraint ORDER is protocol: oracle/blake_air.py restates it independently.
 #pragma once
 #include <type_traits>
@@ -24,8 +29,12 @@ namespace blk {
 constexpr int S_A1 = 0, S_D1 = 1, S_C1 = 2, S_B1 = 3, S_A2 = 4, S_D2 = 5, S_C2 = 6, S_L = 7, S_T = 8;
 constexpr int CAR0 = 576, MS0 = 608, MB0 = 640, HL0 = 648, D0 = 664;
 constexpr int ACT = 672, FIN = 673, FIRST = 674, CAP = 675, T = 676, INC = 677, NUM = 678, FA = 679;
-constexpr int TB0 = 680, IB0 = 712, MK0 = 720, CNT = 728, M1 = 729, M2 = 730, COLS = 731;
-constexpr int N_HELP = 134, HM0 = 128, HT = 132, ZZ = 133, AUX = 2 * N_HELP, TABLE_LOG = 16;
+constexpr int TB0 = 680, IB0 = 712, MK0 = 720, CNT = 728, M1 = 729, M2 = 730, SZ = 731, E0 = 732, COLS = 740;
+// helper elements: 128 of the G functions, 4 message-byte range checks, 4 data-root byte sends, 1 state-root word sends,
+// the table helper, the running sum
+constexpr int N_HELP = 139, HM0 = 128, HB0 = 132, HS = 136, HT = 137, ZZ = 138, AUX = 2 * N_HELP, TABLE_LOG = 16;
+// bus tuples are (t0, t1, t2, t3, tag): fingerprint t0 + g t1 + g^2 t2 + g^3 t3 + g^4 tag
+constexpr int TAG_T1 = 0, TAG_T2 = 1, TAG_BYTE = 2, TAG_WORD = 3;
 VX_HD constexpr int GC(int k, int slot, int j) { return (k * 9 + slot) * 8 + j; }
 VX_HD constexpr int CAR(int k, int q) { return CAR0 + 4 * k + q; }
 VX_HD constexpr int MS(int s, int h) { return MS0 + 2 * s + h; }
@@ -75,11 +84,11 @@ VX_HD F limb4(const F& b0, const F& b1, const F& b2, const F& b3) {
 }  // namespace blk
 
 struct BlakeAir {
-    static constexpr int ID = 6, COLS = blk::COLS, PUB = 18, PERIODIC = 20, PERIOD_LOG = 16, QUOT_ROWS_PER_LANE = 1, AUX = blk::AUX, CHAL = 4, AUXPUB = 0;
+    static constexpr int ID = 6, COLS = blk::COLS, PUB = 20, PERIODIC = 20, PERIOD_LOG = 16, QUOT_ROWS_PER_LANE = 1, AUX = blk::AUX, CHAL = 4, AUXPUB = 1;
     static constexpr int plog(int q) { return q < 16 ? 4 : 16; }
 
     template <class F, class Row, class C>
-    __host__ __device__ static void eval(const Row& loc, const Row& nxt, const F* per, const F* pub, const F* chal, const F*, C& c) {
+    __host__ __device__ static void eval(const Row& loc, const Row& nxt, const F* per, const F* pub, const F* chal, const F* apub, C& c) {
         using namespace blk;
         const F* sel = per;
         const F one = F::from(1), two = F::from(2), two32 = F::from(1ULL << 32), inv32 = F::from(0xFFFFFFFE00000002ULL);  // 2^-32 mod p
@@ -310,6 +319,10 @@ struct BlakeAir {
             c.constraint(loc[IB0 + 7] * (loc[INC] - c128));
             c.constraint((one - fin) * (loc[INC] - c128));
         }
+        // ---- 7b. message size register: constant across the chunks of a message, equal to the byte counter at its end
+        c.constraint(in_blk * (nxt[SZ] - loc[SZ]));
+        c.constraint(sel[15] * (one - fin) * (nxt[SZ] - loc[SZ]));
+        c.constraint(fin * (loc[SZ] - loc[T]));
         // ---- 8. digest register
         const F cap = loc[CAP];
 #pragma unroll 1
@@ -361,13 +374,41 @@ struct BlakeAir {
                 c.constraint_x2(h * du * dv - (du + dv));
                 hsum = hsum + h;
             }
+            // ---- bus sends of the next row.  Data root: byte b of its natural message word under the flag E[b], tuple
+            // (leaf, k, byte) with k = position - (size - 32); rows are numbered by the LOCAL row's selectors.
+            {
+                F r8n = sel[0] * F::from(8);
+                for (int r = 1; r < 15; ++r) r8n = r8n + sel[r] * F::from(8 * (r + 1));
+                const F leaf = nxt[NUM] - pub[16], bus_on = pub[19];  // bus_on = 0: a stand-alone proof, nothing on the bus
+                const F pos0 = nxt[T] - nxt[INC] + r8n - nxt[SZ] + F::from(32);
+                const X2<F> base = beta + leaf + g4 * F::from(TAG_BYTE);
+#pragma unroll 1
+                for (int pair = 0; pair < 4; ++pair) {
+                    const int e = HB0 + pair, b0 = 2 * pair, b1 = b0 + 1;
+                    const X2<F> du = base + gamma * (pos0 + F::from(b0)) + g2 * nxt[MB0 + b0], dv = base + gamma * (pos0 + F::from(b1)) + g2 * nxt[MB0 + b1];
+                    const X2<F> h{nxt[AX(e, 0)], nxt[AX(e, 1)]};
+                    c.constraint_x2(h * du * dv - dv * (nxt[E0 + b0] * bus_on) - du * (nxt[E0 + b1] * bus_on));
+                    hsum = hsum + h;
+                }
+                // state root: big-endian words of bytes 0..3 (rows 5..8 -> words 1, 3, 5, 7) and 4..7 (rows 4..7 -> words 0, 2, 4, 6) of
+                // a first chunk, tuple (tree 0, node id N + leaf, j, word)
+                const F su = sel[4] + sel[5] + sel[6] + sel[7], ju = sel[4] + sel[5] * F::from(3) + sel[6] * F::from(5) + sel[7] * F::from(7);
+                const F sv = sel[3] + sel[4] + sel[5] + sel[6], jv = sel[4] * two + sel[5] * F::from(4) + sel[6] * F::from(6);
+                const F wu = limb4(nxt[MB0 + 3], nxt[MB0 + 2], nxt[MB0 + 1], nxt[MB0 + 0]), wv = limb4(nxt[MB0 + 7], nxt[MB0 + 6], nxt[MB0 + 5], nxt[MB0 + 4]);
+                const X2<F> wbase = beta + gamma * (leaf + pub[18]) + g4 * F::from(TAG_WORD);
+                const X2<F> du = wbase + g2 * ju + g3 * wu, dv = wbase + g2 * jv + g3 * wv;
+                const X2<F> h{nxt[AX(HS, 0)], nxt[AX(HS, 1)]};
+                const F fa = nxt[FA] * bus_on;
+                c.constraint_x2(h * du * dv - dv * (fa * su) - du * (fa * sv));
+                hsum = hsum + h;
+            }
             const F ta = per[16], tb_ = per[17], tl = per[18], tt = per[19];
             const X2<F> dt1 = beta + ta + gamma * tb_ + g2 * (tl + tt * F::from(128));
             const X2<F> dt2 = bt2 + ta + gamma * tb_ + g2 * tl + g3 * tt;
             const X2<F> ht{loc[AX(HT, 0)], loc[AX(HT, 1)]};
             c.constraint_x2(ht * dt1 * dt2 - dt2 * loc[M1] - dt1 * loc[M2]);
             const X2<F> z{loc[AX(ZZ, 0)], loc[AX(ZZ, 1)]}, zn{nxt[AX(ZZ, 0)], nxt[AX(ZZ, 1)]};
-            c.constraint_x2(zn - z - hsum + ht);
+            c.constraint_x2(zn - z - hsum + ht + X2<F>{apub[0], apub[1]});  // apub = (net bus total of this table) / n
         }
     }
 };

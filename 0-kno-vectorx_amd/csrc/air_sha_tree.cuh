@@ -1,0 +1,186 @@
+// ShaTreeAir (AIR ids 7 / 8 / 9 for trees of 256 / 512 / 16 leaves): the two SHA-256 Merkle roots HeaderRangeCircuit
+// outputs -- state_root_merkle_root and data_root_merkle_root (/root/reference
+// circuits/builder/subchain_verification.rs:213-220 for the 8-leaf subtrees of a map job, :268-274 for the reduce
+// nodes; native mirror circuits/input/mod.rs:464-528: unhashed 32-byte leaves, node = SHA256(l || r), zero leaves beyond
+// the range).  The reference spreads the tree over 2J-1 recursive proofs; here it is ONE table whose leaves arrive from
+// the Blake2b AIR (air_blake.cuh) over a logUp bus, so the roots are bound to the very header bytes that were hashed.
+// A node takes 128 rows: the DATA compression of l || r (start state IV) and the constant PAD compression of a 64-byte
+// message; node g of tree t sits at rows 128 (t N + g) in heap numbering (1 = root, children 2g / 2g+1, leaves N..2N-1,
+// slot 0 a dummy).  Compression rows and column layout are ShaChainAir's (air_sha.cuh); everything positional is a
+// PERIODIC column; the only other witness is the pair of leaf-enable flags ENL / ENR of a bottom-level node (a disabled
+// leaf must be zero and takes nothing from the bus).  Row r < 16 of a DATA block receives message word r:
+//   inner nodes and the bottom level of tree 0:  (tree, child id, r mod 8, word, TAG_WORD)
+//   bottom level of tree 1 (data roots):         (leaf, 4 (r mod 8) + q, byte q of the word, TAG_BYTE), q = 0..3
+// and row 63 of a PAD block sends the node's digest (tree, g, j, word_j), except for the root: its digest is public.
+// Constraint ORDER is protocol: oracle/sha_tree_air.py restates it independently.
+#pragma once
+#include <vector>
+
+#include "air_blake.cuh"
+#include "air_sha.cuh"
+
+namespace sht {
+constexpr int ENL = shc::DG0, ENR = shc::DG0 + 1, COLS = shc::COLS, AUX = 16, N_PERIODIC = 16;
+enum { P_SEL0, P_SEL63, P_SCHED, P_K, P_DATA, P_TREE, P_PWA, P_PWL, P_PWR, P_PBL, P_PBR, P_CID, P_JJ, P_PS, P_ROOT, P_GID };
+}  // namespace sht
+
+template <int LOGN, int ID_>
+struct ShaTreeAirT {
+    static constexpr int ID = ID_, COLS = sht::COLS, PUB = 16, PERIODIC = sht::N_PERIODIC, PERIOD_LOG = 8 + LOGN, QUOT_ROWS_PER_LANE = 1, AUX = sht::AUX, CHAL = 4, AUXPUB = 1;
+    static constexpr int TREE_SIZE = 1 << LOGN;
+    static constexpr int plog(int q) { return q < 4 ? 6 : (q == 4 ? 7 : 8 + LOGN); }
+
+    // one period of every periodic column, back to back (host)
+    static void periodic_values(std::vector<uint64_t>& v) {
+        using namespace sht;
+        const size_t N = TREE_SIZE, n = 256 * N;
+        v.assign(4 * 64 + 128 + 11 * n, 0);
+        uint64_t* p = v.data();
+        p[0] = 1, p[64 + 63] = 1;
+        for (int r = 0; r <= 47; ++r) p[128 + r] = 1;
+        for (int r = 0; r < 64; ++r) p[192 + r] = shc::K_H[r];
+        for (int r = 0; r < 64; ++r) p[256 + r] = 1;
+        uint64_t* q = p + 384;  // columns P_TREE .. P_GID, n values each
+        for (size_t row = 0; row < n; ++row) {
+            const size_t r = row & 63, blk = (row >> 6) & 1, pair = row >> 7, tree = pair / N, g = pair % N;
+            const bool msg = blk == 0 && r < 16, left = msg && r < 8, right = msg && r >= 8, bottom = g >= N / 2, inner = g >= 1 && g < N / 2;
+            const size_t c = r >= 8 ? 1 : 0;
+            const bool send = blk == 1 && r == 63;
+            q[(P_TREE - 5) * n + row] = tree;
+            q[(P_PWA - 5) * n + row] = msg && inner;
+            q[(P_PWL - 5) * n + row] = left && bottom && tree == 0;
+            q[(P_PWR - 5) * n + row] = right && bottom && tree == 0;
+            q[(P_PBL - 5) * n + row] = left && bottom && tree == 1;
+            q[(P_PBR - 5) * n + row] = right && bottom && tree == 1;
+            q[(P_CID - 5) * n + row] = msg ? ((bottom && tree == 1) ? 2 * g - N + c : 2 * g + c) : 0;
+            q[(P_JJ - 5) * n + row] = msg ? (r & 7) : 0;
+            q[(P_PS - 5) * n + row] = send && g >= 2;
+            q[(P_ROOT - 5) * n + row] = send && g == 1;
+            q[(P_GID - 5) * n + row] = send ? g : 0;
+        }
+    }
+
+    template <class F, class Row, class C>
+    __host__ __device__ static void eval(const Row& loc, const Row& nxt, const F* per, const F* pub, const F* chal, const F* apub, C& c) {
+        using namespace shc;
+        using namespace sht;
+        const F sel0 = per[P_SEL0], sel63 = per[P_SEL63], sched_on = per[P_SCHED], kr = per[P_K], is_data = per[P_DATA];
+        const F one = F::from(1), two = F::from(2), two32 = F::from(1ULL << 32);
+        const F in_block = one - sel63;
+        auto val = [&](const Row& row, int col0, int nb) -> F {
+            F acc = row[col0 + nb - 1];
+#pragma unroll 1
+            for (int i = nb - 2; i >= 0; --i) acc = acc + acc + row[col0 + i];
+            return acc;
+        };
+        // ---- 1. booleans
+#pragma unroll 1
+        for (int col = 0; col < HIN0; ++col) {
+            const F x = loc[col];
+            c.constraint(x * (x - one));
+        }
+        // ---- 2. three-input XORs: x + y + z = r + 2c
+        auto xor3 = [&](int col0, int r0, int r1, int r2, int shift, int colr, int colc) {
+#pragma unroll 1
+            for (int i = 0; i < 32; ++i) {
+                F acc = loc[col0 + ((i + r0) & 31)] + loc[col0 + ((i + r1) & 31)];
+                if (shift < 0) acc = acc + loc[col0 + ((i + r2) & 31)];
+                else if (i + shift < 32) acc = acc + loc[col0 + i + shift];
+                c.constraint(acc - loc[colr + i] - two * loc[colc + i]);
+            }
+        };
+        xor3(WW(1, 0), 7, 18, 0, 3, S0R, S0C);
+        xor3(WW(14, 0), 17, 19, 0, 10, S1R, S1C);
+        xor3(ST(4, 0), 6, 11, 25, -1, E1R, E1C);
+        xor3(ST(0, 0), 2, 13, 22, -1, A0R, A0C);
+#pragma unroll 1
+        for (int i = 0; i < 32; ++i) c.constraint(loc[ST(0, i)] + loc[ST(1, i)] + loc[ST(2, i)] - two * loc[MAJ + i] - loc[PAR + i]);
+        // ---- 3. the round
+        {
+            F ch = F::from(0);
+#pragma unroll 1
+            for (int i = 31; i >= 0; --i) {
+                const F e = loc[ST(4, i)], f = loc[ST(5, i)], g = loc[ST(6, i)];
+                ch = ch + ch + (e * f + (one - e) * g);
+            }
+            const F t1 = val(loc, ST(7, 0), 32) + val(loc, E1R, 32) + ch + kr + val(loc, WW(0, 0), 32);
+            c.constraint(val(loc, NE0, 32) + two32 * val(loc, CE0, 3) - (val(loc, ST(3, 0), 32) + t1));
+            c.constraint(val(loc, NA0, 32) + two32 * val(loc, CA0, 3) - (t1 + val(loc, A0R, 32) + val(loc, MAJ, 32)));
+        }
+        // ---- 4. state shift inside a block
+#pragma unroll 1
+        for (int i = 0; i < 32; ++i) {
+            c.constraint(in_block * (nxt[ST(0, i)] - loc[NA0 + i]));
+            c.constraint(in_block * (nxt[ST(4, i)] - loc[NE0 + i]));
+            const int wds[6] = {1, 2, 3, 5, 6, 7};
+#pragma unroll 1
+            for (int q = 0; q < 6; ++q) c.constraint(in_block * (nxt[ST(wds[q], i)] - loc[ST(wds[q] - 1, i)]));
+        }
+        // ---- 5. message schedule
+#pragma unroll 1
+        for (int j = 0; j < 15; ++j)
+#pragma unroll 1
+            for (int i = 0; i < 32; ++i) c.constraint(in_block * (nxt[WW(j, i)] - loc[WW(j + 1, i)]));
+        c.constraint(sched_on * (val(nxt, WW(15, 0), 32) + two32 * val(loc, CW0, 2) -
+                                 (val(loc, S1R, 32) + val(loc, WW(9, 0), 32) + val(loc, S0R, 32) + val(loc, WW(0, 0), 32))));
+        // ---- 6. feed-forward at r = 63
+        {
+            const int s64[8] = {NA0, ST(0, 0), ST(1, 0), ST(2, 0), NE0, ST(4, 0), ST(5, 0), ST(6, 0)};
+#pragma unroll 1
+            for (int wd = 0; wd < 8; ++wd)
+                c.constraint(sel63 * (val(loc, FFB(wd, 0), 32) + two32 * loc[FFC0 + wd] - (loc[HIN0 + wd] + val(loc, s64[wd], 32))));
+        }
+        // ---- 7. block boundary: the PAD block starts from the DATA block's output, a DATA block from IV
+#pragma unroll 1
+        for (int wd = 0; wd < 8; ++wd) {
+#pragma unroll 1
+            for (int i = 0; i < 32; ++i) {
+                const F ivb = F::from((uint64_t)((iv(wd) >> i) & 1));
+                c.constraint(sel63 * (nxt[ST(wd, i)] - (is_data * loc[FFB(wd, i)] + (one - is_data) * ivb)));
+            }
+            c.constraint(sel0 * (loc[HIN0 + wd] - val(loc, ST(wd, 0), 32)));
+            c.constraint(in_block * (nxt[HIN0 + wd] - loc[HIN0 + wd]));
+        }
+        // ---- 8. the PAD block's message, the root, zero leaves
+#pragma unroll 1
+        for (int j = 0; j < 16; ++j) c.constraint(sel0 * (one - is_data) * (val(loc, WW(j, 0), 32) - F::from(pad64(j))));
+#pragma unroll 1
+        for (int j = 0; j < 8; ++j) c.constraint(per[P_ROOT] * (val(loc, FFB(j, 0), 32) - (pub[j] + per[P_TREE] * (pub[8 + j] - pub[j]))));
+        const F w0 = val(loc, WW(0, 0), 32);
+        c.constraint((per[P_PWL] + per[P_PBL]) * (one - loc[ENL]) * w0);
+        c.constraint((per[P_PWR] + per[P_PBR]) * (one - loc[ENR]) * w0);
+        // ---- 9. the bus (logUp): 13 lookups in 7 helper elements of the local row, cyclic running sum
+        {
+            const X2<F> beta{chal[0], chal[1]}, gamma{chal[2], chal[3]}, g2 = gamma * gamma, g3 = g2 * gamma, g4 = g2 * g2;
+            const F en_l = loc[ENL], en_r = loc[ENR], zero = F::from(0);
+            const X2<F> tag_w = g4 * F::from(blk::TAG_WORD), tag_b = g4 * F::from(blk::TAG_BYTE);
+            // lookup q: 0 = word receive, 1..4 = byte receives, 5..12 = digest sends
+            auto mult = [&](int q) -> F {
+                if (q == 0) return zero - (per[P_PWA] + per[P_PWL] * en_l + per[P_PWR] * en_r);
+                if (q <= 4) return zero - (per[P_PBL] * en_l + per[P_PBR] * en_r);
+                return per[P_PS];
+            };
+            auto denom = [&](int q) -> X2<F> {
+                if (q == 0) return beta + per[P_TREE] + gamma * per[P_CID] + g2 * per[P_JJ] + g3 * w0 + tag_w;
+                if (q <= 4) return beta + per[P_CID] + gamma * (per[P_JJ] * F::from(4) + F::from((uint64_t)(q - 1))) + g2 * val(loc, WW(0, 24 - 8 * (q - 1)), 8) + tag_b;
+                return beta + per[P_TREE] + gamma * per[P_GID] + g2 * F::from((uint64_t)(q - 5)) + g3 * val(loc, FFB(q - 5, 0), 32) + tag_w;
+            };
+            X2<F> hsum{zero, zero};
+#pragma unroll 1
+            for (int e = 0; e < 7; ++e) {
+                const X2<F> h{loc[COLS + 2 * e], loc[COLS + 2 * e + 1]};
+                const X2<F> du = denom(2 * e);
+                if (e < 6) {
+                    const X2<F> dv = denom(2 * e + 1);
+                    c.constraint_x2(h * du * dv - dv * mult(2 * e) - du * mult(2 * e + 1));
+                } else c.constraint_x2(h * du - mult(2 * e));
+                hsum = hsum + h;
+            }
+            const X2<F> z{loc[COLS + 14], loc[COLS + 15]}, zn{nxt[COLS + 14], nxt[COLS + 15]};
+            c.constraint_x2(zn - z - hsum + X2<F>{apub[0], apub[1]});
+        }
+    }
+};
+using ShaTreeAir256 = ShaTreeAirT<8, 7>;
+using ShaTreeAir512 = ShaTreeAirT<9, 8>;
+using ShaTreeAir16 = ShaTreeAirT<4, 9>;

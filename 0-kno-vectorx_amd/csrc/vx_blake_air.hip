@@ -22,6 +22,7 @@ struct BlockDesc {
     uint32_t D[8];     // digest register before this block
     uint8_t fin, first, act, pad;
     uint32_t num;      // block number of the header this chunk belongs to
+    uint32_t size;     // length of the whole message (< 2^24)
 };
 
 __device__ __forceinline__ uint64_t b_rotr(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(64) void k_blake_chain(const uint8_t* msgs, size_t 
 // Packed words: 8 per G (A1 D1 C1 B1 A2 D2 C2 X; L / T are the low 7 bits / top bit of X's bytes), then
 constexpr int SW_CAR = 64, SW_MS = 65, SW_MB = 81, SW_HL = 82, SW_D = 90, SW_FLAGS = 94, SW_TN = 95, N_STAGE = 96;
 // SW_CAR: 32 carries x 2 bits; SW_MS: the 16 message words in this row's order; SW_D: 4 words of two limbs;
-// SW_FLAGS: ACT FIN FIRST CAP FA (bits 0..4), INC (8..15), CNT (16..23), MK (24..31); SW_TN: T (low half), NUM (high half)
+// SW_FLAGS: ACT FIN FIRST CAP FA (bits 0..4), INC (8..15), CNT (16..23), MK (24..31), E (32..39), SZ (40..63); SW_TN: T (low half), NUM (high half)
 struct ExpandEntry {
     uint16_t col;
     uint8_t shift, bits;
@@ -207,8 +208,14 @@ __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const 
     uint64_t mk = 0;
     for (int bq = 0; bq < 8; ++bq) mk |= (uint64_t)((uint32_t)(8 * r + bq) < d.inc ? 1 : 0) << bq;
     const uint64_t cnt = d.inc < (uint32_t)(8 * (r + 1)) ? d.inc : (uint32_t)(8 * (r + 1));
+    // E[b]: byte 8r + b of this chunk lies in the last 32 bytes of an active message (the data root, decoder.rs:132-149)
+    uint64_t eb = 0;
+    for (int bq = 0; bq < 8; ++bq) {
+        const uint32_t pos = d.t - d.inc + 8 * r + bq;
+        eb |= (uint64_t)((d.act && pos + 32 >= d.size && pos < d.size) ? 1 : 0) << bq;
+    }
     st(SW_FLAGS) = (uint64_t)d.act | ((uint64_t)d.fin << 1) | ((uint64_t)d.first << 2) | ((uint64_t)(cap ? 1 : 0) << 3) | ((uint64_t)((d.first && d.act) ? 1 : 0) << 4) |
-                   ((uint64_t)d.inc << 8) | (cnt << 16) | (mk << 24);
+                   ((uint64_t)d.inc << 8) | (cnt << 16) | (mk << 24) | (eb << 32) | ((uint64_t)d.size << 40);
     st(SW_TN) = (uint64_t)d.t | ((uint64_t)d.num << 32);
     __syncthreads();
     rc_part[(size_t)blockIdx.x * 256 + threadIdx.x] = rc_lds[threadIdx.x];
@@ -252,7 +259,8 @@ static void blake_expand_table(std::vector<ExpandEntry>& ent, std::vector<uint32
     for (int j = 0; j < 4; ++j) add(SW_D + j, D0 + 2 * j, 0, 32), add(SW_D + j, D0 + 2 * j + 1, 32, 32);
     add(SW_FLAGS, ACT, 0, 1), add(SW_FLAGS, FIN, 1, 1), add(SW_FLAGS, FIRST, 2, 1), add(SW_FLAGS, CAP, 3, 1), add(SW_FLAGS, FA, 4, 1);
     add(SW_FLAGS, INC, 8, 8), add(SW_FLAGS, CNT, 16, 8);
-    for (int i = 0; i < 8; ++i) add(SW_FLAGS, IB0 + i, 8 + i, 1), add(SW_FLAGS, MK0 + i, 24 + i, 1);
+    for (int i = 0; i < 8; ++i) add(SW_FLAGS, IB0 + i, 8 + i, 1), add(SW_FLAGS, MK0 + i, 24 + i, 1), add(SW_FLAGS, E0 + i, 32 + i, 1);
+    add(SW_FLAGS, SZ, 40, 24);
     add(SW_TN, T, 0, 32), add(SW_TN, NUM, 32, 32);
     for (int i = 0; i < 32; ++i) add(SW_TN, TB0 + i, i, 1);
     off.assign(1, 0);
@@ -284,6 +292,7 @@ struct AuxArgs {
     uint64_t* part;  // [9][2][n]
     size_t n;
     gl2 beta, gamma;
+    uint64_t first_number, tree_size, bus_on;  // public inputs 16, 18, 19: leaf = NUM - first, node id = tree_size + leaf
 };
 __global__ __launch_bounds__(256) void k_blake_aux(AuxArgs a) {
     using namespace blk;
@@ -412,6 +421,42 @@ __global__ __launch_bounds__(256) void k_blake_aux(AuxArgs a) {
             p[q] = gl2_mul(du, dv), s[q] = gl2_add(du, dv);
         }
         four(p, s, HM0);
+        // bus sends of this row (it is the "next" row of its pair; r = its index in the block).  Data root: byte b under E[b].
+        {
+            const gl2 g3 = gl2_mul(g2, gamma), g4 = gl2_mul(g2, g2);
+            const int r = (int)(i & 15);
+            const uint64_t leaf = gl_sub(N(NUM), a.first_number);
+            const uint64_t pos0 = gl_add(gl_sub(gl_add(gl_sub(N(T), N(INC)), (uint64_t)(8 * r)), N(SZ)), 32);
+            const gl2 bbase = gl2_add(beta, gl2_add(gl2{leaf, 0}, gl2_scale(g4, TAG_BYTE)));
+#pragma unroll 1
+            for (int pair = 0; pair < 4; ++pair) {
+                gl2 h{0, 0};
+                const uint64_t e0 = a.bus_on ? N(E0 + 2 * pair) : 0, e1 = a.bus_on ? N(E0 + 2 * pair + 1) : 0;
+                if (e0 | e1) {
+                    const gl2 du = gl2_add(bbase, gl2_add(gl2_scale(gamma, gl_add(pos0, 2 * pair)), gl2_scale(g2, N(MB0 + 2 * pair))));
+                    const gl2 dv = gl2_add(bbase, gl2_add(gl2_scale(gamma, gl_add(pos0, 2 * pair + 1)), gl2_scale(g2, N(MB0 + 2 * pair + 1))));
+                    h = gl2_mul(gl2_add(gl2_scale(dv, e0), gl2_scale(du, e1)), gl2_inv(gl2_mul(du, dv)));
+                }
+                store(HB0 + pair, h);
+                hsum = gl2_add(hsum, h);
+            }
+            // state root words: rows 5..8 send bytes 0..3 (words 1, 3, 5, 7), rows 4..7 send bytes 4..7 (words 0, 2, 4, 6) of a first chunk
+            gl2 h{0, 0};
+            const uint64_t fa = a.bus_on ? N(FA) : 0;
+            const bool su = r >= 5 && r <= 8, sv = r >= 4 && r <= 7;
+            if (fa && (su || sv)) {
+                const uint64_t node = gl_add(leaf, a.tree_size);
+                const gl2 wbase = gl2_add(beta, gl2_add(gl2_scale(gamma, node), gl2_scale(g4, TAG_WORD)));
+                const uint64_t wu = (N(MB0) << 24) | (N(MB0 + 1) << 16) | (N(MB0 + 2) << 8) | N(MB0 + 3);
+                const uint64_t wv = (N(MB0 + 4) << 24) | (N(MB0 + 5) << 16) | (N(MB0 + 6) << 8) | N(MB0 + 7);
+                const uint64_t ju = su ? (uint64_t)(2 * (r - 5) + 1) : 0, jv = sv ? (uint64_t)(2 * (r - 4)) : 0;
+                const gl2 du = gl2_add(wbase, gl2_add(gl2_scale(g2, ju), gl2_scale(g3, wu))), dv = gl2_add(wbase, gl2_add(gl2_scale(g2, jv), gl2_scale(g3, wv)));
+                const gl2 num = gl2_add(gl2_scale(dv, su ? fa : 0), gl2_scale(du, sv ? fa : 0));
+                h = gl2_mul(num, gl2_inv(gl2_mul(du, dv)));
+            }
+            store(HS, h);
+            hsum = gl2_add(hsum, h);
+        }
         // table helper of this row: ht = M1 / D_t1 + M2 / D_t2
         const uint64_t m1 = N(M1), m2 = N(M2);
         gl2 ht{0, 0};
@@ -440,25 +485,43 @@ __global__ __launch_bounds__(256) void k_blake_aux_z(const uint64_t* part, uint6
     aux[(size_t)(2 * ZZ + 1) * n + ip] = gl_sub(sb, aux[(size_t)(2 * HT + 1) * n + ip]);
 }
 
-int32_t vx_blake_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, uint64_t* aux, uint64_t* aux_pub) {
-    (void)aux_pub;
+// Z(i) = (exclusive prefix sum of the increments)(i) - i * S / n: with the published S / n subtracted from every increment
+// the running sum closes cyclically
+__global__ __launch_bounds__(256) void k_bus_close(uint64_t* za, uint64_t* zb, size_t n, uint64_t spa, uint64_t spb) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    za[i] = gl_sub(za[i], gl_mul(spa, (uint64_t)i));
+    zb[i] = gl_sub(zb[i], gl_mul(spb, (uint64_t)i));
+}
+int32_t vx_bus_close_dev(vx_ctx* ctx, uint64_t* z_cols, int log_n, uint64_t aux_pub[2]) {
+    const size_t n = (size_t)1 << log_n;
+    uint64_t tot[2];
+    VX_TRY(vx_scan_cols_dev(ctx, z_cols, log_n, 2, tot));
+    const uint64_t ninv = glh::inv(n % glh::P);
+    aux_pub[0] = glh::mul(tot[0], ninv), aux_pub[1] = glh::mul(tot[1], ninv);
+    hipLaunchKernelGGL(k_bus_close, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, z_cols, z_cols + n, n, aux_pub[0], aux_pub[1]);
+    VX_HIP(hipGetLastError());
+    return VX_OK;
+}
+
+int32_t vx_blake_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub) {
     const size_t n = (size_t)1 << log_n;
     uint64_t* part = (uint64_t*)vx_pool_alloc(ctx, 18 * n * 8);
     if (!part) return vx_fail(ctx, VX_ERR_OOM, "blake aux: out of device memory");
-    AuxArgs a{trace, aux, part, n, gl2{chal[0], chal[1]}, gl2{chal[2], chal[3]}};
+    AuxArgs a{trace, aux, part, n, gl2{chal[0], chal[1]}, gl2{chal[2], chal[3]}, pub[16], pub[18], pub[19]};
     hipLaunchKernelGGL(k_blake_aux, dim3((unsigned)((n + 255) / 256), 9), dim3(256), 0, ctx->stream, a);
     hipLaunchKernelGGL(k_blake_aux_z, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint64_t*)part, aux, n);
     const hipError_t e = hipGetLastError();
     vx_pool_free(ctx, part);  // recycled only by later work on the same stream
     if (e != hipSuccess) return vx_fail(ctx, VX_ERR_DEVICE, "blake aux: %s", hipGetErrorString(e));
-    return vx_scan_cols_dev(ctx, aux + (size_t)(2 * blk::ZZ) * n, log_n, 2, nullptr);
+    return vx_bus_close_dev(ctx, aux + (size_t)(2 * blk::ZZ) * n, log_n, aux_pub);
 }
 
 extern "C" {
 
 int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_headers,
-                             const uint8_t trusted_hash[32], uint32_t first_block_number, int log_n, vx_buf* trace_out,
-                             uint64_t public_inputs_out[18], uint8_t* digests_out) {
+                             const uint8_t trusted_hash[32], uint32_t first_block_number, uint32_t tree_size, int log_n, vx_buf* trace_out,
+                             uint64_t public_inputs_out[20], uint8_t* digests_out) {
     if (!ctx || !headers || !sizes || !trusted_hash || !trace_out || !public_inputs_out) return VX_ERR_ARG;
     VX_CHECK(stride % 128 == 0 && stride > 0, "blake trace: stride %zu must be a positive multiple of 128", stride);
     VX_CHECK(n_headers >= 1 && n_headers * stride <= headers->n * 8, "blake trace: headers exceed the buffer");
@@ -470,7 +533,7 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
     std::vector<uint32_t> base(n_headers);
     size_t n_real = 0;
     for (size_t i = 0; i < n_headers; ++i) {
-        VX_CHECK(sizes[i] <= stride && sizes[i] >= 36, "blake trace: header %zu has size %u", i, sizes[i]);
+        VX_CHECK(sizes[i] <= stride && sizes[i] >= 36 && sizes[i] < (1u << 24), "blake trace: header %zu has size %u", i, sizes[i]);
         base[i] = (uint32_t)n_real;
         n_real += (sizes[i] + 127) / 128;
     }
@@ -522,6 +585,7 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
             d.t = d.fin ? sizes[i] : 128 * (cidx + 1);
             d.msg_off = i * stride + 128 * (size_t)cidx;
             d.num = first_block_number + (uint32_t)i;
+            d.size = sizes[i];
             memcpy(d.D, D, 32);
         }
         memcpy(D, dig.data() + 32 * i, 32);
@@ -531,7 +595,7 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
         memset(&d, 0, sizeof d);
         d.fin = d.first = 1;
         d.act = 0;
-        d.inc = d.t = 36;
+        d.inc = d.t = d.size = 36;
         d.msg_off = ~0ULL;
         d.num = first_block_number + (uint32_t)n_headers - 1;
         memcpy(d.D, D, 32);
@@ -556,12 +620,14 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
     }
     public_inputs_out[16] = first_block_number;
     public_inputs_out[17] = first_block_number + (uint64_t)n_headers - 1;
+    public_inputs_out[18] = tree_size;
+    public_inputs_out[19] = tree_size ? 1 : 0;  // bus flag: the state / data roots go to a Merkle AIR of that many leaves
     if (digests_out) memcpy(digests_out, dig.data(), dig.size());
     return VX_OK;
 }
 
-static const uint64_t VX_HR_MAGIC = 0x3345474e41525248ULL;  // "HRRANGE3"
-static const size_t VX_HR_HDR = 18;  // magic, max_headers, trusted, target, out96 (12), len(blake proof), len(sha proof)
+static const uint64_t VX_HR_MAGIC = 0x3445474e41525248ULL;  // "HRRANGE4"
+static const size_t VX_HR_HDR = 19;  // magic, max_headers, trusted, target, out96 (12), len(blake proof), len(sha-chain proof), len(Merkle proof)
 
 static int sha_log_n(size_t n_keys) {
     int log_n = 6;
@@ -569,14 +635,22 @@ static int sha_log_n(size_t n_keys) {
     return log_n;
 }
 
+static int tree_air_id(uint32_t max_headers) { return max_headers == 256 ? 7 : max_headers == 512 ? 8 : max_headers == 16 ? 9 : 0; }
+static int tree_log_n(uint32_t max_headers) {
+    int l = 8;
+    while ((1u << (l - 8)) < max_headers) ++l;
+    return l;
+}
+
 int32_t vx_header_range_proof_bound(const vx_stark_config* cfg, size_t n_chunks, size_t n_authorities, size_t* n_words) {
     if (!cfg || !n_words || n_chunks == 0) return VX_ERR_ARG;
     int log_n = blk::TABLE_LOG;
     while (((size_t)1 << log_n) < 16 * n_chunks) ++log_n;
-    size_t w1 = 0, w2 = 0;
+    size_t w1 = 0, w2 = 0, w3 = 0;
     int32_t rc = vx_stark_proof_bound(VX_AIR_BLAKE_CHAIN, cfg, log_n, &w1);
     if (rc == VX_OK && n_authorities) rc = vx_stark_proof_bound(VX_AIR_SHA_CHAIN, cfg, sha_log_n(n_authorities), &w2);
-    *n_words = w1 + w2 + VX_HR_HDR;
+    if (rc == VX_OK) rc = vx_stark_proof_bound(8, cfg, tree_log_n(512), &w3);  // the largest Merkle AIR (the request's max_headers is not known here)
+    *n_words = w1 + w2 + w3 + VX_HR_HDR;
     return rc;
 }
 
@@ -626,43 +700,104 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
             side = nullptr;
         }
     }
-    // 2. Blake2b parent-hash-chain STARK over every compression of every header
+    // 2. Blake2b parent-hash-chain STARK over every compression of every header, and -- on the same logUp bus, under
+    //    shared lookup challenges -- the SHA-256 Merkle AIR that turns the state / data roots of those very header bytes
+    //    (decoder.rs:121-149) into the two output roots (subchain_verification.rs:213-220, 268-274)
+    const int tree_id = tree_air_id(max_headers);
+    VX_CHECK(tree_id, "header_range: max_headers %u has no Merkle AIR (16, 256 or 512)", max_headers);
     size_t chunks = 0;
     for (size_t i = 0; i < n_fetched; ++i) chunks += (sizes[i] + 127) / 128;
     int log_n = blk::TABLE_LOG;  // at least one copy of the lookup tables
     while (((size_t)1 << log_n) < 16 * chunks) ++log_n;
-    vx_buf* trace = nullptr;
-    int32_t rc = vx_alloc(ctx, ((size_t)blk::COLS) << log_n, &trace);
-    uint64_t pub[18];
-    if (rc == VX_OK) rc = vx_blake_chain_trace(ctx, headers, stride, sizes, n_fetched, trusted_hash, trusted_block + 1, log_n, trace, pub, nullptr);
+    const int tl = tree_log_n(max_headers);
+    // the leaves: decode_header on the GPU (all four compact modes natively; the AIR covers mode 2)
+    std::vector<uint32_t> numbers(n_fetched);
+    std::vector<uint8_t> modes(n_fetched), oks(n_fetched), parents(32 * n_fetched), sroots(32 * n_fetched), droots(32 * n_fetched);
+    int32_t rc = vx_decode_header_batch(ctx, headers, stride, sizes, n_fetched, numbers.data(), modes.data(), oks.data(), parents.data(), sroots.data(), droots.data());
+    vx_buf *trace = nullptr, *ttrace = nullptr;
+    if (rc == VX_OK) rc = vx_alloc(ctx, ((size_t)blk::COLS) << log_n, &trace);
+    if (rc == VX_OK) rc = vx_alloc(ctx, ((size_t)VX_SHA_AIR_COLS) << tl, &ttrace);
+    uint64_t pub[20], tpub[16];
+    if (rc == VX_OK) rc = vx_blake_chain_trace(ctx, headers, stride, sizes, n_fetched, trusted_hash, trusted_block + 1, max_headers, log_n, trace, pub, nullptr);
+    if (rc == VX_OK) rc = vx_sha_tree_trace_dev(ctx, sroots.data(), droots.data(), n_fetched, tl - 8, ttrace->d, tpub);
     if (rc == VX_OK) {
-        uint8_t tgt[32];
+        uint8_t tgt[32], roots[64];
         for (int j = 0; j < 8; ++j) {
             uint32_t l = (uint32_t)pub[8 + j];
             memcpy(tgt + 4 * j, &l, 4);
         }
+        for (int j = 0; j < 16; ++j)
+            for (int b = 0; b < 4; ++b) roots[4 * j + b] = (uint8_t)(tpub[j] >> (24 - 8 * b));
         if (memcmp(tgt, out96, 32) != 0) rc = vx_fail(ctx, VX_ERR_STATEMENT, "header_range: chain digest differs from the subchain target hash");
+        else if (memcmp(roots, out96 + 32, 64) != 0) rc = vx_fail(ctx, VX_ERR_STATEMENT, "header_range: Merkle AIR roots differ from the subchain roots");
     }
+    // The hash-chain prover stops after its trace cap and asks for the shared challenges: that is where the Merkle table
+    // is proven (its own trace cap is the other half of the challenge transcript).
+    struct Shared {
+        vx_ctx* ctx;
+        const vx_stark_config* cfg;
+        int tree_id, tl;
+        vx_buf* ttrace;
+        const uint64_t* tpub;
+        const uint64_t *pub_a, *cap_a;
+        size_t n_pub_a;
+        uint64_t chal[4];
+        std::vector<uint64_t> tree_proof;
+        size_t len3;
+        int32_t rc;
+    } sh{ctx, cfg, tree_id, tl, ttrace, tpub, nullptr, nullptr, 0, {0, 0, 0, 0}, {}, 0, VX_OK};
+    const vx_chal_hook hook_b{[](void* u, const uint64_t* pub_b, size_t n_pub_b, const uint64_t* cap_b, size_t cap_words, uint64_t* chal, size_t n_chal) -> int32_t {
+                                  Shared* s = (Shared*)u;
+                                  vx_shared_challenges(s->pub_a, s->n_pub_a, s->cap_a, pub_b, n_pub_b, cap_b, cap_words, s->chal, 4);
+                                  for (size_t q = 0; q < n_chal && q < 4; ++q) chal[q] = s->chal[q];
+                                  return VX_OK;
+                              },
+                              &sh};
+    struct HookA {
+        Shared* s;
+        const vx_chal_hook* hb;
+    } ha{&sh, &hook_b};
+    const vx_chal_hook hook_a{[](void* u, const uint64_t* pub_a, size_t n_pub_a, const uint64_t* cap_a, size_t, uint64_t* chal, size_t n_chal) -> int32_t {
+                                  HookA* h = (HookA*)u;
+                                  Shared* s = h->s;
+                                  s->pub_a = pub_a, s->n_pub_a = n_pub_a, s->cap_a = cap_a;
+                                  size_t bound = 0;
+                                  int32_t r = vx_stark_proof_bound(s->tree_id, s->cfg, s->tl, &bound);
+                                  if (r != VX_OK) return r;
+                                  s->tree_proof.resize(bound);
+                                  r = vx_stark_prove_impl(s->ctx, s->tree_id, s->cfg, s->ttrace->d, s->ttrace->n, /*consume_trace=*/0, s->tl, s->tpub, 16,
+                                                          s->tree_proof.data(), s->tree_proof.size(), &s->len3, h->hb);
+                                  if (r != VX_OK) return r;
+                                  for (size_t q = 0; q < n_chal && q < 4; ++q) chal[q] = s->chal[q];
+                                  return VX_OK;
+                              },
+                              &ha};
     if (rc == VX_OK)
-        rc = vx_stark_prove_impl(ctx, VX_AIR_BLAKE_CHAIN, cfg, trace->d, trace->n, /*consume_trace=*/1, log_n, pub, 18, room ? proof_out + VX_HR_HDR : nullptr, room ? proof_cap - VX_HR_HDR : 0, &len1);
+        rc = vx_stark_prove_impl(ctx, VX_AIR_BLAKE_CHAIN, cfg, trace->d, trace->n, /*consume_trace=*/1, log_n, pub, 20, room ? proof_out + VX_HR_HDR : nullptr,
+                                 room ? proof_cap - VX_HR_HDR : 0, &len1, &hook_a);
     if (trace) (void)vx_free(ctx, trace);
+    if (ttrace) (void)vx_free(ctx, ttrace);
+    const size_t len3 = sh.len3;
     if (sha_thread.joinable()) sha_thread.join();
     else if (just) rc_sha = prove_sha(ctx);  // no side context: one after the other
     if (just) {
         if (rc_sha != VX_OK && side) (void)vx_fail(ctx, rc_sha, "%s", vx_last_error(side));
         if ((rc == VX_OK || rc == VX_ERR_BUFSZ) && rc_sha != VX_OK) rc = rc_sha;
-        if (rc == VX_OK) {
-            if (proof_out && proof_cap >= VX_HR_HDR + len1 + len2) memcpy(proof_out + VX_HR_HDR + len1, sha_proof.data(), len2 * 8);
-            else rc = vx_fail(ctx, VX_ERR_BUFSZ, "header_range: proof needs %zu words, buffer has %zu", VX_HR_HDR + len1 + len2, proof_cap);
-        }
     }
-    *proof_len = VX_HR_HDR + len1 + len2;
+    *proof_len = VX_HR_HDR + len1 + len2 + len3;
+    if (rc == VX_OK) {
+        if (proof_out && proof_cap >= *proof_len) {
+            if (len2) memcpy(proof_out + VX_HR_HDR + len1, sha_proof.data(), len2 * 8);
+            memcpy(proof_out + VX_HR_HDR + len1 + len2, sh.tree_proof.data(), len3 * 8);
+        } else rc = vx_fail(ctx, VX_ERR_BUFSZ, "header_range: proof needs %zu words, buffer has %zu", *proof_len, proof_cap);
+    }
     if (rc != VX_OK) return rc;
     proof_out[0] = VX_HR_MAGIC;
     proof_out[1] = max_headers;
     proof_out[2] = trusted_block;
     proof_out[3] = target_block;
     memcpy(proof_out + 4, out96, 96);
+    proof_out[18] = len3;
     proof_out[16] = len1;
     proof_out[17] = len2;
     return VX_OK;

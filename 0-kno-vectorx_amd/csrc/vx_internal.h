@@ -125,12 +125,32 @@ struct Tw2 {
 };
 int32_t vx_get_tw2(vx_ctx* ctx, int log_s, int inverse, Tw2* out);
 int32_t vx_lde_consume_dev(vx_ctx* ctx, uint64_t* values, int log_n, size_t n_cols, int rate_bits, uint64_t shift, uint64_t* dst);
+// Called by the prover once the trace cap of an AIR with an auxiliary round is known; fills `chal` (n_chal values) with
+// lookup challenges that depend on EVERY table sharing the bus (typically by proving the other table from inside).
+struct vx_chal_hook {
+    int32_t (*fn)(void* user, const uint64_t* pub, size_t n_pub, const uint64_t* cap, size_t cap_words, uint64_t* chal, size_t n_chal);
+    void* user;
+};
 int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg, uint64_t* trace_d, size_t trace_len, int consume_trace,
                             int log_n, const uint64_t* public_inputs, size_t n_public, uint64_t* proof_out, size_t proof_cap,
-                            size_t* proof_len);
+                            size_t* proof_len, const vx_chal_hook* hook = nullptr);
+void vx_shared_challenges(const uint64_t* pub_a, size_t n_a, const uint64_t* cap_a, const uint64_t* pub_b, size_t n_b, const uint64_t* cap_b,
+                          size_t cap_words, uint64_t* out, size_t n_out);
+// verifier with externally derived lookup challenges (nullptr = drawn from the proof's own transcript); apub_out (optional)
+// receives a pointer to the values published with the auxiliary cap, and log_n_out the degree bits
+int32_t vx_stark_verify_ext(const vx_stark_config* cfg, const uint64_t* proof, size_t proof_len, int expect_air, const uint64_t* expect_public,
+                            size_t n_expect_public, const uint64_t* ext_chal, const uint64_t** apub_out, int* log_n_out, char* err, size_t errlen);
+// (public inputs, trace cap) of a serialised proof, for deriving shared challenges; false if the proof is too short
+bool vx_stark_proof_peek(const uint64_t* proof, size_t len, int cap_height, const uint64_t** pub, size_t* n_pub, const uint64_t** cap);
 int32_t vx_lde_keep_dev(vx_ctx* ctx, const uint64_t* values, int log_n, size_t n_cols, int rate_bits, uint64_t shift, uint64_t* coef_brev,
                         uint64_t* dst);
 int32_t vx_scan_cols_dev(vx_ctx* ctx, uint64_t* data, int log_n, size_t n_cols, uint64_t* totals_host);
-int32_t vx_blake_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, uint64_t* aux, uint64_t* aux_pub);
-int32_t vx_lookup_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, uint64_t* aux, uint64_t* aux_pub);
+int32_t vx_blake_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub);
+int32_t vx_lookup_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub);
+int32_t vx_sha_tree_trace_dev(vx_ctx* ctx, const uint8_t* state_roots, const uint8_t* data_roots, size_t n_leaves, int log_tree, uint64_t* trace_d,
+                              uint64_t pub_out[16]);
+int32_t vx_bus_close_dev(vx_ctx* ctx, uint64_t* z_cols, int log_n, uint64_t aux_pub[2]);
+int32_t vx_sha_tree_gen_aux_16(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub);
+int32_t vx_sha_tree_gen_aux_256(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub);
+int32_t vx_sha_tree_gen_aux_512(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub);
 void vx_merkle_levels_launch(vx_ctx* ctx, uint64_t* levels, size_t n_leaves, size_t cap);

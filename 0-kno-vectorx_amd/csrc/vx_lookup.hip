@@ -108,8 +108,8 @@ __global__ __launch_bounds__(256) void k_lookup_aux(const uint64_t* tr, size_t n
     const gl2 dz = gl2_sub(h, ht);  // Z(next) - Z(this): turned into the running sum by the scan
     aux[4 * n + i] = dz.a, aux[5 * n + i] = dz.b;
 }
-int32_t vx_lookup_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, uint64_t* aux, uint64_t* aux_pub) {
-    (void)aux_pub;
+int32_t vx_lookup_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub) {
+    (void)aux_pub, (void)pub;
     const size_t n = (size_t)1 << log_n;
     hipLaunchKernelGGL(k_lookup_aux, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, trace, n, gl2{chal[0], chal[1]},
                        gl2{chal[2], chal[3]}, aux);

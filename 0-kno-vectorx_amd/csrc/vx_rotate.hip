@@ -192,8 +192,8 @@ int32_t vx_rotate_prove(vx_ctx* ctx, const vx_buf* header, uint32_t header_size,
     const int bl = blake_rows_log(chunks);
     vx_buf* trace = nullptr;
     VX_TRY(vx_alloc(ctx, ((size_t)VX_BLAKE_AIR_COLS) << bl, &trace));
-    uint64_t pub[18];
-    int32_t rc = vx_blake_chain_trace(ctx, header, MAX_HEADER_SIZE, &header_size, 1, parent, epoch_end_block_number, bl, trace, pub, header_hash);
+    uint64_t pub[20];  // tree_size 0: a stand-alone hash proof, nothing on the bus
+    int32_t rc = vx_blake_chain_trace(ctx, header, MAX_HEADER_SIZE, &header_size, 1, parent, epoch_end_block_number, 0, bl, trace, pub, header_hash);
     // 2. justification by the current set over (epoch_end_block_number, header hash) (rotate.rs:297-302)
     if (rc == VX_OK)
         rc = vx_verify_simple_justification(ctx, epoch_end_block_number, header_hash, just->authority_set_id, just->authority_set_hash,
@@ -205,7 +205,7 @@ int32_t vx_rotate_prove(vx_ctx* ctx, const vx_buf* header, uint32_t header_size,
     int32_t rc_room = VX_OK;
     auto room = [&](size_t off) { return rc_room == VX_OK && proof_out && proof_cap > off; };
     if (rc == VX_OK) {
-        rc = vx_stark_prove_impl(ctx, VX_AIR_BLAKE_CHAIN, cfg, trace->d, trace->n, 1, bl, pub, 18, room(VX_ROT_HDR) ? proof_out + VX_ROT_HDR : nullptr,
+        rc = vx_stark_prove_impl(ctx, VX_AIR_BLAKE_CHAIN, cfg, trace->d, trace->n, 1, bl, pub, 20, room(VX_ROT_HDR) ? proof_out + VX_ROT_HDR : nullptr,
                                  room(VX_ROT_HDR) ? proof_cap - VX_ROT_HDR : 0, &len[0]);
         if (rc == VX_ERR_BUFSZ) rc_room = rc, rc = VX_OK;
     }
@@ -266,7 +266,7 @@ int32_t vx_rotate_verify(const vx_stark_config* cfg, const uint64_t* blob, size_
     // Blake proof: a chain of exactly one header, numbered epoch_end_block, hashing to the blob's header hash.  The
     // anchor (first 8 public inputs) is the parent hash the header itself carries -- free in this statement.
     const uint64_t* p0 = blob + VX_ROT_HDR;
-    uint64_t pub[18];
+    uint64_t pub[20];
     for (int j = 0; j < 8; ++j) {
         uint32_t a, b;
         memcpy(&a, (const uint8_t*)(blob + 20) + 4 * j, 4);
@@ -275,7 +275,8 @@ int32_t vx_rotate_verify(const vx_stark_config* cfg, const uint64_t* blob, size_
         pub[8 + j] = b;
     }
     pub[16] = pub[17] = blob[2];
-    int32_t rc = vx_stark_verify(cfg, p0, l0, VX_AIR_BLAKE_CHAIN, pub, 18, err, errlen);
+    pub[18] = pub[19] = 0;
+    int32_t rc = vx_stark_verify(cfg, p0, l0, VX_AIR_BLAKE_CHAIN, pub, 20, err, errlen);
     if (rc != VX_OK) return rc;
     uint64_t spub[8];
     be_limbs(authority_set_hash, spub);

@@ -3,13 +3,13 @@
 // prepared (the 2n-1 compressions of the commitment chain are sequential and tiny: host).
 #include <string.h>
 
-#include "air_sha.cuh"
+#include "air_sha_tree.cuh"
 #include "vx_internal.h"
 
 struct ShaBlock {
     uint32_t h_in[8], block[16], dg[8], type, pad[3];
 };
-enum { SB_FIRST = 0, SB_DATA = 1, SB_PAD = 2, SB_IDLE = 3 };
+enum { SB_FIRST = 0, SB_DATA = 1, SB_PAD = 2, SB_IDLE = 3, SB_TREE = 4 /* ShaTreeAir: block kinds are periodic there, no type flags */ };
 
 __host__ __device__ static inline uint32_t s_rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
 static void h_compress(const uint32_t* h_in, const uint32_t* block, uint32_t* out) {
@@ -162,4 +162,120 @@ int32_t vx_sha_chain_trace(vx_ctx* ctx, const uint8_t* pubkeys, size_t n_keys, i
     }
     return VX_OK;
 }
+}
+
+// ---- ShaTreeAir: the two SHA-256 Merkle trees over state roots and data roots ------------------------------------------
+// The trees are tiny (2 (N - 1) nodes): node values on the host, then the same row kernel as the chain AIR.  Block
+// descriptor of node g of tree t: DATA block (IV, l || r) and PAD block (DATA's output, the constant second block of a
+// 64-byte message); dg[0] / dg[1] carry the leaf-enable flags ENL / ENR of a bottom-level node.
+int32_t vx_sha_tree_trace_dev(vx_ctx* ctx, const uint8_t* state_roots, const uint8_t* data_roots, size_t n_leaves, int log_tree, uint64_t* trace_d,
+                              uint64_t pub_out[16]) {
+    const size_t N = (size_t)1 << log_tree, n = 256 * N, n_blocks = n >> 6;
+    VX_CHECK(n_leaves >= 1 && n_leaves <= N, "sha tree: %zu leaves do not fit a tree of %zu", n_leaves, N);
+    std::vector<ShaBlock> blocks(n_blocks);
+    memset(blocks.data(), 0, n_blocks * sizeof(ShaBlock));
+    auto be32 = [](const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; };
+    std::vector<uint32_t> node(2 * N * 8);  // heap array of digests as big-endian words
+    for (int t = 0; t < 2; ++t) {
+        const uint8_t* leaves = t == 0 ? state_roots : data_roots;
+        std::fill(node.begin(), node.end(), 0u);
+        for (size_t i = 0; i < n_leaves; ++i)
+            for (int j = 0; j < 8; ++j) node[(N + i) * 8 + j] = be32(leaves + 32 * i + 4 * j);
+        for (size_t g = N - 1; g >= 1; --g) {
+            ShaBlock& d = blocks[2 * ((size_t)t * N + g)];
+            ShaBlock& p = blocks[2 * ((size_t)t * N + g) + 1];
+            d.type = p.type = SB_TREE;
+            for (int j = 0; j < 8; ++j) d.h_in[j] = shc::IV_H[j], d.block[j] = node[2 * g * 8 + j], d.block[8 + j] = node[(2 * g + 1) * 8 + j];
+            uint32_t mid[8];
+            h_compress(d.h_in, d.block, mid);
+            for (int j = 0; j < 8; ++j) p.h_in[j] = mid[j];
+            for (int j = 0; j < 16; ++j) p.block[j] = shc::pad64(j);
+            h_compress(p.h_in, p.block, &node[g * 8]);
+            if (g >= N / 2) d.dg[0] = p.dg[0] = 2 * g - N < n_leaves, d.dg[1] = p.dg[1] = 2 * g - N + 1 < n_leaves;
+        }
+        {  // slot 0: a dummy node (zero message), never on the bus
+            ShaBlock& d = blocks[2 * (size_t)t * N];
+            ShaBlock& p = blocks[2 * (size_t)t * N + 1];
+            d.type = p.type = SB_TREE;
+            for (int j = 0; j < 8; ++j) d.h_in[j] = shc::IV_H[j];
+            uint32_t mid[8];
+            h_compress(d.h_in, d.block, mid);
+            for (int j = 0; j < 8; ++j) p.h_in[j] = mid[j];
+            for (int j = 0; j < 16; ++j) p.block[j] = shc::pad64(j);
+        }
+        for (int j = 0; j < 8; ++j) pub_out[8 * t + j] = node[8 + j];
+    }
+    uint64_t* sc;
+    VX_TRY(vx_scratch(ctx, (n_blocks * sizeof(ShaBlock) + 7) / 8, &sc));
+    VX_HIP(hipMemcpyAsync(sc, blocks.data(), n_blocks * sizeof(ShaBlock), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_sha_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const ShaBlock*)sc, trace_d, n);
+    VX_HIP(hipGetLastError());
+    VX_HIP(hipStreamSynchronize(ctx->stream));  // blocks (host vector) must outlive the copy
+    return VX_OK;
+}
+
+// auxiliary columns of ShaTreeAir: one lane per row; the positional (periodic) quantities are recomputed from the row index
+__global__ __launch_bounds__(256) void k_sha_tree_aux(const uint64_t* tr, uint64_t* aux, size_t n, size_t N, gl2 beta, gl2 gamma) {
+    using namespace shc;
+    const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const size_t r = row & 63, bk = (row >> 6) & 1, pair = row >> 7, tree = pair / N, g = pair % N;
+    const bool msg = bk == 0 && r < 16, bottom = g >= N / 2, inner = g >= 1 && g < N / 2, send = bk == 1 && r == 63 && g >= 2;
+    const uint64_t en = msg ? tr[(size_t)(r < 8 ? sht::ENL : sht::ENR) * n + row] : 0;
+    const uint64_t m_word = msg && (inner || (bottom && tree == 0 && en)) ? 1 : 0, m_byte = msg && bottom && tree == 1 && en ? 1 : 0;
+    auto word = [&](int col0, int nb) -> uint64_t {
+        uint64_t v = 0;
+        for (int i = 0; i < nb; ++i) v |= tr[(size_t)(col0 + i) * n + row] << i;
+        return v;
+    };
+    gl2 h[7], hsum{0, 0};
+    for (int e = 0; e < 7; ++e) h[e] = gl2{0, 0};
+    if (m_word | m_byte | (send ? 1 : 0)) {
+        const gl2 g2 = gl2_mul(gamma, gamma), g3 = gl2_mul(g2, gamma), g4 = gl2_mul(g2, g2);
+        const gl2 tag_w = gl2_scale(g4, blk::TAG_WORD), tag_b = gl2_scale(g4, blk::TAG_BYTE);
+        const uint64_t c = r >= 8 ? 1 : 0, jj = r & 7, w0 = (msg ? word(WW(0, 0), 32) : 0);
+        const uint64_t cid = (bottom && tree == 1) ? 2 * g - N + c : 2 * g + c;
+        gl2 d[13];
+        uint64_t m[13];  // 1 = receive (-1), 2 = send (+1), 0 = inactive
+        d[0] = gl2_add(gl2_add(beta, gl2{(uint64_t)tree, 0}), gl2_add(gl2_add(gl2_scale(gamma, cid), gl2_scale(g2, jj)), gl2_add(gl2_scale(g3, w0), tag_w)));
+        m[0] = m_word;
+        for (int q = 0; q < 4; ++q) {
+            const uint64_t byte = (w0 >> (24 - 8 * q)) & 0xFF;
+            d[1 + q] = gl2_add(gl2_add(beta, gl2{cid, 0}), gl2_add(gl2_add(gl2_scale(gamma, 4 * jj + q), gl2_scale(g2, byte)), tag_b));
+            m[1 + q] = m_byte;
+        }
+        for (int j = 0; j < 8; ++j) {
+            const uint64_t ff = send ? word(FFB(j, 0), 32) : 0;
+            d[5 + j] = gl2_add(gl2_add(beta, gl2{(uint64_t)tree, 0}), gl2_add(gl2_add(gl2_scale(gamma, g), gl2_scale(g2, j)), gl2_add(gl2_scale(g3, ff), tag_w)));
+            m[5 + j] = send ? 2 : 0;
+        }
+        auto term = [&](int q) -> gl2 {  // m / D with m in {-1, 0, +1}
+            if (!m[q]) return gl2{0, 0};
+            const gl2 iv = gl2_inv(d[q]);
+            return m[q] == 2 ? iv : gl2{gl_neg(iv.a), gl_neg(iv.b)};
+        };
+        for (int e = 0; e < 7; ++e) {
+            h[e] = term(2 * e);
+            if (e < 6) h[e] = gl2_add(h[e], term(2 * e + 1));
+            hsum = gl2_add(hsum, h[e]);
+        }
+    }
+    for (int e = 0; e < 7; ++e) aux[(size_t)(2 * e) * n + row] = h[e].a, aux[(size_t)(2 * e + 1) * n + row] = h[e].b;
+    aux[(size_t)14 * n + row] = hsum.a, aux[(size_t)15 * n + row] = hsum.b;  // increments; the scan makes them the running sum
+}
+static int32_t sha_tree_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, size_t N, const uint64_t* chal, uint64_t* aux, uint64_t* aux_pub) {
+    const size_t n = (size_t)1 << log_n;
+    VX_CHECK(n == 256 * N, "sha tree aux: a tree of %zu leaves has %zu rows, not 2^%d", N, 256 * N, log_n);
+    hipLaunchKernelGGL(k_sha_tree_aux, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, trace, aux, n, N, gl2{chal[0], chal[1]}, gl2{chal[2], chal[3]});
+    VX_HIP(hipGetLastError());
+    return vx_bus_close_dev(ctx, aux + 14 * n, log_n, aux_pub);
+}
+int32_t vx_sha_tree_gen_aux_16(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t*, uint64_t* aux, uint64_t* aux_pub) {
+    return sha_tree_gen_aux(ctx, trace, log_n, 16, chal, aux, aux_pub);
+}
+int32_t vx_sha_tree_gen_aux_256(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t*, uint64_t* aux, uint64_t* aux_pub) {
+    return sha_tree_gen_aux(ctx, trace, log_n, 256, chal, aux, aux_pub);
+}
+int32_t vx_sha_tree_gen_aux_512(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t*, uint64_t* aux, uint64_t* aux_pub) {
+    return sha_tree_gen_aux(ctx, trace, log_n, 512, chal, aux, aux_pub);
 }

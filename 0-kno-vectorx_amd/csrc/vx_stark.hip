@@ -18,6 +18,7 @@
 #include "air.cuh"
 #include "air_blake.cuh"
 #include "air_sha.cuh"
+#include "air_sha_tree.cuh"
 #include "poseidon_constants.h"
 #include "vx_internal.h"
 
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256) void k_fri_combine(CombineArgs a) {
 }
 
 // ------------------------------------------------------------------ AIR registry
-typedef int32_t (*gen_aux_fn)(vx_ctx*, const uint64_t* trace, int log_n, const uint64_t* chal, uint64_t* aux, uint64_t* aux_pub);
+typedef int32_t (*gen_aux_fn)(vx_ctx*, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub);
 struct AirDesc {
     int id, cols, pub, periodic, period_log;
     void (*periodic_values)(std::vector<uint64_t>&);  // one period of every periodic column, back to back
@@ -373,6 +374,8 @@ static AirDesc desc(void (*pv)(std::vector<uint64_t>&), gen_aux_fn ga = nullptr)
 static const AirDesc AIRS[] = {
     desc<ShaAir>(sha_periodic), desc<BlakeAir>(blake_periodic, vx_blake_air_gen_aux), desc<FibAir>(no_periodic), desc<MixAir>(mix_periodic),
     desc<LookupAir>(lookup_periodic, vx_lookup_air_gen_aux),
+    desc<ShaTreeAir256>(ShaTreeAir256::periodic_values, vx_sha_tree_gen_aux_256), desc<ShaTreeAir512>(ShaTreeAir512::periodic_values, vx_sha_tree_gen_aux_512),
+    desc<ShaTreeAir16>(ShaTreeAir16::periodic_values, vx_sha_tree_gen_aux_16),
 };
 static const AirDesc* find_air(int id) {
     for (const AirDesc& d : AIRS)
@@ -492,8 +495,8 @@ int32_t vx_quotient_eval(vx_ctx* ctx, int air_id, int rate_bits, const vx_buf* t
     return quotient_eval_dev(ctx, air, log_n, rate_bits, trace_lde->d, alphas, public_inputs, n_public, nullptr, nullptr, out->d, mem);
 }
 
-int32_t vx_stark_aux_trace(vx_ctx* ctx, int air_id, const vx_buf* trace, int log_n, const uint64_t* challenges, size_t n_challenges, vx_buf* aux_out,
-                           uint64_t* aux_public_out) {
+int32_t vx_stark_aux_trace(vx_ctx* ctx, int air_id, const vx_buf* trace, int log_n, const uint64_t* public_inputs, size_t n_public,
+                           const uint64_t* challenges, size_t n_challenges, vx_buf* aux_out, uint64_t* aux_public_out) {
     if (!ctx || !trace || !challenges || !aux_out) return VX_ERR_ARG;
     const AirDesc* air = find_air(air_id);
     VX_CHECK(air && air->aux > 0 && air->gen_aux, "aux trace: AIR %d has no auxiliary round", air_id);
@@ -503,7 +506,8 @@ int32_t vx_stark_aux_trace(vx_ctx* ctx, int air_id, const vx_buf* trace, int log
     VX_CHECK(trace->n >= n * (size_t)air->cols && aux_out->n >= n * (size_t)air->aux, "aux trace: buffers too small");
     for (size_t i = 0; i < n_challenges; ++i) VX_CHECK(challenges[i] < glh::P, "aux trace: non-canonical challenge");
     uint64_t apub[8] = {0};
-    VX_TRY(air->gen_aux(ctx, trace->d, log_n, challenges, aux_out->d, apub));
+    VX_CHECK((int)n_public == air->pub && (n_public == 0 || public_inputs), "aux trace: AIR %d takes %d public inputs", air_id, air->pub);
+    VX_TRY(air->gen_aux(ctx, trace->d, log_n, challenges, public_inputs, aux_out->d, apub));
     if (aux_public_out)
         for (int q = 0; q < 2 * air->auxpub; ++q) aux_public_out[q] = apub[q];
     return VX_OK;
@@ -513,7 +517,7 @@ int32_t vx_stark_prove(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_in, c
                        const uint64_t* public_inputs, size_t n_public, uint64_t* proof_out, size_t proof_cap,
                        size_t* proof_len) {
     if (!ctx || !cfg_in || !trace || !proof_len) return VX_ERR_ARG;
-    return vx_stark_prove_impl(ctx, air_id, cfg_in, trace->d, trace->n, 0, log_n, public_inputs, n_public, proof_out, proof_cap, proof_len);
+    return vx_stark_prove_impl(ctx, air_id, cfg_in, trace->d, trace->n, 0, log_n, public_inputs, n_public, proof_out, proof_cap, proof_len, nullptr);
 }
 }  // extern "C"
 
@@ -619,11 +623,22 @@ static int32_t quotient_eval_dev(vx_ctx* ctx, const AirDesc* air, int L, int r, 
     return VX_OK;
 }
 
+// Lookup challenges shared by two tables: a transcript of both tables' public inputs and trace caps.
+void vx_shared_challenges(const uint64_t* pub_a, size_t n_a, const uint64_t* cap_a, const uint64_t* pub_b, size_t n_b, const uint64_t* cap_b,
+                          size_t cap_words, uint64_t* out, size_t n_out) {
+    Challenger sc;
+    sc.observe(pub_a, n_a);
+    sc.observe(cap_a, cap_words);
+    sc.observe(pub_b, n_b);
+    sc.observe(cap_b, cap_words);
+    for (size_t q = 0; q < n_out; ++q) out[q] = sc.challenge();
+}
+
 // consume_trace != 0: the trace buffer is overwritten (it ends up holding the bit-reversed coefficients);
 // saves the n*c coefficient scratch -- the caller must own the buffer.
 int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_in, uint64_t* trace_d, size_t trace_len, int consume_trace,
                             int log_n, const uint64_t* public_inputs, size_t n_public, uint64_t* proof_out, size_t proof_cap,
-                            size_t* proof_len) {
+                            size_t* proof_len, const vx_chal_hook* hook) {
     if (!ctx || !cfg_in || !trace_d || !proof_len) return VX_ERR_ARG;
     const AirDesc* air = find_air(air_id);
     VX_CHECK(air, "stark prove: unknown AIR id %d", air_id);
@@ -687,10 +702,17 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
     uint64_t* aux_d = nullptr;  // [ca][n]: values, then (after the in-place inverse NTT) coefficients in bit-reversed positions
     vx_tree* t_aux = nullptr;
     if (ca) {
-        for (int q = 0; q < air->chal; ++q) chal[q] = ch.challenge();
+        if (hook) {
+            // lookup challenges SHARED with other tables (a bus between AIRs): the caller derives them once every
+            // table's trace cap exists; this transcript absorbs them so that everything after depends on them
+            VX_TRY(hook->fn(hook->user, public_inputs, n_public, proof.data() + proof.size() - cap_words, cap_words, chal, (size_t)air->chal));
+            for (int q = 0; q < air->chal; ++q) VX_CHECK(chal[q] < glh::P, "stark prove: shared challenge %d is not canonical", q);
+            ch.observe(chal, (size_t)air->chal);
+        } else
+            for (int q = 0; q < air->chal; ++q) chal[q] = ch.challenge();
         aux_d = mem.alloc(n * ca);
         VX_CHECK(aux_d, "stark prove: out of device memory (auxiliary trace)");
-        VX_TRY(air->gen_aux(ctx, trace_d, L, chal, aux_d, apub));
+        VX_TRY(air->gen_aux(ctx, trace_d, L, chal, public_inputs, aux_d, apub));
         VX_TRY(vx_lde_consume_dev(ctx, aux_d, L, ca, r, g, trace_lde + N * cm));
         VX_TRY(vx_merkle_build_dev(ctx, trace_lde + N * cm, N, ca, VX_LEAVES_COLS_BITREV, cfg.cap_height, &t_aux));
         mem.trees.push_back(t_aux);

@@ -11,6 +11,7 @@
 #include "air.cuh"
 #include "air_blake.cuh"
 #include "air_sha.cuh"
+#include "air_sha_tree.cuh"
 #include "poseidon_constants.h"
 #include "vx_internal.h"
 
@@ -174,7 +175,8 @@ void v_lookup_periodic(std::vector<uint64_t>& v) {
 }
 const AirV V_AIRS[] = {
     vdesc<ShaAir>(v_sha_periodic), vdesc<FibAir>(v_no_periodic), vdesc<MixAir>(v_mix_periodic), vdesc<BlakeAir>(v_blake_periodic),
-    vdesc<LookupAir>(v_lookup_periodic),
+    vdesc<LookupAir>(v_lookup_periodic), vdesc<ShaTreeAir256>(ShaTreeAir256::periodic_values), vdesc<ShaTreeAir512>(ShaTreeAir512::periodic_values),
+    vdesc<ShaTreeAir16>(ShaTreeAir16::periodic_values),
 };
 size_t brev(size_t x, int bits) {
     size_t r = 0;
@@ -200,6 +202,31 @@ extern "C" {
 
 int32_t vx_stark_verify(const vx_stark_config* cfg, const uint64_t* pr, size_t len, int expect_air,
                         const uint64_t* expect_public, size_t n_expect_public, char* err, size_t errlen) {
+    return vx_stark_verify_ext(cfg, pr, len, expect_air, expect_public, n_expect_public, nullptr, nullptr, nullptr, err, errlen);
+}
+}  // extern "C"
+
+bool vx_stark_proof_peek(const uint64_t* pr, size_t len, int cap_height, const uint64_t** pub, size_t* n_pub, const uint64_t** cap) {
+    if (len < 12 || pr[9] > 16) return false;
+    const size_t pos = 10 + pr[9];
+    if (pos + 2 > len) return false;
+    const size_t np = pr[pos + 1];
+    if (np > 64 || cap_height < 0 || cap_height > 16 || pos + 2 + np + ((size_t)4 << cap_height) > len) return false;
+    *pub = pr + pos + 2, *n_pub = np, *cap = pr + pos + 2 + np;
+    return true;
+}
+void v_shared_challenges(const uint64_t* pub_a, size_t n_a, const uint64_t* cap_a, const uint64_t* pub_b, size_t n_b, const uint64_t* cap_b, size_t cap_words,
+                         uint64_t* out, size_t n_out) {
+    VChallenger sc;
+    sc.observe(pub_a, n_a);
+    sc.observe(cap_a, cap_words);
+    sc.observe(pub_b, n_b);
+    sc.observe(cap_b, cap_words);
+    for (size_t q = 0; q < n_out; ++q) out[q] = sc.challenge();
+}
+
+int32_t vx_stark_verify_ext(const vx_stark_config* cfg, const uint64_t* pr, size_t len, int expect_air, const uint64_t* expect_public,
+                            size_t n_expect_public, const uint64_t* ext_chal, const uint64_t** apub_out, int* log_n_out, char* err, size_t errlen) {
     if (!cfg || !pr) return VX_ERR_ARG;
     size_t pos = 0;
     auto have = [&](size_t k) { return pos + k <= len; };
@@ -282,7 +309,11 @@ int32_t vx_stark_verify(const vx_stark_config* cfg, const uint64_t* pr, size_t l
     uint64_t chal[8] = {0};
     if (ca) {  // auxiliary round: lookup challenges after the trace cap, then the published values and the second cap
         NEED(air->chal <= 8 && 2 * air->auxpub <= 8, "AIR %d auxiliary round is misconfigured", air_id);
-        for (int q = 0; q < air->chal; ++q) chal[q] = ch.challenge();
+        if (ext_chal) {
+            for (int q = 0; q < air->chal; ++q) chal[q] = ext_chal[q];
+            ch.observe(chal, (size_t)air->chal);
+        } else
+            for (int q = 0; q < air->chal; ++q) chal[q] = ch.challenge();
         ch.observe(apub, 2 * (size_t)air->auxpub);
         ch.observe(cap_a, cap_words);
     }
@@ -441,20 +472,30 @@ int32_t vx_stark_verify(const vx_stark_config* cfg, const uint64_t* pr, size_t l
         NEED(fx_eq(fp, ev), "final polynomial evaluation mismatch (query %zu)", qi);
     }
     NEED(pos == len, "trailing data in proof (%zu of %zu words used)", pos, len);
+    if (ca && !ext_chal)  // a stand-alone proof has nobody to cancel a bus total against
+        for (int q = 0; q < 2 * air->auxpub; ++q) NEED(apub[q] == 0, "stand-alone proof publishes a non-zero bus total");
+    if (apub_out) *apub_out = apub;
+    if (log_n_out) *log_n_out = L;
     return VX_OK;
 }
+
+extern "C" {
 
 int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob, size_t len, uint32_t max_headers,
                                uint32_t trusted_block, const uint8_t trusted_hash[32], const uint8_t* authority_set_hash,
                                uint32_t target_block, const uint8_t out96[96], char* err, size_t errlen) {
     if (!cfg || !blob || !trusted_hash || !out96) return VX_ERR_ARG;
-    NEED(len > 18 && blob[0] == 0x3345474e41525248ULL, "bad header_range blob");
+    NEED(len > 19 && blob[0] == 0x3445474e41525248ULL, "bad header_range blob");
     NEED(blob[1] == max_headers && blob[2] == trusted_block && blob[3] == target_block, "blob is for a different request");
     NEED(memcmp(blob + 4, out96, 96) == 0, "public outputs differ from the blob");
     NEED(target_block > trusted_block, "empty block range");
-    const size_t len1 = blob[16], len2 = blob[17];
-    NEED(len1 <= len && len2 <= len && 18 + len1 + len2 == len, "blob lengths are inconsistent");
-    uint64_t pub[18];
+    const size_t len1 = blob[16], len2 = blob[17], len3 = blob[18];
+    NEED(len1 <= len && len2 <= len && len3 <= len && 19 + len1 + len2 + len3 == len, "blob lengths are inconsistent");
+    const int tree_id = max_headers == 256 ? 7 : max_headers == 512 ? 8 : max_headers == 16 ? 9 : 0;
+    NEED(tree_id, "max_headers %u has no Merkle AIR", max_headers);
+    const uint64_t *pa = blob + 19, *pb = blob + 19 + len1 + len2;
+    // public inputs of the two tables, rebuilt from the request and the claimed outputs
+    uint64_t pub[20], tpub[16];
     for (int j = 0; j < 8; ++j) {
         uint32_t a, b;
         memcpy(&a, trusted_hash + 4 * j, 4);
@@ -464,15 +505,36 @@ int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob,
     }
     pub[16] = (uint64_t)trusted_block + 1;
     pub[17] = target_block;
-    int32_t rc = vx_stark_verify(cfg, blob + 18, len1, VX_AIR_BLAKE_CHAIN, pub, 18, err, errlen);
+    pub[18] = max_headers;  // the Merkle tree size the state / data roots are sent to
+    pub[19] = 1;            // bus on
+    for (int j = 0; j < 16; ++j)  // state_root_merkle_root || data_root_merkle_root as big-endian words
+        tpub[j] = ((uint64_t)out96[32 + 4 * j] << 24) | ((uint64_t)out96[33 + 4 * j] << 16) | ((uint64_t)out96[34 + 4 * j] << 8) | out96[35 + 4 * j];
+    // the lookup challenges both proofs must have used: a transcript of both trace caps
+    const uint64_t *ppa, *ppb, *cap_a, *cap_b;
+    size_t npa, npb;
+    NEED(vx_stark_proof_peek(pa, len1, cfg->cap_height, &ppa, &npa, &cap_a) && vx_stark_proof_peek(pb, len3, cfg->cap_height, &ppb, &npb, &cap_b),
+         "proofs are too short to hold a trace cap");
+    uint64_t chal[4];
+    v_shared_challenges(ppa, npa, cap_a, ppb, npb, cap_b, (size_t)4 << cfg->cap_height, chal, 4);
+    const uint64_t *apub_a = nullptr, *apub_b = nullptr;
+    int la = 0, lb = 0;
+    int32_t rc = vx_stark_verify_ext(cfg, pa, len1, VX_AIR_BLAKE_CHAIN, pub, 20, chal, &apub_a, &la, err, errlen);
     if (rc != VX_OK) return rc;
+    rc = vx_stark_verify_ext(cfg, pb, len3, tree_id, tpub, 16, chal, &apub_b, &lb, err, errlen);
+    if (rc != VX_OK) return rc;
+    // the bus closes: what the hash-chain table sent (state-root words, data-root bytes of every header) is exactly what
+    // the Merkle table received.  Each table publishes its total divided by its row count.
+    for (int q = 0; q < 2; ++q) {
+        const uint64_t sa = glh::mul(apub_a[q], ((uint64_t)1 << la) % glh::P), sb = glh::mul(apub_b[q], ((uint64_t)1 << lb) % glh::P);
+        NEED(glh::add(sa, sb) == 0, "the bus between the hash-chain table and the Merkle table does not balance");
+    }
     if (authority_set_hash) {  // the EVM input `authority_set_hash` (header_range.rs:35) must be the proven commitment
         NEED(len2 > 0, "blob carries no authority-set commitment proof");
         uint64_t spub[8];
         for (int j = 0; j < 8; ++j)
             spub[j] = ((uint64_t)authority_set_hash[4 * j] << 24) | ((uint64_t)authority_set_hash[4 * j + 1] << 16) |
                       ((uint64_t)authority_set_hash[4 * j + 2] << 8) | authority_set_hash[4 * j + 3];
-        rc = vx_stark_verify(cfg, blob + 18 + len1, len2, VX_AIR_SHA_CHAIN, spub, 8, err, errlen);
+        rc = vx_stark_verify(cfg, blob + 19 + len1, len2, VX_AIR_SHA_CHAIN, spub, 8, err, errlen);
     }
     return rc;
 }

@@ -30,7 +30,8 @@ SYMBOLS = [
 ]
 
 VX_AIR_FIBONACCI, VX_AIR_MIX, VX_AIR_BLAKE_CHAIN, VX_AIR_LOOKUP = 1, 2, 6, 5
-VX_BLAKE_AIR_COLS, VX_BLAKE_AIR_AUX_COLS = 731, 268
+VX_BLAKE_AIR_COLS, VX_BLAKE_AIR_AUX_COLS = 740, 278
+VX_AIR_SHA_TREE = {256: 7, 512: 8, 16: 9}
 VX_AIR_SHA_CHAIN, VX_SHA_AIR_COLS = 4, 1444
 
 
@@ -113,7 +114,7 @@ def load_library():
         "vx_stark_prove": [vp, C.c_int, C.POINTER(StarkConfig), vp, C.c_int, vp, sz, vp, sz, C.POINTER(sz)],
         "vx_blake2b_256_batch": [vp, vp, sz, vp, sz, vp], "vx_sha256_pairs": [vp, vp, sz, vp],
         "vx_verify_subchain": [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp],
-        "vx_blake_chain_trace": [vp, vp, sz, vp, sz, vp, C.c_uint32, C.c_int, vp, vp, vp],
+        "vx_blake_chain_trace": [vp, vp, sz, vp, sz, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp],
         "vx_ed25519_verify_batch": [vp, vp, vp, vp, C.c_uint32, vp, sz, vp],
         "vx_sha_chain_trace": [vp, vp, sz, C.c_int, vp, vp, vp],
         "vx_verify_simple_justification": [vp, C.c_uint32, vp, u64, vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32],
@@ -125,7 +126,7 @@ def load_library():
         "vx_quotient_eval": [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, sz, vp],
         "vx_decode_header_batch": [vp, vp, sz, vp, sz, vp, vp, vp, vp, vp, vp],
         "vx_decode_precommit_batch": [vp, vp, sz, vp, vp, vp, vp, vp],
-        "vx_stark_aux_trace": [vp, C.c_int, vp, C.c_int, vp, sz, vp, vp],
+        "vx_stark_aux_trace": [vp, C.c_int, vp, C.c_int, vp, sz, vp, sz, vp, vp],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -162,13 +163,13 @@ def stark_verify(proof, cfg=None, expect_air=0, expect_public=None):
         raise VxError(rc, err.value.decode())
 
 
-HR_HDR = 18  # words before the first proof in a header_range blob
+HR_HDR = 19  # words before the first proof in a header_range blob
 
 
 def split_blob(blob):
-    """(blake proof words, sha proof words) of a header_range blob."""
-    l1, l2 = int(blob[16]), int(blob[17])
-    return blob[HR_HDR: HR_HDR + l1], blob[HR_HDR + l1: HR_HDR + l1 + l2]
+    """(hash-chain proof, authority-commitment proof, Merkle proof) words of a header_range blob."""
+    l1, l2, l3 = int(blob[16]), int(blob[17]), int(blob[18])
+    return blob[HR_HDR: HR_HDR + l1], blob[HR_HDR + l1: HR_HDR + l1 + l2], blob[HR_HDR + l1 + l2: HR_HDR + l1 + l2 + l3]
 
 
 def header_range_verify(blob, max_headers, trusted_block, trusted_hash, target_block, out96, cfg=None, authority_set_hash=None):
@@ -382,12 +383,14 @@ class Context:
         self._ck(self.L.vx_stark_prove(self.h, air_id, C.byref(cfg), trace_buf.h, log_n, _ptr(pub), pub.size, _ptr(out), out.size, C.byref(need)))
         return out[: need.value]
 
-    def stark_aux_trace(self, air_id, trace_buf, log_n, challenges, n_aux_cols):
-        """The auxiliary (logUp) columns of an AIR for given lookup challenges -> Buffer [n_aux_cols][2^log_n]."""
+    def stark_aux_trace(self, air_id, trace_buf, log_n, challenges, n_aux_cols, public_inputs=()):
+        """The auxiliary (logUp) columns of an AIR for given lookup challenges -> (Buffer [n_aux_cols][2^log_n], published values)."""
         ch = np.ascontiguousarray(challenges, dtype=np.uint64)
+        pub = np.ascontiguousarray(public_inputs, dtype=np.uint64)
         out = self.alloc(n_aux_cols << log_n)
-        self._ck(self.L.vx_stark_aux_trace(self.h, air_id, trace_buf.h, log_n, _ptr(ch), ch.size, out.h, None))
-        return out
+        apub = np.zeros(8, dtype=np.uint64)
+        self._ck(self.L.vx_stark_aux_trace(self.h, air_id, trace_buf.h, log_n, _ptr(pub) if pub.size else None, pub.size, _ptr(ch), ch.size, out.h, _ptr(apub)))
+        return out, apub
 
     def header_range_prove(self, headers_buf, stride, sizes, max_headers, trusted_block, trusted_hash, target_block, cfg=None, out=None, just=None):
         """HeaderRangeCircuit::prove for a chain resident in HBM -> (96-byte output, proof blob words).
@@ -454,13 +457,13 @@ class Context:
         self._ck(self.L.vx_sha256_pairs(self.h, _ptr(p), p.shape[0], _ptr(out)))
         return out
 
-    def blake_chain_trace(self, headers_buf, stride, sizes, trusted_hash, first_block_number, log_n, trace_buf=None):
+    def blake_chain_trace(self, headers_buf, stride, sizes, trusted_hash, first_block_number, log_n, trace_buf=None, tree_size=0):
         sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
         th = np.frombuffer(bytes(trusted_hash), dtype=np.uint8).copy()
         trace_buf = trace_buf or self.alloc(VX_BLAKE_AIR_COLS << log_n)
-        pub = np.zeros(18, dtype=np.uint64)
+        pub = np.zeros(20, dtype=np.uint64)
         dig = np.zeros((sizes.size, 32), dtype=np.uint8)
-        self._ck(self.L.vx_blake_chain_trace(self.h, headers_buf.h, stride, _ptr(sizes), sizes.size, _ptr(th), first_block_number, log_n, trace_buf.h, _ptr(pub), _ptr(dig)))
+        self._ck(self.L.vx_blake_chain_trace(self.h, headers_buf.h, stride, _ptr(sizes), sizes.size, _ptr(th), first_block_number, tree_size, log_n, trace_buf.h, _ptr(pub), _ptr(dig)))
         return trace_buf, pub, dig
 
     def sha_chain_trace(self, pubkeys, log_n, trace_buf=None):

@@ -172,8 +172,8 @@ int32_t vx_quotient_eval(vx_ctx* ctx, int air_id, int rate_bits, const vx_buf* t
  * vx_stark_prove runs between the trace cap and the constraint challenges, exposed on its own as a test surface.
  * trace: the AIR's main columns [cols][2^log_n]; challenges: the AIR's CHAL base-field elements (canonical);
  * aux_out: [aux cols][2^log_n]; aux_public_out (may be NULL): the values published with the auxiliary cap. */
-int32_t vx_stark_aux_trace(vx_ctx* ctx, int air_id, const vx_buf* trace, int log_n, const uint64_t* challenges, size_t n_challenges,
-                           vx_buf* aux_out, uint64_t* aux_public_out);
+int32_t vx_stark_aux_trace(vx_ctx* ctx, int air_id, const vx_buf* trace, int log_n, const uint64_t* public_inputs, size_t n_public,
+                           const uint64_t* challenges, size_t n_challenges, vx_buf* aux_out, uint64_t* aux_public_out);
 /* upper bound on the proof length (uint64 words) for buffer sizing */
 int32_t vx_stark_proof_bound(int air_id, const vx_stark_config* cfg, int log_n, size_t* n_words);
 int32_t vx_stark_prove(vx_ctx* ctx, int air_id, const vx_stark_config* cfg, const vx_buf* trace, int log_n,
@@ -200,8 +200,11 @@ int32_t vx_sha256_pairs(vx_ctx* ctx, const uint8_t* pairs64, size_t n, uint8_t* 
  * circuits/builder/subchain_verification.rs:163-177).  headers as for vx_verify_subchain (stride a
  * multiple of 128).  Writes the column-major MAIN trace (731 columns x 2^log_n rows, 16 rows per
  * compression, padded with inactive blocks; byte cells + the multiplicities of the two 2^16-row XOR
- * lookup tables, so log_n >= 16) into trace_out, the 18 public inputs (trusted hash, target hash as
- * 32-bit little-endian limbs, first and last block number) and optionally the digests (host).  The 268
+ * lookup tables, so log_n >= 16) into trace_out, the 20 public inputs (trusted hash, target hash as
+ * 32-bit little-endian limbs, first and last block number, tree_size, bus flag) and optionally the digests
+ * (host).  tree_size = 16 / 256 / 512: the state roots (decoder.rs:121-128) and data roots (:132-149) of the
+ * headers go onto the logUp bus towards a ShaTreeAir of that many leaves (vx_header_range_prove proves both
+ * tables under shared challenges); tree_size = 0: a stand-alone hash-chain proof.  The 278
  * auxiliary (logUp) columns are derived inside vx_stark_prove once the lookup challenges exist.
  * KNOWN DEVIATION from decoder.rs:39-92 (which decodes all four SCALE compact modes): the AIR proves
  * that header i carries block number first_block_number + i as a 4-byte (mode 2) compact int, i.e.
@@ -209,10 +212,10 @@ int32_t vx_sha256_pairs(vx_ctx* ctx, const uint8_t* pairs64, size_t n, uint8_t* 
  * VX_ERR_ARG (tests/test_gpu_decoders.py pins the code).  The native path (vx_verify_subchain,
  * vx_decode_header_batch) handles all four modes.
  * Prove it with vx_stark_prove(ctx, VX_AIR_BLAKE_CHAIN, ...). */
-enum { VX_AIR_BLAKE_CHAIN = 6, VX_BLAKE_AIR_COLS = 731, VX_BLAKE_AIR_AUX_COLS = 268 };
+enum { VX_AIR_BLAKE_CHAIN = 6, VX_BLAKE_AIR_COLS = 740, VX_BLAKE_AIR_AUX_COLS = 278 };
 int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_headers,
-                             const uint8_t trusted_hash[32], uint32_t first_block_number, int log_n, vx_buf* trace_out,
-                             uint64_t public_inputs_out[18], uint8_t* digests_out);
+                             const uint8_t trusted_hash[32], uint32_t first_block_number, uint32_t tree_size, int log_n, vx_buf* trace_out,
+                             uint64_t public_inputs_out[20], uint8_t* digests_out);
 
 /* ---- K8: ShaChainAir trace generation (compute_authority_set_commitment, justification.rs:127-162):
  * the chained SHA-256 commitment h_0 = SHA256(pk_0), h_i = SHA256(h_{i-1} || pk_i) over n_keys 32-byte

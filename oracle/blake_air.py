@@ -20,6 +20,14 @@ Each lookup contributes 1/(beta + fingerprint(tuple)); two lookups share one ext
 running sum Z closes cyclically: the sum over all rows is zero iff every looked-up tuple is in its table.
 Finalisation reuses the same-row D2 lookups of rows 13 and 14:  U = v_lo ^ v_hi, then h_out = U ^ h.
 The trace must have at least 2^16 rows (one copy of the tables).
+
+Bus to the SHA-256 Merkle AIR (oracle/sha_tree_air.py): the same running sum also carries what decode_header extracts
+(/root/reference circuits/builder/decoder.rs:104-157) -- the state root, bytes 36..68 of a header whose block number is
+a 4-byte compact int (:121-128), sent as eight big-endian words (tree 0, node id N + leaf, j, word) from the message
+bytes of rows 4..8 of the header's first chunk, and the data root, the last 32 bytes (:132-149), sent byte by byte
+(leaf, k, byte) with a witness flag E per message byte; k = position - (size - 32) is computed from the byte counter and
+a per-message size register SZ.  Whoever receives must take each (leaf, k) exactly once, which pins E.  The net bus
+total S of this table is published (as S / n) and must cancel against the other table's.
 """
 import hashlib
 
@@ -33,11 +41,14 @@ ID = 6
 S_A1, S_D1, S_C1, S_B1, S_A2, S_D2, S_C2, S_L, S_T = range(9)
 CAR0, MS0, MB0, HL0, D0 = 576, 608, 640, 648, 664
 ACT, FIN, FIRST, CAP, T, INC, NUM, FA = range(672, 680)
-TB0, IB0, MK0, CNT, M1, M2, COLS = 680, 712, 720, 728, 729, 730, 731
-N_HELP = 134  # 128 G helpers, 4 message-byte range checks, table helper, running sum Z
-HM0, HT, ZZ = 128, 132, 133
-AUX, CHAL, AUXPUB = 2 * N_HELP, 4, 0
-PUB, PERIODIC, PERIOD_LOG = 18, 20, 16
+TB0, IB0, MK0, CNT, M1, M2, SZ, E0, COLS = 680, 712, 720, 728, 729, 730, 731, 732, 740
+# helpers: 128 of the G functions, 4 message-byte range checks, 4 data-root byte sends, 1 state-root word sends, table helper, running sum Z
+N_HELP = 139
+HM0, HB0, HS, HT, ZZ = 128, 132, 136, 137, 138
+AUX, CHAL, AUXPUB = 2 * N_HELP, 4, 1
+PUB, PERIODIC, PERIOD_LOG = 20, 20, 16
+# tuples on the bus are (t0, t1, t2, t3, tag): fingerprint t0 + g t1 + g^2 t2 + g^3 t3 + g^4 tag
+TAG_T1, TAG_T2, TAG_BYTE, TAG_WORD = 0, 1, 2, 3
 PERIOD_LOGS = [4] * 16 + [16] * 4
 TABLE_LOG = 16
 INV32 = pow(1 << 32, P - 2, P)
@@ -144,9 +155,10 @@ def limb(bytes8, h):
     return acc
 
 
-def lookups(loc, nxt, sel):
-    """The 264 lookups of the row pair in protocol order: (multiplicity, table, tuple).  Works on any backend
-    (field vectors, extension scalars, plain numpy integers)."""
+def lookups(loc, nxt, sel, pub=None):
+    """The lookups of the row pair in protocol order: (multiplicity, tag, tuple).  Works on any backend (field
+    vectors, extension scalars, plain numpy integers).  The 264 table lookups first (pairs share a helper with one common
+    multiplicity), then -- when `pub` is given -- the 10 bus sends to the Merkle AIR."""
     g_on = sel[0]
     for r in range(1, 12):
         g_on = g_on + sel[r]
@@ -155,14 +167,30 @@ def lookups(loc, nxt, sel):
     for k in range(8):
         a, b, c, d = g_inputs(loc, nxt, k)
         A1, D1, C1, B1, A2, D2, C2, L, Tt = (cells(nxt, k, s) for s in range(9))
-        out += [(g_on, 1, (d[i], A1[i], D1[(i + 4) % 8])) for i in range(8)]
-        out += [(g_on, 1, (b[i], C1[i], B1[(i + 5) % 8])) for i in range(8)]
-        out += [(m3, 1, (D1[i], A2[i], D2[(i + 6) % 8])) for i in range(8)]
-        out += [(g_on, 2, (B1[i], C2[i], L[i], Tt[i])) for i in range(8)]
+        out += [(g_on, TAG_T1, (d[i], A1[i], D1[(i + 4) % 8])) for i in range(8)]
+        out += [(g_on, TAG_T1, (b[i], C1[i], B1[(i + 5) % 8])) for i in range(8)]
+        out += [(m3, TAG_T1, (D1[i], A2[i], D2[(i + 6) % 8])) for i in range(8)]
+        out += [(g_on, TAG_T2, (B1[i], C2[i], L[i], Tt[i])) for i in range(8)]
     one = sel[0]
     for r in range(1, 16):
         one = one + sel[r]
-    out += [(one, 1, (nxt[MB0 + i], 0, nxt[MB0 + i])) for i in range(8)]
+    out += [(one, TAG_T1, (nxt[MB0 + i], 0, nxt[MB0 + i])) for i in range(8)]
+    if pub is None:
+        return out
+    # ---- bus sends (rows are numbered by the LOCAL row's selectors: the next row is row r + 1 of its block)
+    r8n = sel[0] * 8
+    for r in range(1, 15):
+        r8n = r8n + sel[r] * (8 * (r + 1))  # 8 * (row index of the next row); sel[15] -> next row is row 0
+    leaf = nxt[NUM] - pub[16]
+    pos0 = nxt[T] - nxt[INC] + r8n - nxt[SZ] + 32
+    bus_on = pub[19]  # 0 for a stand-alone proof (nothing on the bus, published total 0), 1 next to the Merkle AIR
+    out += [(nxt[E0 + b] * bus_on, TAG_BYTE, (leaf, pos0 + b, nxt[MB0 + b])) for b in range(8)]
+    su, ju = sel[4] + sel[5] + sel[6] + sel[7], sel[4] + sel[5] * 3 + sel[6] * 5 + sel[7] * 7   # next row 5..8: words 1, 3, 5, 7 (bytes 0..3)
+    sv, jv = sel[3] + sel[4] + sel[5] + sel[6], sel[4] * 2 + sel[5] * 4 + sel[6] * 6             # next row 4..7: words 0, 2, 4, 6 (bytes 4..7)
+    be = lambda o: ((nxt[MB0 + o] * 256 + nxt[MB0 + o + 1]) * 256 + nxt[MB0 + o + 2]) * 256 + nxt[MB0 + o + 3]  # noqa: E731
+    node = leaf + pub[18]
+    zero = sel[0] * 0
+    out += [(nxt[FA] * su * bus_on, TAG_WORD, (zero, node, ju, be(0))), (nxt[FA] * sv * bus_on, TAG_WORD, (zero, node, jv, be(4)))]
     return out
 
 
@@ -294,6 +322,10 @@ def block_rows(blk):
         for b in range(8):
             t[MK0 + b, r] = 1 if 8 * r + b < blk["inc"] else 0
         t[CNT, r] = min(blk["inc"], 8 * (r + 1))
+        t[SZ, r] = blk["size"]
+        for b in range(8):
+            pos = blk["t"] - blk["inc"] + 8 * r + b
+            t[E0 + b, r] = 1 if (blk["act"] and blk["size"] - 32 <= pos < blk["size"]) else 0
         if r == 0:
             for w in range(16):
                 put_out(r, w, v0[w])
@@ -343,23 +375,29 @@ def multiplicities(tr):
     n = tr.shape[1]
     loc, nxt, sel = int_rows(tr)
     m1, m2 = np.zeros(1 << TABLE_LOG, dtype=np.int64), np.zeros(1 << TABLE_LOG, dtype=np.int64)
-    for m, table, tup in lookups(loc, nxt, sel):
+    for m, tag, tup in lookups(loc, nxt, sel):
         a, b = np.broadcast_to(tup[0], (n,)), np.broadcast_to(tup[1], (n,))
         idx = (a + 256 * b)[np.asarray(m) != 0]
         assert idx.size == 0 or (0 <= idx.min() and idx.max() < (1 << TABLE_LOG)), "lookup input is not a byte"
-        np.add.at(m1 if table == 1 else m2, idx, 1)
+        np.add.at(m1 if tag == TAG_T1 else m2, idx, 1)
     return m1, m2
 
 
-def gen_trace(messages, log_n, trusted_hash, first_number=None, forge=None):
-    """Full main trace [COLS][n] + public inputs (trusted / target hash limbs, first / last block number)."""
+def gen_trace(messages, log_n, trusted_hash, first_number=None, forge=None, tree_size=0):
+    """Full main trace [COLS][n] + public inputs (trusted / target hash limbs, first / last block number, Merkle tree
+    size, bus flag).  tree_size = 0: a stand-alone proof, nothing goes on the bus."""
     n = 1 << log_n
     assert log_n >= TABLE_LOG, "the trace must hold one copy of the 2^16-row lookup tables"
     if first_number is None:
         first_number = (int.from_bytes(messages[0][32:36], "little") - 2) // 4
     # padding blocks are identical: generate each distinct block once
     real_blocks, target, last_number = gen_blocks(messages, sum(max(1, (len(m) + 127) // 128) for m in messages), trusted_hash, first_number)
-    pad = dict(m=target + (4 * last_number + 2).to_bytes(4, "little") + bytes(92), h=list(IVP), t=36, inc=36, fin=True, first=True, act=0, D=target, num=last_number)
+    bi = 0
+    for msg in messages:  # the size register: every chunk of a message knows the message's length
+        for _ in range(max(1, (len(msg) + 127) // 128)):
+            real_blocks[bi]["size"] = len(msg)
+            bi += 1
+    pad = dict(m=target + (4 * last_number + 2).to_bytes(4, "little") + bytes(92), h=list(IVP), t=36, inc=36, fin=True, first=True, act=0, D=target, num=last_number, size=36)
     blocks = real_blocks + [pad]
     if forge is not None:
         blocks, target, last_number = forge(real_blocks, pad, target, last_number)
@@ -374,27 +412,27 @@ def gen_trace(messages, log_n, trusted_hash, first_number=None, forge=None):
     tr[M1, : 1 << TABLE_LOG], tr[M2, : 1 << TABLE_LOG] = m1.astype(np.uint64), m2.astype(np.uint64)
     lt = [int.from_bytes(trusted_hash[4 * j: 4 * j + 4], "little") for j in range(8)]
     lg = [int.from_bytes(target[4 * j: 4 * j + 4], "little") for j in range(8)]
-    return tr, lt + lg + [first_number, last_number], target
+    return tr, lt + lg + [first_number, last_number, tree_size, 1 if tree_size else 0], target
 
 
 # ----------------------------------------------------------------------------- constraints
-def fingerprints(loc, nxt, sel, per, chal):
-    """-> (list of (m, D) for the 264 lookups, D_t1, D_t2) with D = beta + fingerprint, extension valued."""
+def fingerprints(loc, nxt, sel, per, chal, pub):
+    """-> (list of (m, D) for the 274 lookups / sends, D_t1, D_t2) with D = beta + fingerprint, extension valued."""
     X2 = S.X2
     beta, gamma = X2(chal[0], chal[1]), X2(chal[2], chal[3])
     g2 = gamma * gamma
     g3 = g2 * gamma
     g4 = g2 * g2
 
-    def fp1(a, b, c):
-        return beta + a + gamma * b + g2 * c
+    def fp(tag, tup):
+        d = beta + tup[0] + gamma * tup[1] + g2 * tup[2]
+        if len(tup) > 3:
+            d = d + g3 * tup[3]
+        return d + g4 * tag if tag else d
 
-    def fp2(a, b, l, t):
-        return beta + a + gamma * b + g2 * l + g3 * t + g4
-
-    ds = [(m, fp1(*tup) if table == 1 else fp2(*tup)) for m, table, tup in lookups(loc, nxt, sel)]
+    ds = [(m, fp(tag, tup)) for m, tag, tup in lookups(loc, nxt, sel, pub)]
     ta, tb, tl, tt = per[16], per[17], per[18], per[19]
-    return ds, fp1(ta, tb, tl + tt * 128), fp2(ta, tb, tl, tt)
+    return ds, fp(TAG_T1, (ta, tb, tl + tt * 128)), fp(TAG_T2, (ta, tb, tl, tt))
 
 
 class BlakeChainAir:
@@ -537,6 +575,10 @@ class BlakeChainAir:
         c.constraint(loc[INC] - ib)
         c.constraint(loc[IB0 + 7] * (loc[INC] - 128))
         c.constraint((1 - loc[FIN]) * (loc[INC] - 128))
+        # ---- 7b. message size register: constant across the chunks of a message, equal to the byte counter at its end
+        c.constraint(in_blk * (nxt[SZ] - loc[SZ]))
+        c.constraint(sel[15] * (1 - loc[FIN]) * (nxt[SZ] - loc[SZ]))
+        c.constraint(loc[FIN] * (loc[SZ] - loc[T]))
         # ---- 8. digest register D: captured at FIN2 -> PAD of an active final block
         for j in range(8):
             c.transition((1 - sel[14]) * (nxt[D0 + j] - loc[D0 + j]))
@@ -549,22 +591,23 @@ class BlakeChainAir:
         c.last_row(loc[FIN] - 1)
         c.first_row(loc[NUM] - pub[16])
         c.last_row(loc[NUM] - pub[17])
-        # ---- 10. lookups (logUp): helpers of the row `nxt`, table side of the row `loc`, cyclic running sum
-        ds, dt1, dt2 = fingerprints(loc, nxt, sel, per, chal)
+        # ---- 10. lookups and bus sends (logUp): helpers of the row `nxt`, table side of the row `loc`, cyclic running sum
+        ds, dt1, dt2 = fingerprints(loc, nxt, sel, per, chal, pub)
         hsum = None
         for e in range(N_HELP - 2):
-            (m, du), (_m2, dv) = ds[2 * e], ds[2 * e + 1]
+            (mu, du), (mv, dv) = ds[2 * e], ds[2 * e + 1]
             h = X2(nxt[AX(e, 0)], nxt[AX(e, 1)])
-            c.constraint_x2(h * du * dv - (du + dv) * m)
+            c.constraint_x2(h * du * dv - dv * mu - du * mv)
             hsum = h if hsum is None else hsum + h
         ht = X2(loc[AX(HT, 0)], loc[AX(HT, 1)])
         c.constraint_x2(ht * dt1 * dt2 - dt2 * loc[M1] - dt1 * loc[M2])
         z, zn = X2(loc[AX(ZZ, 0)], loc[AX(ZZ, 1)]), X2(nxt[AX(ZZ, 0)], nxt[AX(ZZ, 1)])
-        c.constraint_x2(zn - z - hsum + ht)
+        c.constraint_x2(zn - z - hsum + ht + X2(aux_pub[0], aux_pub[1]))  # aux_pub = (net bus total of this table) / n
 
     @staticmethod
-    def gen_aux(trace, chal):
-        """Auxiliary columns [AUX][n] for the challenges (vectorised: field vectors through the C oracle)."""
+    def gen_aux(trace, chal, pub):
+        """Auxiliary columns [AUX][n] for the challenges (vectorised: field vectors through the C oracle) and the
+        published bus total / n."""
         tr = np.ascontiguousarray(trace, dtype=np.uint64)
         n = tr.shape[1]
         VecF = S.VecF
@@ -572,7 +615,7 @@ class BlakeChainAir:
         nxt = [VecF(np.roll(tr[j], -1)) for j in range(COLS)]
         per = [VecF(np.tile(np.array(v, dtype=np.uint64), n // len(v))) for v in periodic_values()]
         cv = [VecF.const(x, loc[0]) for x in chal]
-        ds, dt1, dt2 = fingerprints(loc, nxt, per[:16], per, cv)
+        ds, dt1, dt2 = fingerprints(loc, nxt, per[:16], per, cv, [VecF.const(x, loc[0]) for x in pub])
         aux = np.zeros((AUX, n), dtype=np.uint64)
 
         def inv(x):  # extension inverse, vectorised
@@ -583,22 +626,26 @@ class BlakeChainAir:
 
         hsum_a, hsum_b = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
         for e in range(N_HELP - 2):
-            (m, du), (_m2, dv) = ds[2 * e], ds[2 * e + 1]
-            h = (du + dv) * inv(du * dv) * m  # values of the pair (loc = row i, nxt = row i+1): they belong to row i+1
+            (mu, du), (mv, dv) = ds[2 * e], ds[2 * e + 1]
+            h = (dv * mu + du * mv) * inv(du * dv)  # values of the pair (loc = row i, nxt = row i+1): they belong to row i+1
             ha, hb = np.roll(h.a.v, 1), np.roll(h.b.v, 1)
             aux[2 * e], aux[2 * e + 1] = ha, hb
             hsum_a, hsum_b = O.batch_op("add", hsum_a, ha), O.batch_op("add", hsum_b, hb)
         ht = (dt2 * loc[M1] + dt1 * loc[M2]) * inv(dt1 * dt2)
         aux[2 * HT], aux[2 * HT + 1] = ht.a.v, ht.b.v
-        # Z(i+1) = Z(i) + sum_e h_e(i+1) - ht(i), Z(0) = 0
+        # Z(i+1) = Z(i) + sum_e h_e(i+1) - ht(i) - S/n, Z(0) = 0, S = the total over all rows (what this table puts on the bus)
         da = O.batch_op("sub", np.roll(hsum_a, -1), ht.a.v)
         db = O.batch_op("sub", np.roll(hsum_b, -1), ht.b.v)
+        ninv = pow(n, P - 2, P)
+        apub = []
         for comp, d in ((0, da), (1, db)):
+            dl = d.tolist()
+            sp = sum(dl) % P * ninv % P
             z = np.zeros(n, dtype=np.uint64)
             acc = 0
-            dl = d.tolist()
             for i in range(n - 1):
-                acc = (acc + dl[i]) % P
+                acc = (acc + dl[i] - sp) % P
                 z[i + 1] = acc
             aux[2 * ZZ + comp] = z
-        return aux, []
+            apub.append(sp)
+        return aux, apub

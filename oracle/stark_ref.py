@@ -457,7 +457,28 @@ def quotient_values(air, lde_nat, pub, alphas, L, r, chal=None, aux_pub=None):
     return qvals
 
 
-def prove(air, trace, public_inputs, cfg=None):
+def shared_challenges(pub_a, cap_a, pub_b, cap_b, n):
+    """Lookup challenges shared by two tables (a bus between AIRs): a transcript of both public inputs and trace caps."""
+    sc = O.Challenger()
+    for pub, cap in ((pub_a, cap_a), (pub_b, cap_b)):
+        if len(pub):
+            sc.observe(np.array([int(x) for x in pub], dtype=np.uint64))
+        sc.observe(np.asarray(cap, dtype=np.uint64).reshape(-1))
+    return [sc.challenge() for _ in range(n)]
+
+
+def proof_peek(proof, cap_h):
+    """(public inputs, trace cap) of a serialised proof."""
+    pr = [int(x) for x in np.asarray(proof[:64 + 2 * (4 << cap_h)], dtype=np.uint64)]
+    pos = 10 + pr[9]
+    n_pub = pr[pos + 1]
+    pub = [int(x) for x in proof[pos + 2: pos + 2 + n_pub]]
+    cap = np.asarray(proof[pos + 2 + n_pub: pos + 2 + n_pub + (4 << cap_h)], dtype=np.uint64)
+    return pub, cap
+
+
+def prove(air, trace, public_inputs, cfg=None, chal_hook=None):
+    """chal_hook(pub, trace_cap) -> lookup challenges shared with other tables (absorbed by this transcript)."""
     cfg = dict(DEFAULT_CFG, **(cfg or {}))
     L_ = _lib()
     trace = np.ascontiguousarray(trace, dtype=np.uint64)
@@ -486,8 +507,13 @@ def prove(air, trace, public_inputs, cfg=None):
     # in a second tree before the constraint challenges are drawn
     chal = aux_pub = None
     if c_aux:
-        chal = [ch.challenge() for _ in range(air.CHAL)]
-        aux, aux_pub = air.gen_aux(trace, chal)
+        if chal_hook is not None:
+            chal = [int(x) % P for x in chal_hook(pub, tree_t.cap.reshape(-1))]
+            assert len(chal) == air.CHAL
+            ch.observe(np.array(chal, dtype=np.uint64))
+        else:
+            chal = [ch.challenge() for _ in range(air.CHAL)]
+        aux, aux_pub = air.gen_aux(trace, chal, pub) if getattr(air, "AUXPUB", 0) else air.gen_aux(trace, chal)
         aux = np.ascontiguousarray(aux, dtype=np.uint64)
         aux_pub = [int(x) % P for x in aux_pub]
         assert aux.shape == (c_aux, n) and len(aux_pub) == 2 * air.AUXPUB
@@ -604,8 +630,8 @@ def _need(cond, msg):
         raise VerifyError(msg)
 
 
-def verify(proof, cfg=None, expect_air=None, expect_public=None):
-    """verify_stark_proof + verify_fri_proof.  Raises VerifyError."""
+def verify(proof, cfg=None, expect_air=None, expect_public=None, ext_chal=None):
+    """verify_stark_proof + verify_fri_proof.  Raises VerifyError.  ext_chal: lookup challenges derived outside (shared bus)."""
     cfg = dict(DEFAULT_CFG, **(cfg or {}))
     pr = [int(x) for x in np.asarray(proof, dtype=np.uint64)]
     pos = 0
@@ -655,7 +681,11 @@ def verify(proof, cfg=None, expect_air=None, expect_public=None):
     ch.observe(cap_t.reshape(-1))
     chal = None
     if c_aux:
-        chal = [ch.challenge() for _ in range(air.CHAL)]
+        if ext_chal is not None:
+            chal = [int(x) % P for x in ext_chal]
+            ch.observe(np.array(chal, dtype=np.uint64))
+        else:
+            chal = [ch.challenge() for _ in range(air.CHAL)]
         if aux_pub:
             ch.observe(np.array(aux_pub, dtype=np.uint64))
         ch.observe(cap_a.reshape(-1))
@@ -753,4 +783,6 @@ def verify(proof, cfg=None, expect_air=None, expect_public=None):
             fp = fp * x + e
         _need(fp == ev, "final polynomial evaluation mismatch")
     _need(pos == len(pr), "trailing data in proof")
-    return dict(air=air_id, degree_bits=L, public_inputs=pub)
+    if c_aux and ext_chal is None:  # a stand-alone proof has nobody to cancel a bus total against
+        _need(not any(aux_pub), "stand-alone proof publishes a non-zero bus total")
+    return dict(air=air_id, degree_bits=L, public_inputs=pub, aux_public=aux_pub)

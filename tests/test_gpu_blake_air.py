@@ -7,10 +7,13 @@ import numpy as np
 import pytest
 
 from oracle import blake_air as B
+from oracle import sha_tree_air as T
 from oracle import stark_ref as S
 
 pytestmark = pytest.mark.gpu
 S.register_air(B.BlakeChainAir)
+TREE16 = T.make_air(16)
+S.register_air(TREE16)
 L0 = 16
 
 
@@ -22,23 +25,26 @@ def limbs(b):
     return [int.from_bytes(b[4 * j: 4 * j + 4], "little") for j in range(8)]
 
 
-@pytest.mark.parametrize("n_headers", [1, 5])
-def test_trace_and_aux_columns_match_oracle(ctx, vx, oracle, n_headers):
+@pytest.mark.parametrize("n_headers,tree", [(1, 0), (5, 16)])
+def test_trace_and_aux_columns_match_oracle(ctx, vx, oracle, n_headers, tree):
+    """tree = 0: a stand-alone hash-chain proof (nothing on the bus); tree = 16: state / data roots go to the Merkle AIR."""
     ch = vx.synth.Chain(n_headers, profile="Ptiny", stride=512)
-    buf, pub, dig = ctx.blake_chain_trace(ctx.from_host(ch.headers), 512, ch.sizes, ch.trusted_hash, ch.trusted_block + 1, L0)
-    want, wpub, target = B.gen_trace(chain_msgs(ch), L0, ch.trusted_hash)
+    buf, pub, dig = ctx.blake_chain_trace(ctx.from_host(ch.headers), 512, ch.sizes, ch.trusted_hash, ch.trusted_block + 1, L0, tree_size=tree)
+    want, wpub, target = B.gen_trace(chain_msgs(ch), L0, ch.trusted_hash, tree_size=tree)
     got = buf.download().reshape(B.COLS, 1 << L0)
     bad = np.argwhere(got != want)
     assert bad.size == 0, f"first differing cells (col,row): {bad[:5].tolist()}"
     assert [int(x) for x in pub] == wpub and target == ch.target_hash
     assert [d.tobytes() for d in dig] == ch.hashes == [hashlib.blake2b(m, digest_size=32).digest() for m in chain_msgs(ch)]
-    # the auxiliary round for fixed challenges: helper columns, table helper and running sum, cell by cell
+    # the auxiliary round for fixed challenges: helper columns, bus sends, table helper and running sum, cell by cell
     chal = [0x0123456789ABCDEF, 0x0FEDCBA987654321, 0x1111111122222222, 0x3333333344444444]
-    aux = ctx.stark_aux_trace(B.ID, buf, L0, chal, B.AUX).download().reshape(B.AUX, 1 << L0)
-    waux, _ = B.BlakeChainAir.gen_aux(want, chal)
+    abuf, apub = ctx.stark_aux_trace(B.ID, buf, L0, chal, B.AUX, wpub)
+    aux = abuf.download().reshape(B.AUX, 1 << L0)
+    waux, wapub = B.BlakeChainAir.gen_aux(want, chal, wpub)
     bad = np.argwhere(aux != waux)
     assert bad.size == 0, f"first differing auxiliary cells (col,row): {bad[:5].tolist()}"
-    assert S.check_trace(B.BlakeChainAir, got, wpub, chal, aux, []) is None  # every constraint, every row, on the GPU's columns
+    assert [int(x) for x in apub[:2]] == wapub and (any(wapub) == bool(tree))
+    assert S.check_trace(B.BlakeChainAir, got, wpub, chal, aux, wapub) is None  # every constraint, every row, on the GPU's columns
 
 
 def test_edge_sizes_trace(ctx, vx, oracle):
@@ -59,6 +65,7 @@ def test_edge_sizes_trace(ctx, vx, oracle):
 
 
 def test_proof_bytes_and_verification(ctx, vx, oracle):
+    """Stand-alone hash-chain proof (nothing on the bus): GPU bytes == reference prover."""
     ch = vx.synth.Chain(2, profile="Ptiny", stride=512)
     buf, pub, _ = ctx.blake_chain_trace(ctx.from_host(ch.headers), 512, ch.sizes, ch.trusted_hash, ch.trusted_block + 1, L0)
     pcfg, cfg = ctx.stark_config(num_queries=10), dict(S.DEFAULT_CFG, num_queries=10)
@@ -72,6 +79,21 @@ def test_proof_bytes_and_verification(ctx, vx, oracle):
     vx.lib.stark_verify(got, pcfg, expect_air=B.ID, expect_public=wpub)
 
 
+def test_hash_chain_proof_bytes_with_the_bus_on(ctx, vx, oracle):
+    """The hash-chain table's proof inside a header_range blob (state / data roots on the bus, shared challenges)
+    == the reference prover's, byte for byte."""
+    ch = vx.synth.Chain(3, profile="Ptiny", stride=512)
+    cfg, ocfg = ctx.stark_config(num_queries=9), dict(S.DEFAULT_CFG, num_queries=9)
+    _, blob = ctx.header_range_prove(ctx.from_host(ch.headers), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
+    p_blake, _, p_tree = vx.lib.split_blob(blob)
+    pub_b, cap_b = S.proof_peek(p_tree, ocfg["cap_height"])
+    trace, wpub, _ = B.gen_trace(chain_msgs(ch), L0, ch.trusted_hash, tree_size=16)
+    want = S.prove(B.BlakeChainAir, trace, wpub, ocfg, chal_hook=lambda pub_a, cap_a: S.shared_challenges(pub_a, cap_a, pub_b, cap_b, 4))
+    assert p_blake.size == want.size
+    diff = np.nonzero(p_blake != want)[0]
+    assert diff.size == 0, f"first differing words {diff[:5]} of {want.size}"
+
+
 def test_larger_chain_verifies_and_forgeries_fail(ctx, vx, oracle):
     ch = vx.synth.Chain(16, profile="Ptiny", stride=512)
     hb = ctx.from_host(ch.headers)
@@ -79,7 +101,7 @@ def test_larger_chain_verifies_and_forgeries_fail(ctx, vx, oracle):
     pcfg, cfg = ctx.stark_config(num_queries=20), dict(S.DEFAULT_CFG, num_queries=20)
     proof = ctx.stark_prove(B.ID, buf, L0, pub, pcfg)
     info = S.verify(proof, cfg, expect_air=B.ID)
-    assert info["public_inputs"] == limbs(ch.trusted_hash) + limbs(ch.target_hash) + [ch.trusted_block + 1, ch.target_block]
+    assert info["public_inputs"] == limbs(ch.trusted_hash) + limbs(ch.target_hash) + [ch.trusted_block + 1, ch.target_block, 0, 0]
     # a trace with one wrong witness byte, a wrong lookup output, or a wrong multiplicity must not verify
     tr = buf.download().reshape(B.COLS, 1 << L0)
     for col, row in ((B.GC(3, B.S_C1, 5), 100), (B.GC(6, B.S_D2, 1), 37), (B.GC(2, B.S_T, 7), 21), (B.M1, 4660), (B.M2, 77)):
@@ -112,24 +134,38 @@ def test_forged_act_flag_cannot_be_proven(ctx, vx, oracle):
         vx.lib.stark_verify(pr, pcfg)
 
 
+def oracle_verify_blob(vx, blob, cfg, max_headers):
+    """The reference verifier on a header_range blob: both tables under the shared challenges, and the bus balance."""
+    p_blake, p_sha, p_tree = vx.lib.split_blob(blob)
+    pub_a, cap_a = S.proof_peek(p_blake, cfg["cap_height"])
+    pub_b, cap_b = S.proof_peek(p_tree, cfg["cap_height"])
+    chal = S.shared_challenges(pub_a, cap_a, pub_b, cap_b, 4)
+    ia = S.verify(p_blake, cfg, expect_air=B.ID, ext_chal=chal)
+    ib = S.verify(p_tree, cfg, expect_air=T.IDS[max_headers], ext_chal=chal)
+    for q in range(2):
+        assert (ia["aux_public"][q] * (1 << ia["degree_bits"]) + ib["aux_public"][q] * (1 << ib["degree_bits"])) % B.P == 0, "bus does not balance"
+    return ia, ib
+
+
 def test_header_range_prove_end_to_end(ctx, vx, oracle):
-    """Top-level entry: public outputs + BlakeChainAir proof in one blob; the reference verifier accepts it."""
+    """Top-level entry: public outputs + hash-chain proof + Merkle proof (+ authority commitment) in one blob."""
     ch = vx.synth.Chain(16, profile="Ptiny", stride=512)
-    cfg = ctx.stark_config(num_queries=12)
+    cfg, ocfg = ctx.stark_config(num_queries=12), dict(S.DEFAULT_CFG, num_queries=12)
     out96, blob = ctx.header_range_prove(ctx.from_host(ch.headers), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
     assert out96 == ch.expected_outputs(16)
-    assert int(blob[0]) == 0x3345474E41525248 and [int(x) for x in blob[1:4]] == [16, ch.trusted_block, ch.target_block]
+    assert int(blob[0]) == 0x3445474E41525248 and [int(x) for x in blob[1:4]] == [16, ch.trusted_block, ch.target_block]
     assert blob[4:16].tobytes() == out96
-    info = S.verify(vx.lib.split_blob(blob)[0], dict(S.DEFAULT_CFG, num_queries=12), expect_air=B.ID)
+    ia, ib = oracle_verify_blob(vx, blob, ocfg, 16)
     assert vx.lib.split_blob(blob)[1].size == 0
-    assert info["public_inputs"] == limbs(ch.trusted_hash) + limbs(out96[:32]) + [ch.trusted_block + 1, ch.target_block]
+    assert ia["public_inputs"] == limbs(ch.trusted_hash) + limbs(out96[:32]) + [ch.trusted_block + 1, ch.target_block, 16, 1]
+    assert ib["public_inputs"] == [int.from_bytes(out96[32 + 4 * j: 36 + 4 * j], "big") for j in range(16)]  # ALL 96 output bytes are public inputs of a proof
     # with a justification: accepted when > 2/3 signed the target, refused otherwise
     good = vx.lib.PackedJustification(vx.synth.Justification(ch.target_block, ch.target_hash, n_auth=9, n_signed=7), 12)
     o2, b2 = ctx.header_range_prove(ctx.from_host(ch.headers), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg, just=good)
-    assert o2 == out96 and (vx.lib.split_blob(b2)[0] == vx.lib.split_blob(blob)[0]).all()
+    assert o2 == out96 and (vx.lib.split_blob(b2)[0] == vx.lib.split_blob(blob)[0]).all() and (vx.lib.split_blob(b2)[2] == vx.lib.split_blob(blob)[2]).all()
     from oracle import sha_air as A
     S.register_air(A.ShaChainAir)
-    S.verify(vx.lib.split_blob(b2)[1], dict(S.DEFAULT_CFG, num_queries=12), expect_air=A.ID)
+    S.verify(vx.lib.split_blob(b2)[1], ocfg, expect_air=A.ID)
     vx.lib.header_range_verify(b2, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, o2, cfg, authority_set_hash=good.sh.tobytes())
     with pytest.raises(vx.VxError):
         vx.lib.header_range_verify(b2, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, o2, cfg, authority_set_hash=bytes(32))
@@ -147,6 +183,50 @@ def test_header_range_prove_end_to_end(ctx, vx, oracle):
     with pytest.raises(vx.VxError) as e:
         ctx.header_range_prove(ctx.from_host(h), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
     assert e.value.code == -5
+
+
+def test_merkle_roots_are_bound_by_the_proof(ctx, vx, oracle):
+    """all 96 output bytes are proven.  The two Merkle roots are public inputs of the Merkle table, whose
+    leaves come over the bus from the header bytes the hash-chain table hashed: a blob claiming any other state / data
+    root byte does not verify, nor does a Merkle proof transplanted from a different chain."""
+    ch = vx.synth.Chain(11, profile="Ptiny", stride=512)  # 11 of 16 leaves: zero leaves beyond the range
+    cfg = ctx.stark_config(num_queries=10)
+    out96, blob = ctx.header_range_prove(ctx.from_host(ch.headers), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
+    assert out96 == ch.expected_outputs(16)
+    vx.lib.header_range_verify(blob, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg)
+    oracle_verify_blob(vx, blob, dict(S.DEFAULT_CFG, num_queries=10), 16)
+    for byte in (32, 47, 63, 64, 80, 95):  # every region of the two roots
+        bad_out = bytearray(out96)
+        bad_out[byte] ^= 1
+        bad_blob = blob.copy()
+        bad_blob[4:16] = np.frombuffer(bytes(bad_out), dtype=np.uint64)
+        with pytest.raises(vx.VxError):
+            vx.lib.header_range_verify(bad_blob, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, bytes(bad_out), cfg)
+    # a Merkle proof from a different chain (other roots, internally consistent) next to this chain's hash-chain proof
+    other = vx.synth.Chain(11, profile="Ptiny", stride=512, seed=777)
+    o2, b2 = ctx.header_range_prove(ctx.from_host(other.headers), 512, other.sizes, 16, other.trusted_block, other.trusted_hash, other.target_block, cfg)
+    pa, _, _ = vx.lib.split_blob(blob)
+    _, _, pb = vx.lib.split_blob(b2)
+    franken = np.concatenate([blob[:16], np.array([pa.size, 0, pb.size], dtype=np.uint64), pa, pb])
+    fr_out = out96[:32] + o2[32:]
+    franken[4:16] = np.frombuffer(fr_out, dtype=np.uint64)
+    with pytest.raises(vx.VxError):
+        vx.lib.header_range_verify(franken, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, fr_out, cfg)
+
+
+def test_merkle_table_proof_bytes_match_reference_prover(ctx, vx, oracle):
+    """The Merkle table's proof inside a header_range blob == the coefficient-space reference prover's, byte for byte,
+    under the shared challenges (the other half of whose transcript is the GPU's hash-chain trace cap)."""
+    ch = vx.synth.Chain(5, profile="Ptiny", stride=512)
+    cfg, ocfg = ctx.stark_config(num_queries=9), dict(S.DEFAULT_CFG, num_queries=9)
+    out96, blob = ctx.header_range_prove(ctx.from_host(ch.headers), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
+    p_blake, _, p_tree = vx.lib.split_blob(blob)
+    pub_a, cap_a = S.proof_peek(p_blake, ocfg["cap_height"])
+    ttr, tpub = T.gen_trace(ch.state_roots, ch.data_roots, 16)
+    want = S.prove(TREE16, ttr, tpub, ocfg, chal_hook=lambda pub_b, cap_b: S.shared_challenges(pub_a, cap_a, pub_b, cap_b, 4))
+    assert p_tree.size == want.size
+    diff = np.nonzero(p_tree != want)[0]
+    assert diff.size == 0, f"first differing words {diff[:5]} of {want.size}"
 
 
 def test_product_verifier_on_gpu_proofs(ctx, vx):

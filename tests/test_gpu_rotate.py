@@ -79,7 +79,7 @@ def test_rotate_prove_small(ctx, vx):
     p0, p1, p2 = vx.lib.split_rotate_blob(blob)
     limbs = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "little") for j in range(8)]  # noqa: E731
     info = S.verify(p0, pcfg, expect_air=B.ID)
-    assert info["public_inputs"] == limbs(e.bytes[:32]) + limbs(e.hash) + [140000, 140000]
+    assert info["public_inputs"] == limbs(e.bytes[:32]) + limbs(e.hash) + [140000, 140000, 0, 0]  # stand-alone: nothing on the bus
     be = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "big") for j in range(8)]  # noqa: E731
     assert S.verify(p1, pcfg, expect_air=A.ID)["public_inputs"] == be(sj.authority_set_hash)
     assert S.verify(p2, pcfg, expect_air=A.ID)["public_inputs"] == be(out32)

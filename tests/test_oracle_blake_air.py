@@ -24,7 +24,7 @@ def make(lengths, trusted=hashlib.sha256(b"t").digest(), first=70000):
 
 
 def check(tr, pub):
-    aux, apub = A.gen_aux(tr, CHAL)
+    aux, apub = A.gen_aux(tr, CHAL, pub)
     return S.check_trace(A, tr, pub, CHAL, aux, apub)
 
 
@@ -37,9 +37,9 @@ def forged_trace(log_n):
     def forge(real, pad, tgt, last):
         junk = tgt + (4 * (last + 1) + 2).to_bytes(4, "little") + bytes(92) + bytes(40)  # 168 bytes = 2 chunks
         h0 = list(B.IVP)
-        b0 = dict(m=junk[:128], h=h0, t=128, inc=128, fin=False, first=True, act=1, D=tgt, num=last + 1)
+        b0 = dict(m=junk[:128], h=h0, t=128, inc=128, fin=False, first=True, act=1, D=tgt, num=last + 1, size=168)
         h1 = B.compress(h0, b0["m"], 128, False)[0]
-        b1 = dict(m=junk[128:] + bytes(88), h=h1, t=168, inc=40, fin=True, first=False, act=0, D=tgt, num=last + 1)
+        b1 = dict(m=junk[128:] + bytes(88), h=h1, t=168, inc=40, fin=True, first=False, act=0, D=tgt, num=last + 1, size=168)
         pad2 = dict(pad, m=tgt + (4 * (last + 1) + 2).to_bytes(4, "little") + bytes(92), num=last + 1)
         return real + [b0, b1, pad2], tgt, last + 1
 
@@ -50,10 +50,10 @@ def forged_trace(log_n):
 def test_trace_satisfies_constraints_and_detects_corruption(oracle):
     msgs, trusted, target = make([300, 129, 36])
     tr, pub, tgt = B.gen_trace(msgs, 16, trusted)
-    assert tgt == target and pub[16:] == [70000, 70002]
+    assert tgt == target and pub[16:] == [70000, 70002, 0, 0]
     assert int(tr[B.M1].sum()) == 160 * 65536 and int(tr[B.M2].sum()) == 48 * 65536  # lookups per row: 12/16 * 192 + 2/16 * 64 + 8, 12/16 * 64
-    aux, apub = A.gen_aux(tr, CHAL)
-    assert S.check_trace(A, tr, pub, CHAL, aux, apub) is None
+    aux, apub = A.gen_aux(tr, CHAL, pub)
+    assert apub == [0, 0] and S.check_trace(A, tr, pub, CHAL, aux, apub) is None  # stand-alone: nothing on the bus
     # single-cell corruptions of the main trace (auxiliary columns left as committed): some constraint next to the cell fails
     cells = ((B.GC(5, B.S_B1, 3), 20), (B.GC(2, B.S_L, 0), 37), (B.GC(2, B.S_T, 7), 37), (B.CAR(2, 0), 37), (B.MS(3, 1), 5), (B.D0 + 2, 40),
              (B.HL(3, 1), 30), (B.GC(1, B.S_D2, 4), 29), (B.GC(1, B.S_A2, 4), 30), (B.FIN, 70), (B.T, 17), (B.MB0 + 1, 3), (B.M1, 77), (B.M2, 5))
@@ -61,18 +61,20 @@ def test_trace_satisfies_constraints_and_detects_corruption(oracle):
         bad = tr.copy()
         bad[col, row] += np.uint64(1)
         assert S.check_trace(A, bad, pub, CHAL, aux, apub, rows=(max(0, row - 2), row + 2)) is not None, (col, row)
-    # a cheating prover recomputes the auxiliary columns: a wrong multiplicity, or a non-byte cell whose limb still adds up
-    # (+256 in one byte, -1 in the next), then breaks the cyclic running sum -- the logUp argument itself
+    # a cheating prover recomputes the auxiliary columns: with a wrong multiplicity, or a non-byte cell whose limb still adds
+    # up (+256 in one byte, -1 in the next), every row constraint can be met -- but the lookups no longer cancel against the
+    # tables, so the table's published bus total is not zero, and a stand-alone proof must publish zero (the verifier's rule)
     for edits in (((B.M1, 77, 1),), ((B.GC(6, B.S_A2, 2), 16 + 5, 256), (B.GC(6, B.S_A2, 3), 16 + 5, -1))):
         bad = tr.copy()
         for col, row, delta in edits:
             bad[col, row] = np.uint64(int(bad[col, row]) + delta)
-        v = check(bad, pub)
-        assert v is not None and v[0] >= 819, v  # the helper / running-sum constraints at the end of the list
+        aux2, apub2 = A.gen_aux(bad, CHAL, pub)
+        assert S.check_trace(A, bad, pub, CHAL, aux2, apub2) is None and apub2 != [0, 0]
+        assert S.check_trace(A, bad, pub, CHAL, aux2, [0, 0]) is not None  # claiming zero anyway breaks the running sum
     # wrong claimed target / block numbers
     assert S.check_trace(A, tr, pub[:8] + [pub[8] ^ 1] + pub[9:], CHAL, aux, apub, rows=(65530, 65536)) is not None
-    assert S.check_trace(A, tr, pub[:16] + [pub[16] + 1, pub[17]], CHAL, aux, apub, rows=(0, 4)) is not None
-    assert S.check_trace(A, tr, pub[:17] + [pub[17] + 1], CHAL, aux, apub, rows=(65530, 65536)) is not None
+    assert S.check_trace(A, tr, pub[:16] + [pub[16] + 1] + pub[17:], CHAL, aux, apub, rows=(0, 4)) is not None
+    assert S.check_trace(A, tr, pub[:17] + [pub[17] + 1] + pub[18:], CHAL, aux, apub, rows=(65530, 65536)) is not None
 
 
 def test_prove_verify(blake_proof):

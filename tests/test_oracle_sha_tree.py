@@ -1,0 +1,98 @@
+"""ShaTreeAir restatement (CPU): the SHA-256 Merkle table satisfies every constraint, its roots are the native mirror's
+(circuits/input/mod.rs:464-528), the logUp bus balances against the Blake2b header-chain table for the same headers and
+breaks when a root byte is changed on either side, and the reference prover / verifier round-trip under external
+(shared) challenges."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import blake_air as B
+from oracle import sha_tree_air as T
+from oracle import stark_ref as S
+
+P = B.P
+CHAL = [0x0123456789ABCDEF, 0x0FEDCBA987654321, 0x1111111122222222, 0x3333333344444444]
+N = 16
+A = T.make_air(N)
+S.register_air(A)
+
+
+def make(lengths, trusted=hashlib.sha256(b"t").digest(), first=70000):
+    msgs, d = [], trusted
+    for k, n in enumerate(lengths):
+        m = d + (4 * (first + k) + 2).to_bytes(4, "little") + bytes((3 * i + n) & 0xFF for i in range(n - 36))
+        msgs.append(m)
+        d = hashlib.blake2b(m, digest_size=32).digest()
+    return msgs, trusted, d
+
+
+def mirror_root(leaves, n):
+    nodes = list(leaves) + [bytes(32)] * (n - len(leaves))
+    while len(nodes) > 1:
+        nodes = [hashlib.sha256(nodes[i] + nodes[i + 1]).digest() for i in range(0, len(nodes), 2)]
+    return [int.from_bytes(nodes[0][4 * j: 4 * j + 4], "big") for j in range(8)]
+
+
+def balance(apub_a, n_a, apub_b, n_b):
+    return [(apub_a[i] * n_a + apub_b[i] * n_b) % P for i in range(2)]
+
+
+def test_tree_constraints_roots_and_bus_balance(oracle):
+    msgs, trusted, _ = make([300, 129, 72, 131, 500])  # 72: state root and data root overlap; leaves 5..15 are zero leaves
+    sr, dr = [m[36:68] for m in msgs], [m[-32:] for m in msgs]
+    ttr, tpub = T.gen_trace(sr, dr, N)
+    assert tpub == mirror_root(sr, N) + mirror_root(dr, N)
+    taux, apub_b = A.gen_aux(ttr, CHAL, tpub)
+    assert S.check_trace(A, ttr, tpub, CHAL, taux, apub_b) is None
+    # the hash-chain table for the same headers puts exactly what the tree takes on the bus
+    tr, pub, _ = B.gen_trace(msgs, 16, trusted, tree_size=N)
+    assert pub[18:] == [N, 1]
+    aux, apub_a = B.BlakeChainAir.gen_aux(tr, CHAL, pub)
+    assert S.check_trace(B.BlakeChainAir, tr, pub, CHAL, aux, apub_a, rows=(0, 200)) is None
+    assert balance(apub_a, 1 << 16, apub_b, 256 * N) == [0, 0]
+    # a tree over different leaves (one state-root byte, one data-root byte changed) satisfies ITS constraints but not the bus
+    for which in (0, 1):
+        sr2, dr2 = [bytes(x) for x in sr], [bytes(x) for x in dr]
+        tgt = sr2 if which == 0 else dr2
+        tgt[2] = tgt[2][:5] + bytes([tgt[2][5] ^ 1]) + tgt[2][6:]
+        t2, p2 = T.gen_trace(sr2, dr2, N)
+        a2, ap2 = A.gen_aux(t2, CHAL, p2)
+        assert S.check_trace(A, t2, p2, CHAL, a2, ap2) is None and p2 != tpub
+        assert balance(apub_a, 1 << 16, ap2, 256 * N) != [0, 0]
+    # enabling a leaf nobody sent, or disabling one that was sent, breaks the balance too
+    for col, leaf in ((T.ENR, 5), (T.ENL, 4)):
+        g = (N + leaf) // 2
+        t2 = ttr.copy()
+        rows = slice(128 * g, 128 * g + 128)
+        t2[col, rows] = 1 - t2[col, rows]
+        a2, ap2 = A.gen_aux(t2, CHAL, tpub)
+        assert balance(apub_a, 1 << 16, ap2, 256 * N) != [0, 0] or S.check_trace(A, t2, tpub, CHAL, a2, ap2) is not None
+    # single-cell corruptions of the tree trace
+    for col, row in ((T.H.ST(2, 7), 300), (T.H.WW(0, 3), 128 * 9 + 2), (T.H.FFB(1, 0), 128 * 3 + 127), (T.H.HIN0 + 2, 128 * 5 + 70)):
+        bad = ttr.copy()
+        bad[col, row] ^= np.uint64(1)
+        assert S.check_trace(A, bad, tpub, CHAL, taux, apub_b, rows=(max(0, row - 2), row + 2)) is not None, (col, row)
+    assert S.check_trace(A, ttr, [tpub[0] ^ 1] + tpub[1:], CHAL, taux, apub_b, rows=(128 + 127, 128 + 128)) is not None  # wrong claimed root
+
+
+def test_tree_prove_verify_under_shared_challenges(oracle):
+    msgs, _, _ = make([200, 90, 300])
+    ttr, tpub = T.gen_trace([m[36:68] for m in msgs], [m[-32:] for m in msgs], N)
+    cfg = dict(S.DEFAULT_CFG, num_queries=8)
+    seen = {}
+
+    def hook(pub, cap):
+        seen["cap"] = np.array(cap, dtype=np.uint64)
+        return S.shared_challenges([1, 2, 3], np.arange(64, dtype=np.uint64), pub, cap, 4)  # a stand-in for the other table
+
+    proof = S.prove(A, ttr, tpub, cfg, chal_hook=hook)
+    pub_b, cap_b = S.proof_peek(proof, cfg["cap_height"])
+    assert pub_b == tpub and (cap_b == seen["cap"]).all()
+    chal = S.shared_challenges([1, 2, 3], np.arange(64, dtype=np.uint64), pub_b, cap_b, 4)
+    info = S.verify(proof, cfg, expect_air=A.ID, expect_public=tpub, ext_chal=chal)
+    assert any(info["aux_public"])  # this table takes leaves from the bus: its total is not zero ...
+    with pytest.raises(S.VerifyError):  # ... so it is no proof on its own
+        S.verify(proof, cfg)
+    with pytest.raises(S.VerifyError):  # and other challenges do not fit the transcript
+        S.verify(proof, cfg, ext_chal=[c ^ 1 for c in chal])
