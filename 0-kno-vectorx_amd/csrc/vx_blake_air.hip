@@ -11,6 +11,8 @@
 #include <string.h>
 
 #include "air_blake.cuh"
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 #include "vx_internal.h"
@@ -659,6 +661,8 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
                               const vx_justification* just, const vx_stark_config* cfg, uint8_t out96[96], uint64_t* proof_out,
                               size_t proof_cap, size_t* proof_len) {
     if (!ctx || !cfg || !proof_len || !out96) return VX_ERR_ARG;
+    const int tree_id = tree_air_id(max_headers);
+    VX_CHECK(tree_id, "header_range: max_headers %u has no Merkle AIR (16, 256 or 512)", max_headers);
     // 1. statement + public outputs (map/reduce chain rules, Merkle roots)
     VX_TRY(vx_verify_subchain(ctx, headers, stride, sizes, n_fetched, max_headers, trusted_block, trusted_hash, target_block, out96));
     // 1b. the target header is justified by > 2/3 of the committed authority set (header_range.rs:49-54): checked on
@@ -703,8 +707,6 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
     // 2. Blake2b parent-hash-chain STARK over every compression of every header, and -- on the same logUp bus, under
     //    shared lookup challenges -- the SHA-256 Merkle AIR that turns the state / data roots of those very header bytes
     //    (decoder.rs:121-149) into the two output roots (subchain_verification.rs:213-220, 268-274)
-    const int tree_id = tree_air_id(max_headers);
-    VX_CHECK(tree_id, "header_range: max_headers %u has no Merkle AIR (16, 256 or 512)", max_headers);
     size_t chunks = 0;
     for (size_t i = 0; i < n_fetched; ++i) chunks += (sizes[i] + 127) / 128;
     int log_n = blk::TABLE_LOG;  // at least one copy of the lookup tables
@@ -714,70 +716,101 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
     std::vector<uint32_t> numbers(n_fetched);
     std::vector<uint8_t> modes(n_fetched), oks(n_fetched), parents(32 * n_fetched), sroots(32 * n_fetched), droots(32 * n_fetched);
     int32_t rc = vx_decode_header_batch(ctx, headers, stride, sizes, n_fetched, numbers.data(), modes.data(), oks.data(), parents.data(), sroots.data(), droots.data());
-    vx_buf *trace = nullptr, *ttrace = nullptr;
-    if (rc == VX_OK) rc = vx_alloc(ctx, ((size_t)blk::COLS) << log_n, &trace);
-    if (rc == VX_OK) rc = vx_alloc(ctx, ((size_t)VX_SHA_AIR_COLS) << tl, &ttrace);
-    uint64_t pub[20], tpub[16];
-    if (rc == VX_OK) rc = vx_blake_chain_trace(ctx, headers, stride, sizes, n_fetched, trusted_hash, trusted_block + 1, max_headers, log_n, trace, pub, nullptr);
-    if (rc == VX_OK) rc = vx_sha_tree_trace_dev(ctx, sroots.data(), droots.data(), n_fetched, tl - 8, ttrace->d, tpub);
+    // The two tables share their lookup challenges: each prover stops after its trace cap (the challenge hook) and waits
+    // for the other's cap; both then derive the same challenges from (hash-chain pub, cap, Merkle pub, cap).  The Merkle
+    // table is small, so it is proven on a further side context from its own host thread while this context proves the
+    // hash chain -- a rendezvous, not a nesting.
+    struct Rendezvous {
+        std::mutex m;
+        std::condition_variable cv;
+        bool have[2] = {false, false}, failed = false;
+        std::vector<uint64_t> pub[2], cap[2];
+        static int32_t meet(Rendezvous* r, int who, const uint64_t* pub, size_t n_pub, const uint64_t* cap, size_t cap_words, uint64_t* chal, size_t n_chal) {
+            std::unique_lock<std::mutex> lk(r->m);
+            r->pub[who].assign(pub, pub + n_pub);
+            r->cap[who].assign(cap, cap + cap_words);
+            r->have[who] = true;
+            r->cv.notify_all();
+            r->cv.wait(lk, [&] { return r->have[1 - who] || r->failed; });
+            if (!r->have[1 - who]) return VX_ERR_STATEMENT;  // the other table's prover gave up
+            uint64_t c[4];
+            vx_shared_challenges(r->pub[0].data(), r->pub[0].size(), r->cap[0].data(), r->pub[1].data(), r->pub[1].size(), r->cap[1].data(), cap_words, c, 4);
+            for (size_t q = 0; q < n_chal && q < 4; ++q) chal[q] = c[q];
+            return VX_OK;
+        }
+        void fail() {
+            std::lock_guard<std::mutex> lk(m);
+            failed = true;
+            cv.notify_all();
+        }
+    } rv;
+    const vx_chal_hook hook_a{[](void* u, const uint64_t* pub, size_t n_pub, const uint64_t* cap, size_t cw, uint64_t* chal, size_t n_chal) -> int32_t {
+                                  return Rendezvous::meet((Rendezvous*)u, 0, pub, n_pub, cap, cw, chal, n_chal);
+                              },
+                              &rv};
+    const vx_chal_hook hook_b{[](void* u, const uint64_t* pub, size_t n_pub, const uint64_t* cap, size_t cw, uint64_t* chal, size_t n_chal) -> int32_t {
+                                  return Rendezvous::meet((Rendezvous*)u, 1, pub, n_pub, cap, cw, chal, n_chal);
+                              },
+                              &rv};
+    std::vector<uint64_t> tree_proof;
+    size_t len3 = 0;
+    uint64_t tpub[16];
+    int32_t rc_tree = VX_OK;
+    auto prove_tree = [&](vx_ctx* c) -> int32_t {
+        (void)hipSetDevice(c->device);
+        vx_buf* tt = nullptr;
+        int32_t r = vx_alloc(c, ((size_t)VX_SHA_AIR_COLS) << tl, &tt);
+        if (r == VX_OK) r = vx_sha_tree_trace_dev(c, sroots.data(), droots.data(), n_fetched, tl - 8, tt->d, tpub);
+        if (r == VX_OK) {
+            uint8_t roots[64];
+            for (int j = 0; j < 16; ++j)
+                for (int b = 0; b < 4; ++b) roots[4 * j + b] = (uint8_t)(tpub[j] >> (24 - 8 * b));
+            if (memcmp(roots, out96 + 32, 64) != 0) r = vx_fail(c, VX_ERR_STATEMENT, "header_range: Merkle AIR roots differ from the subchain roots");
+        }
+        size_t bound = 0;
+        if (r == VX_OK) r = vx_stark_proof_bound(tree_id, cfg, tl, &bound);
+        if (r == VX_OK) {
+            tree_proof.resize(bound);
+            r = vx_stark_prove_impl(c, tree_id, cfg, tt->d, tt->n, /*consume_trace=*/0, tl, tpub, 16, tree_proof.data(), tree_proof.size(), &len3, &hook_b);
+        }
+        if (tt) (void)vx_free(c, tt);
+        if (r != VX_OK) rv.fail();
+        return r;
+    };
+    std::thread tree_thread;
+    vx_ctx* side2 = nullptr;
     if (rc == VX_OK) {
-        uint8_t tgt[32], roots[64];
+        vx_ctx* s1 = vx_side_ctx(ctx);
+        side2 = s1 ? vx_side_ctx(s1) : nullptr;
+        if (side2) {
+            try {
+                tree_thread = std::thread([&] { rc_tree = prove_tree(side2); });
+            } catch (...) {
+                side2 = nullptr;
+            }
+        }
+        if (!side2) rc = vx_fail(ctx, VX_ERR_DEVICE, "header_range: no side context / host thread for the Merkle table (the two provers meet at their challenge hooks)");
+    }
+    vx_buf* trace = nullptr;
+    if (rc == VX_OK) rc = vx_alloc(ctx, ((size_t)blk::COLS) << log_n, &trace);
+    uint64_t pub[20];
+    if (rc == VX_OK) rc = vx_blake_chain_trace(ctx, headers, stride, sizes, n_fetched, trusted_hash, trusted_block + 1, max_headers, log_n, trace, pub, nullptr);
+    if (rc == VX_OK) {
+        uint8_t tgt[32];
         for (int j = 0; j < 8; ++j) {
             uint32_t l = (uint32_t)pub[8 + j];
             memcpy(tgt + 4 * j, &l, 4);
         }
-        for (int j = 0; j < 16; ++j)
-            for (int b = 0; b < 4; ++b) roots[4 * j + b] = (uint8_t)(tpub[j] >> (24 - 8 * b));
         if (memcmp(tgt, out96, 32) != 0) rc = vx_fail(ctx, VX_ERR_STATEMENT, "header_range: chain digest differs from the subchain target hash");
-        else if (memcmp(roots, out96 + 32, 64) != 0) rc = vx_fail(ctx, VX_ERR_STATEMENT, "header_range: Merkle AIR roots differ from the subchain roots");
     }
-    // The hash-chain prover stops after its trace cap and asks for the shared challenges: that is where the Merkle table
-    // is proven (its own trace cap is the other half of the challenge transcript).
-    struct Shared {
-        vx_ctx* ctx;
-        const vx_stark_config* cfg;
-        int tree_id, tl;
-        vx_buf* ttrace;
-        const uint64_t* tpub;
-        const uint64_t *pub_a, *cap_a;
-        size_t n_pub_a;
-        uint64_t chal[4];
-        std::vector<uint64_t> tree_proof;
-        size_t len3;
-        int32_t rc;
-    } sh{ctx, cfg, tree_id, tl, ttrace, tpub, nullptr, nullptr, 0, {0, 0, 0, 0}, {}, 0, VX_OK};
-    const vx_chal_hook hook_b{[](void* u, const uint64_t* pub_b, size_t n_pub_b, const uint64_t* cap_b, size_t cap_words, uint64_t* chal, size_t n_chal) -> int32_t {
-                                  Shared* s = (Shared*)u;
-                                  vx_shared_challenges(s->pub_a, s->n_pub_a, s->cap_a, pub_b, n_pub_b, cap_b, cap_words, s->chal, 4);
-                                  for (size_t q = 0; q < n_chal && q < 4; ++q) chal[q] = s->chal[q];
-                                  return VX_OK;
-                              },
-                              &sh};
-    struct HookA {
-        Shared* s;
-        const vx_chal_hook* hb;
-    } ha{&sh, &hook_b};
-    const vx_chal_hook hook_a{[](void* u, const uint64_t* pub_a, size_t n_pub_a, const uint64_t* cap_a, size_t, uint64_t* chal, size_t n_chal) -> int32_t {
-                                  HookA* h = (HookA*)u;
-                                  Shared* s = h->s;
-                                  s->pub_a = pub_a, s->n_pub_a = n_pub_a, s->cap_a = cap_a;
-                                  size_t bound = 0;
-                                  int32_t r = vx_stark_proof_bound(s->tree_id, s->cfg, s->tl, &bound);
-                                  if (r != VX_OK) return r;
-                                  s->tree_proof.resize(bound);
-                                  r = vx_stark_prove_impl(s->ctx, s->tree_id, s->cfg, s->ttrace->d, s->ttrace->n, /*consume_trace=*/0, s->tl, s->tpub, 16,
-                                                          s->tree_proof.data(), s->tree_proof.size(), &s->len3, h->hb);
-                                  if (r != VX_OK) return r;
-                                  for (size_t q = 0; q < n_chal && q < 4; ++q) chal[q] = s->chal[q];
-                                  return VX_OK;
-                              },
-                              &ha};
     if (rc == VX_OK)
         rc = vx_stark_prove_impl(ctx, VX_AIR_BLAKE_CHAIN, cfg, trace->d, trace->n, /*consume_trace=*/1, log_n, pub, 20, room ? proof_out + VX_HR_HDR : nullptr,
                                  room ? proof_cap - VX_HR_HDR : 0, &len1, &hook_a);
+    if (rc != VX_OK && rc != VX_ERR_BUFSZ) rv.fail();  // do not leave the Merkle prover waiting at its hook
     if (trace) (void)vx_free(ctx, trace);
-    if (ttrace) (void)vx_free(ctx, ttrace);
-    const size_t len3 = sh.len3;
+    if (tree_thread.joinable()) tree_thread.join();
+    if (rc_tree != VX_OK && side2) (void)vx_fail(ctx, rc_tree, "%s", vx_last_error(side2));
+    if ((rc == VX_OK || rc == VX_ERR_BUFSZ) && rc_tree != VX_OK) rc = rc_tree;
     if (sha_thread.joinable()) sha_thread.join();
     else if (just) rc_sha = prove_sha(ctx);  // no side context: one after the other
     if (just) {
@@ -788,7 +821,7 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
     if (rc == VX_OK) {
         if (proof_out && proof_cap >= *proof_len) {
             if (len2) memcpy(proof_out + VX_HR_HDR + len1, sha_proof.data(), len2 * 8);
-            memcpy(proof_out + VX_HR_HDR + len1 + len2, sh.tree_proof.data(), len3 * 8);
+            memcpy(proof_out + VX_HR_HDR + len1 + len2, tree_proof.data(), len3 * 8);
         } else rc = vx_fail(ctx, VX_ERR_BUFSZ, "header_range: proof needs %zu words, buffer has %zu", *proof_len, proof_cap);
     }
     if (rc != VX_OK) return rc;
