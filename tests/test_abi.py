@@ -45,3 +45,16 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cuh", ".cpp")) or f == "Makefile":
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "vxo_" not in src and "libvxoracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_integration_md_rust_block_is_generated_from_the_header():
+    """INTEGRATION.md's `extern "C"` block is generated from include/vx.h and names every declared symbol
+    (it used to claim a one-to-one mirror while omitting a dozen entry points)."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_bindings.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name in declared_symbols():
+        assert f"pub fn {name}(" in text, name
