@@ -4,18 +4,24 @@
 // native mirror circuits/input/mod.rs:250-260).  The reference proves SHA-256 with curta's STARK
 // (starkyx v1.0.0, not vendored); this AIR is a from-scratch FIPS 180-4 arithmetisation, degree <= 3:
 // one row per round, 64 rows per compression; three-input XORs as x + y + z = r + 2c, Ch as a
-// degree-2 expression, Maj through (maj, parity) bits; block types FIRST / DATA / PAD / IDLE.
+// degree-2 expression, Maj through (maj, parity) bits; block types FIRST / DATA / PAD / IDLE.  731 columns: only the
+// words an XOR / AND reads are bit-decomposed (see the layout note); the compression rows are shared with ShaTreeAir.
 // Constraint ORDER is protocol: oracle/sha_air.py restates it independently.
 #pragma once
 #include "air.cuh"
 
 namespace shc {
-constexpr int NA0 = 256, NE0 = 288, W0 = 320, S0R = 832, S0C = 864, S1R = 896, S1C = 928, E1R = 960, E1C = 992, A0R = 1024, A0C = 1056;
-constexpr int MAJ = 1088, PAR = 1120, CE0 = 1152, CA0 = 1155, CW0 = 1158, FF0 = 1160, FFC0 = 1416, HIN0 = 1424, DG0 = 1432;
-constexpr int T_FIRST = 1440, T_DATA = 1441, T_PAD = 1442, T_IDLE = 1443, COLS = 1444;
-VX_HD constexpr int ST(int w, int i) { return 32 * w + i; }
-VX_HD constexpr int WW(int j, int i) { return W0 + 32 * j + i; }
-VX_HD constexpr int FFB(int w, int i) { return FF0 + 32 * w + i; }
+// Column layout.  Only the words an XOR / AND needs exist as 32 little-endian bit columns: a, b, c, e, f, g of the state
+// (Sigma0, Maj / Sigma1, Ch), the new a and e, and positions 0, 1, 14 of the 16-word schedule window (w_r enters T1 and a
+// bus, sigma0 reads w_{r+1}, sigma1 reads w_{r+14}).  d, h and the other 13 window positions are single VALUE columns:
+// every such value was, or will be, a bit-decomposed word on another row, and everything downstream works modulo 2^32.
+constexpr int A_ = 0, B_ = 32, C_ = 64, E_ = 96, F_ = 128, G_ = 160, DV = 192, HV = 193, NA0 = 194, NE0 = 226;
+constexpr int W0B = 258, W1B = 290, W14B = 322, WV0 = 354, WV15 = 366;
+constexpr int S0R = 367, S0C = 399, S1R = 431, S1C = 463, E1R = 495, E1C = 527, A0R = 559, A0C = 591, MAJ = 623, PAR = 655;
+constexpr int CE0 = 687, CA0 = 690, CW0 = 693, FFV0 = 695, FFC0 = 703, HIN0 = 711, DG0 = 719;
+constexpr int T_FIRST = 727, T_DATA = 728, T_PAD = 729, T_IDLE = 730, COLS = 731;
+VX_HD constexpr int WV(int p) { return p == 15 ? WV15 : WV0 + p - 2; }  // value column of window position p (2..13, 15)
+VX_HD constexpr int st_bits(int wd) { return wd == 0 ? A_ : wd == 1 ? B_ : wd == 2 ? C_ : wd == 4 ? E_ : wd == 5 ? F_ : wd == 6 ? G_ : -1; }
 #define SHC_IV_INIT {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19}
 #define SHC_K_INIT {0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, \
     0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, \
@@ -38,6 +44,101 @@ VX_HD constexpr uint32_t tail32(int j) { return j == 0 ? 0x80000000u : (j == 7 ?
 VX_HD constexpr uint32_t pad64(int j) { return j == 0 ? 0x80000000u : (j == 15 ? 512u : 0u); }
 }  // namespace shc
 
+// Sections 1-7 shared by every SHA-256 table: the rows of a compression and the hand-over at a block boundary.
+// data_flag: 1 where the block AFTER the local one continues from its output (DATA -> PAD), else it starts from IV.
+template <class F, class Row, class C>
+__host__ __device__ inline void sha_compression_constraints(const Row& loc, const Row& nxt, const F* per, const F& data_flag, C& c) {
+    using namespace shc;
+    const F sel0 = per[0], sel63 = per[1], sched_on = per[2], kr = per[3];
+    const F one = F::from(1), two = F::from(2), two32 = F::from(1ULL << 32);
+    const F in_block = one - sel63;
+    auto val = [&](const Row& row, int col0, int nb) -> F {
+        F acc = row[col0 + nb - 1];
+#pragma unroll 1
+        for (int i = nb - 2; i >= 0; --i) acc = acc + acc + row[col0 + i];
+        return acc;
+    };
+    auto window = [&](const Row& row, int p) -> F { return p == 0 ? val(row, W0B, 32) : p == 1 ? val(row, W1B, 32) : p == 14 ? val(row, W14B, 32) : row[WV(p)]; };
+    auto state_word = [&](const Row& row, int wd) -> F { return wd == 3 ? row[DV] : wd == 7 ? row[HV] : val(row, st_bits(wd), 32); };
+    // ---- 1. booleans
+    {
+        const int lo[4] = {0, NA0, S0R, FFC0}, hi[4] = {DV, WV0, FFV0, HIN0};
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q)
+#pragma unroll 1
+            for (int col = lo[q]; col < hi[q]; ++col) {
+                const F x = loc[col];
+                c.constraint(x * (x - one));
+            }
+    }
+    // ---- 2. three-input XORs: x + y + z = r + 2c
+    auto xor3 = [&](int col0, int r0, int r1, int r2, int shift, int colr, int colc) {
+#pragma unroll 1
+        for (int i = 0; i < 32; ++i) {
+            F acc = loc[col0 + ((i + r0) & 31)] + loc[col0 + ((i + r1) & 31)];
+            if (shift < 0) acc = acc + loc[col0 + ((i + r2) & 31)];
+            else if (i + shift < 32) acc = acc + loc[col0 + i + shift];
+            c.constraint(acc - loc[colr + i] - two * loc[colc + i]);
+        }
+    };
+    xor3(W1B, 7, 18, 0, 3, S0R, S0C);
+    xor3(W14B, 17, 19, 0, 10, S1R, S1C);
+    xor3(E_, 6, 11, 25, -1, E1R, E1C);
+    xor3(A_, 2, 13, 22, -1, A0R, A0C);
+#pragma unroll 1
+    for (int i = 0; i < 32; ++i) c.constraint(loc[A_ + i] + loc[B_ + i] + loc[C_ + i] - two * loc[MAJ + i] - loc[PAR + i]);
+    // ---- 3. the round
+    {
+        F ch = F::from(0);
+#pragma unroll 1
+        for (int i = 31; i >= 0; --i) {
+            const F e = loc[E_ + i], f = loc[F_ + i], g = loc[G_ + i];
+            ch = ch + ch + (e * f + (one - e) * g);
+        }
+        const F t1 = loc[HV] + val(loc, E1R, 32) + ch + kr + val(loc, W0B, 32);
+        c.constraint(val(loc, NE0, 32) + two32 * val(loc, CE0, 3) - (loc[DV] + t1));
+        c.constraint(val(loc, NA0, 32) + two32 * val(loc, CA0, 3) - (t1 + val(loc, A0R, 32) + val(loc, MAJ, 32)));
+    }
+    // ---- 4. state shift inside a block
+#pragma unroll 1
+    for (int i = 0; i < 32; ++i) {
+        c.constraint(in_block * (nxt[A_ + i] - loc[NA0 + i]));
+        c.constraint(in_block * (nxt[E_ + i] - loc[NE0 + i]));
+        c.constraint(in_block * (nxt[B_ + i] - loc[A_ + i]));
+        c.constraint(in_block * (nxt[C_ + i] - loc[B_ + i]));
+        c.constraint(in_block * (nxt[F_ + i] - loc[E_ + i]));
+        c.constraint(in_block * (nxt[G_ + i] - loc[F_ + i]));
+    }
+    c.constraint(in_block * (nxt[DV] - val(loc, C_, 32)));
+    c.constraint(in_block * (nxt[HV] - val(loc, G_, 32)));
+    // ---- 5. message schedule: window shift, and w_{r+16} while r <= 47
+#pragma unroll 1
+    for (int i = 0; i < 32; ++i) c.constraint(in_block * (nxt[W0B + i] - loc[W1B + i]));
+#pragma unroll 1
+    for (int p = 1; p < 15; ++p) c.constraint(in_block * (window(nxt, p) - window(loc, p + 1)));
+    c.constraint(sched_on * (nxt[WV15] + two32 * val(loc, CW0, 2) - (val(loc, S1R, 32) + loc[WV(9)] + val(loc, S0R, 32) + val(loc, W0B, 32))));
+    // ---- 6. feed-forward at r = 63: FF = H_in + (NA, a, b, c, NE, e, f, g)
+    {
+        const int s64[8] = {NA0, A_, B_, C_, NE0, E_, F_, G_};
+#pragma unroll 1
+        for (int wd = 0; wd < 8; ++wd) c.constraint(sel63 * (loc[FFV0 + wd] + two32 * loc[FFC0 + wd] - (loc[HIN0 + wd] + val(loc, s64[wd], 32))));
+    }
+    // ---- 7. block boundary: next start state = FF where data_flag, IV otherwise; H_in register
+#pragma unroll 1
+    for (int wd = 0; wd < 8; ++wd) {
+        const int sb = st_bits(wd);
+        if (sb >= 0) {
+#pragma unroll 1
+            for (int i = 0; i < 32; ++i) c.constraint(sel63 * (one - data_flag) * (nxt[sb + i] - F::from((uint64_t)((iv(wd) >> i) & 1))));
+            c.constraint(sel63 * data_flag * (val(nxt, sb, 32) - loc[FFV0 + wd]));
+        } else {
+            c.constraint(sel63 * (state_word(nxt, wd) - (data_flag * loc[FFV0 + wd] + (one - data_flag) * F::from((uint64_t)iv(wd)))));
+        }
+        c.constraint(sel0 * (loc[HIN0 + wd] - state_word(loc, wd)));
+        c.constraint(in_block * (nxt[HIN0 + wd] - loc[HIN0 + wd]));
+    }
+}
+
 struct ShaAir {
     static constexpr int ID = 4, COLS = shc::COLS, PUB = 8, PERIODIC = 4, PERIOD_LOG = 6, QUOT_ROWS_PER_LANE = 1, AUX = 0, CHAL = 0, AUXPUB = 0;
     static constexpr int plog(int) { return 6; }
@@ -45,8 +146,8 @@ struct ShaAir {
     template <class F, class Row, class C>
     __host__ __device__ static void eval(const Row& loc, const Row& nxt, const F* per, const F* pub, const F*, const F*, C& c) {
         using namespace shc;
-        const F sel0 = per[0], sel63 = per[1], sched_on = per[2], kr = per[3];
-        const F one = F::from(1), two = F::from(2), two32 = F::from(1ULL << 32);
+        const F sel0 = per[0], sel63 = per[1];
+        const F one = F::from(1);
         const F in_block = one - sel63;
         auto val = [&](const Row& row, int col0, int nb) -> F {
             F acc = row[col0 + nb - 1];
@@ -54,90 +155,20 @@ struct ShaAir {
             for (int i = nb - 2; i >= 0; --i) acc = acc + acc + row[col0 + i];
             return acc;
         };
-        // ---- 1. booleans
+        auto window = [&](const Row& row, int p) -> F { return p == 0 ? val(row, W0B, 32) : p == 1 ? val(row, W1B, 32) : p == 14 ? val(row, W14B, 32) : row[WV(p)]; };
+        // ---- 0. the four type flags
+        const int t[4] = {T_FIRST, T_DATA, T_PAD, T_IDLE};
 #pragma unroll 1
-        for (int col = 0; col < HIN0; ++col) {
-            const F x = loc[col];
+        for (int q = 0; q < 4; ++q) {
+            const F x = loc[t[q]];
             c.constraint(x * (x - one));
         }
-        {
-            const int t[4] = {T_FIRST, T_DATA, T_PAD, T_IDLE};
-#pragma unroll 1
-            for (int q = 0; q < 4; ++q) {
-                const F x = loc[t[q]];
-                c.constraint(x * (x - one));
-            }
-        }
         c.constraint(loc[T_FIRST] + loc[T_DATA] + loc[T_PAD] + loc[T_IDLE] - one);
-        // ---- 2. three-input XORs: x + y + z = r + 2c
-        auto xor3 = [&](int col0, int r0, int r1, int r2, int shift, int colr, int colc) {
-#pragma unroll 1
-            for (int i = 0; i < 32; ++i) {
-                F acc = loc[col0 + ((i + r0) & 31)] + loc[col0 + ((i + r1) & 31)];
-                if (shift < 0) acc = acc + loc[col0 + ((i + r2) & 31)];
-                else if (i + shift < 32) acc = acc + loc[col0 + i + shift];
-                c.constraint(acc - loc[colr + i] - two * loc[colc + i]);
-            }
-        };
-        xor3(WW(1, 0), 7, 18, 0, 3, S0R, S0C);
-        xor3(WW(14, 0), 17, 19, 0, 10, S1R, S1C);
-        xor3(ST(4, 0), 6, 11, 25, -1, E1R, E1C);
-        xor3(ST(0, 0), 2, 13, 22, -1, A0R, A0C);
-#pragma unroll 1
-        for (int i = 0; i < 32; ++i) c.constraint(loc[ST(0, i)] + loc[ST(1, i)] + loc[ST(2, i)] - two * loc[MAJ + i] - loc[PAR + i]);
-        // ---- 3. the round
-        {
-            F ch = F::from(0);
-#pragma unroll 1
-            for (int i = 31; i >= 0; --i) {
-                const F e = loc[ST(4, i)], f = loc[ST(5, i)], g = loc[ST(6, i)];
-                ch = ch + ch + (e * f + (one - e) * g);
-            }
-            const F t1 = val(loc, ST(7, 0), 32) + val(loc, E1R, 32) + ch + kr + val(loc, WW(0, 0), 32);
-            c.constraint(val(loc, NE0, 32) + two32 * val(loc, CE0, 3) - (val(loc, ST(3, 0), 32) + t1));
-            c.constraint(val(loc, NA0, 32) + two32 * val(loc, CA0, 3) - (t1 + val(loc, A0R, 32) + val(loc, MAJ, 32)));
-        }
-        // ---- 4. state shift inside a block
-#pragma unroll 1
-        for (int i = 0; i < 32; ++i) {
-            c.constraint(in_block * (nxt[ST(0, i)] - loc[NA0 + i]));
-            c.constraint(in_block * (nxt[ST(4, i)] - loc[NE0 + i]));
-            const int wds[6] = {1, 2, 3, 5, 6, 7};
-#pragma unroll 1
-            for (int q = 0; q < 6; ++q) c.constraint(in_block * (nxt[ST(wds[q], i)] - loc[ST(wds[q] - 1, i)]));
-        }
-        // ---- 5. message schedule
-#pragma unroll 1
-        for (int j = 0; j < 15; ++j)
-#pragma unroll 1
-            for (int i = 0; i < 32; ++i) c.constraint(in_block * (nxt[WW(j, i)] - loc[WW(j + 1, i)]));
-        c.constraint(sched_on * (val(nxt, WW(15, 0), 32) + two32 * val(loc, CW0, 2) -
-                                 (val(loc, S1R, 32) + val(loc, WW(9, 0), 32) + val(loc, S0R, 32) + val(loc, WW(0, 0), 32))));
-        // ---- 6. feed-forward at r = 63
-        {
-            const int s64[8] = {NA0, ST(0, 0), ST(1, 0), ST(2, 0), NE0, ST(4, 0), ST(5, 0), ST(6, 0)};
-#pragma unroll 1
-            for (int wd = 0; wd < 8; ++wd)
-                c.constraint(sel63 * (val(loc, FFB(wd, 0), 32) + two32 * loc[FFC0 + wd] - (loc[HIN0 + wd] + val(loc, s64[wd], 32))));
-        }
-        // ---- 7. block boundary
         const F tdata = loc[T_DATA];
-#pragma unroll 1
-        for (int wd = 0; wd < 8; ++wd) {
-#pragma unroll 1
-            for (int i = 0; i < 32; ++i) {
-                const F ivb = F::from((uint64_t)((iv(wd) >> i) & 1));
-                c.constraint(sel63 * (nxt[ST(wd, i)] - (tdata * loc[FFB(wd, i)] + (one - tdata) * ivb)));
-            }
-            c.constraint(sel0 * (loc[HIN0 + wd] - val(loc, ST(wd, 0), 32)));
-            c.constraint(in_block * (nxt[HIN0 + wd] - loc[HIN0 + wd]));
-        }
+        sha_compression_constraints<F>(loc, nxt, per, tdata, c);
         // ---- 8. block types
-        {
-            const int t[4] = {T_FIRST, T_DATA, T_PAD, T_IDLE};
 #pragma unroll 1
-            for (int q = 0; q < 4; ++q) c.constraint(in_block * (nxt[t[q]] - loc[t[q]]));
-        }
+        for (int q = 0; q < 4; ++q) c.constraint(in_block * (nxt[t[q]] - loc[t[q]]));
         c.constraint(sel63 * (nxt[T_PAD] - tdata));
         c.transition(sel63 * nxt[T_FIRST]);
         c.first_row(loc[T_FIRST] - one);
@@ -145,16 +176,16 @@ struct ShaAir {
         // ---- 9. message contents at the first row of a block
 #pragma unroll 1
         for (int j = 0; j < 8; ++j) {
-            c.constraint(sel0 * tdata * (val(loc, WW(j, 0), 32) - loc[DG0 + j]));
-            c.constraint(sel0 * loc[T_FIRST] * (val(loc, WW(8 + j, 0), 32) - F::from(tail32(j))));
+            c.constraint(sel0 * tdata * (window(loc, j) - loc[DG0 + j]));
+            c.constraint(sel0 * loc[T_FIRST] * (window(loc, 8 + j) - F::from(tail32(j))));
         }
 #pragma unroll 1
-        for (int j = 0; j < 16; ++j) c.constraint(sel0 * loc[T_PAD] * (val(loc, WW(j, 0), 32) - F::from(pad64(j))));
+        for (int j = 0; j < 16; ++j) c.constraint(sel0 * loc[T_PAD] * (window(loc, j) - F::from(pad64(j))));
         // ---- 10. digest register
         const F upd = loc[T_FIRST] + loc[T_PAD];
 #pragma unroll 1
         for (int wd = 0; wd < 8; ++wd) {
-            const F ff = val(loc, FFB(wd, 0), 32), dg = loc[DG0 + wd];
+            const F ff = loc[FFV0 + wd], dg = loc[DG0 + wd];
             const F nd = upd * ff + (one - upd) * dg;
             c.constraint(in_block * (nxt[DG0 + wd] - dg));
             c.constraint(sel63 * (nxt[DG0 + wd] - nd));

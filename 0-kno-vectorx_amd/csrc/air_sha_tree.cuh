@@ -6,7 +6,7 @@
 // the Blake2b AIR (air_blake.cuh) over a logUp bus, so the roots are bound to the very header bytes that were hashed.
 // A node takes 128 rows: the DATA compression of l || r (start state IV) and the constant PAD compression of a 64-byte
 // message; node g of tree t sits at rows 128 (t N + g) in heap numbering (1 = root, children 2g / 2g+1, leaves N..2N-1,
-// slot 0 a dummy).  Compression rows and column layout are ShaChainAir's (air_sha.cuh); everything positional is a
+// slot 0 a dummy).  Compression rows and column layout are ShaChainAir's (air_sha.cuh, 731 columns); everything positional is a
 // PERIODIC column; the only other witness is the pair of leaf-enable flags ENL / ENR of a bottom-level node (a disabled
 // leaf must be zero and takes nothing from the bus).  Row r < 16 of a DATA block receives message word r:
 //   inner nodes and the bottom level of tree 0:  (tree, child id, r mod 8, word, TAG_WORD)
@@ -64,89 +64,23 @@ struct ShaTreeAirT {
     __host__ __device__ static void eval(const Row& loc, const Row& nxt, const F* per, const F* pub, const F* chal, const F* apub, C& c) {
         using namespace shc;
         using namespace sht;
-        const F sel0 = per[P_SEL0], sel63 = per[P_SEL63], sched_on = per[P_SCHED], kr = per[P_K], is_data = per[P_DATA];
-        const F one = F::from(1), two = F::from(2), two32 = F::from(1ULL << 32);
-        const F in_block = one - sel63;
+        const F sel0 = per[P_SEL0], is_data = per[P_DATA];
+        const F one = F::from(1);
         auto val = [&](const Row& row, int col0, int nb) -> F {
             F acc = row[col0 + nb - 1];
 #pragma unroll 1
             for (int i = nb - 2; i >= 0; --i) acc = acc + acc + row[col0 + i];
             return acc;
         };
-        // ---- 1. booleans
-#pragma unroll 1
-        for (int col = 0; col < HIN0; ++col) {
-            const F x = loc[col];
-            c.constraint(x * (x - one));
-        }
-        // ---- 2. three-input XORs: x + y + z = r + 2c
-        auto xor3 = [&](int col0, int r0, int r1, int r2, int shift, int colr, int colc) {
-#pragma unroll 1
-            for (int i = 0; i < 32; ++i) {
-                F acc = loc[col0 + ((i + r0) & 31)] + loc[col0 + ((i + r1) & 31)];
-                if (shift < 0) acc = acc + loc[col0 + ((i + r2) & 31)];
-                else if (i + shift < 32) acc = acc + loc[col0 + i + shift];
-                c.constraint(acc - loc[colr + i] - two * loc[colc + i]);
-            }
-        };
-        xor3(WW(1, 0), 7, 18, 0, 3, S0R, S0C);
-        xor3(WW(14, 0), 17, 19, 0, 10, S1R, S1C);
-        xor3(ST(4, 0), 6, 11, 25, -1, E1R, E1C);
-        xor3(ST(0, 0), 2, 13, 22, -1, A0R, A0C);
-#pragma unroll 1
-        for (int i = 0; i < 32; ++i) c.constraint(loc[ST(0, i)] + loc[ST(1, i)] + loc[ST(2, i)] - two * loc[MAJ + i] - loc[PAR + i]);
-        // ---- 3. the round
-        {
-            F ch = F::from(0);
-#pragma unroll 1
-            for (int i = 31; i >= 0; --i) {
-                const F e = loc[ST(4, i)], f = loc[ST(5, i)], g = loc[ST(6, i)];
-                ch = ch + ch + (e * f + (one - e) * g);
-            }
-            const F t1 = val(loc, ST(7, 0), 32) + val(loc, E1R, 32) + ch + kr + val(loc, WW(0, 0), 32);
-            c.constraint(val(loc, NE0, 32) + two32 * val(loc, CE0, 3) - (val(loc, ST(3, 0), 32) + t1));
-            c.constraint(val(loc, NA0, 32) + two32 * val(loc, CA0, 3) - (t1 + val(loc, A0R, 32) + val(loc, MAJ, 32)));
-        }
-        // ---- 4. state shift inside a block
-#pragma unroll 1
-        for (int i = 0; i < 32; ++i) {
-            c.constraint(in_block * (nxt[ST(0, i)] - loc[NA0 + i]));
-            c.constraint(in_block * (nxt[ST(4, i)] - loc[NE0 + i]));
-            const int wds[6] = {1, 2, 3, 5, 6, 7};
-#pragma unroll 1
-            for (int q = 0; q < 6; ++q) c.constraint(in_block * (nxt[ST(wds[q], i)] - loc[ST(wds[q] - 1, i)]));
-        }
-        // ---- 5. message schedule
-#pragma unroll 1
-        for (int j = 0; j < 15; ++j)
-#pragma unroll 1
-            for (int i = 0; i < 32; ++i) c.constraint(in_block * (nxt[WW(j, i)] - loc[WW(j + 1, i)]));
-        c.constraint(sched_on * (val(nxt, WW(15, 0), 32) + two32 * val(loc, CW0, 2) -
-                                 (val(loc, S1R, 32) + val(loc, WW(9, 0), 32) + val(loc, S0R, 32) + val(loc, WW(0, 0), 32))));
-        // ---- 6. feed-forward at r = 63
-        {
-            const int s64[8] = {NA0, ST(0, 0), ST(1, 0), ST(2, 0), NE0, ST(4, 0), ST(5, 0), ST(6, 0)};
-#pragma unroll 1
-            for (int wd = 0; wd < 8; ++wd)
-                c.constraint(sel63 * (val(loc, FFB(wd, 0), 32) + two32 * loc[FFC0 + wd] - (loc[HIN0 + wd] + val(loc, s64[wd], 32))));
-        }
-        // ---- 7. block boundary: the PAD block starts from the DATA block's output, a DATA block from IV
-#pragma unroll 1
-        for (int wd = 0; wd < 8; ++wd) {
-#pragma unroll 1
-            for (int i = 0; i < 32; ++i) {
-                const F ivb = F::from((uint64_t)((iv(wd) >> i) & 1));
-                c.constraint(sel63 * (nxt[ST(wd, i)] - (is_data * loc[FFB(wd, i)] + (one - is_data) * ivb)));
-            }
-            c.constraint(sel0 * (loc[HIN0 + wd] - val(loc, ST(wd, 0), 32)));
-            c.constraint(in_block * (nxt[HIN0 + wd] - loc[HIN0 + wd]));
-        }
+        auto window = [&](const Row& row, int p) -> F { return p == 0 ? val(row, W0B, 32) : p == 1 ? val(row, W1B, 32) : p == 14 ? val(row, W14B, 32) : row[WV(p)]; };
+        // ---- 1-7. the compression rows (shared with ShaChainAir); a PAD block continues from its DATA block
+        sha_compression_constraints<F>(loc, nxt, per, is_data, c);
         // ---- 8. the PAD block's message, the root, zero leaves
 #pragma unroll 1
-        for (int j = 0; j < 16; ++j) c.constraint(sel0 * (one - is_data) * (val(loc, WW(j, 0), 32) - F::from(pad64(j))));
+        for (int j = 0; j < 16; ++j) c.constraint(sel0 * (one - is_data) * (window(loc, j) - F::from(pad64(j))));
 #pragma unroll 1
-        for (int j = 0; j < 8; ++j) c.constraint(per[P_ROOT] * (val(loc, FFB(j, 0), 32) - (pub[j] + per[P_TREE] * (pub[8 + j] - pub[j]))));
-        const F w0 = val(loc, WW(0, 0), 32);
+        for (int j = 0; j < 8; ++j) c.constraint(per[P_ROOT] * (loc[FFV0 + j] - (pub[j] + per[P_TREE] * (pub[8 + j] - pub[j]))));
+        const F w0 = val(loc, W0B, 32);
         c.constraint((per[P_PWL] + per[P_PBL]) * (one - loc[ENL]) * w0);
         c.constraint((per[P_PWR] + per[P_PBR]) * (one - loc[ENR]) * w0);
         // ---- 9. the bus (logUp): 13 lookups in 7 helper elements of the local row, cyclic running sum
@@ -162,8 +96,8 @@ struct ShaTreeAirT {
             };
             auto denom = [&](int q) -> X2<F> {
                 if (q == 0) return beta + per[P_TREE] + gamma * per[P_CID] + g2 * per[P_JJ] + g3 * w0 + tag_w;
-                if (q <= 4) return beta + per[P_CID] + gamma * (per[P_JJ] * F::from(4) + F::from((uint64_t)(q - 1))) + g2 * val(loc, WW(0, 24 - 8 * (q - 1)), 8) + tag_b;
-                return beta + per[P_TREE] + gamma * per[P_GID] + g2 * F::from((uint64_t)(q - 5)) + g3 * val(loc, FFB(q - 5, 0), 32) + tag_w;
+                if (q <= 4) return beta + per[P_CID] + gamma * (per[P_JJ] * F::from(4) + F::from((uint64_t)(q - 1))) + g2 * val(loc, W0B + 24 - 8 * (q - 1), 8) + tag_b;
+                return beta + per[P_TREE] + gamma * per[P_GID] + g2 * F::from((uint64_t)(q - 5)) + g3 * loc[FFV0 + q - 5] + tag_w;
             };
             X2<F> hsum{zero, zero};
 #pragma unroll 1

@@ -60,10 +60,18 @@ __global__ __launch_bounds__(256) void k_sha_trace(const ShaBlock* blocks, uint6
     const uint32_t ch = (e & f) ^ (~e & g), mj = (a & bb) ^ (a & c) ^ (bb & c);
     const uint64_t t1 = (uint64_t)h + e1 + ch + K[r] + w[r];
     const uint64_t ne_full = (uint64_t)d + t1, na_full = t1 + a0 + mj;
-    for (int wd = 0; wd < 8; ++wd) sbits(tr, n, row, ST(wd, 0), s[wd]);
+    // state: a, b, c, e, f, g as bits, d and h as values
+    sbits(tr, n, row, A_, a), sbits(tr, n, row, B_, bb), sbits(tr, n, row, C_, c), sbits(tr, n, row, E_, e), sbits(tr, n, row, F_, f), sbits(tr, n, row, G_, g);
+    tr[(size_t)DV * n + row] = d;
+    tr[(size_t)HV * n + row] = h;
     sbits(tr, n, row, NA0, (uint32_t)na_full);
     sbits(tr, n, row, NE0, (uint32_t)ne_full);
-    for (int j = 0; j < 16; ++j) sbits(tr, n, row, WW(j, 0), w[r + j]);
+    // schedule window w_r .. w_{r+15}: positions 0, 1, 14 as bits, the others as values
+    sbits(tr, n, row, W0B, w[r]);
+    sbits(tr, n, row, W1B, w[r + 1]);
+    sbits(tr, n, row, W14B, w[r + 14]);
+    for (int p = 2; p < 14; ++p) tr[(size_t)WV(p) * n + row] = w[r + p];
+    tr[(size_t)WV15 * n + row] = w[r + 15];
     const uint32_t w1 = w[r + 1], w14 = w[r + 14];
     sxor3(tr, n, row, s_rotr(w1, 7), s_rotr(w1, 18), w1 >> 3, S0R, S0C);
     sxor3(tr, n, row, s_rotr(w14, 17), s_rotr(w14, 19), w14 >> 10, S1R, S1C);
@@ -88,7 +96,7 @@ __global__ __launch_bounds__(256) void k_sha_trace(const ShaBlock* blocks, uint6
             const uint32_t s64[8] = {(uint32_t)na_full, a, bb, c, (uint32_t)ne_full, e, f, g};
             tot = (uint64_t)b.h_in[wd] + s64[wd];
         }
-        sbits(tr, n, row, FFB(wd, 0), (uint32_t)tot);
+        tr[(size_t)(FFV0 + wd) * n + row] = (uint32_t)tot;
         tr[(size_t)(FFC0 + wd) * n + row] = tot >> 32;
         tr[(size_t)(HIN0 + wd) * n + row] = b.h_in[wd];
         tr[(size_t)(DG0 + wd) * n + row] = b.dg[wd];
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(256) void k_sha_tree_aux(const uint64_t* tr, uint64
     if (m_word | m_byte | (send ? 1 : 0)) {
         const gl2 g2 = gl2_mul(gamma, gamma), g3 = gl2_mul(g2, gamma), g4 = gl2_mul(g2, g2);
         const gl2 tag_w = gl2_scale(g4, blk::TAG_WORD), tag_b = gl2_scale(g4, blk::TAG_BYTE);
-        const uint64_t c = r >= 8 ? 1 : 0, jj = r & 7, w0 = (msg ? word(WW(0, 0), 32) : 0);
+        const uint64_t c = r >= 8 ? 1 : 0, jj = r & 7, w0 = (msg ? word(W0B, 32) : 0);
         const uint64_t cid = (bottom && tree == 1) ? 2 * g - N + c : 2 * g + c;
         gl2 d[13];
         uint64_t m[13];  // 1 = receive (-1), 2 = send (+1), 0 = inactive
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(256) void k_sha_tree_aux(const uint64_t* tr, uint64
             m[1 + q] = m_byte;
         }
         for (int j = 0; j < 8; ++j) {
-            const uint64_t ff = send ? word(FFB(j, 0), 32) : 0;
+            const uint64_t ff = send ? tr[(size_t)(FFV0 + j) * n + row] : 0;
             d[5 + j] = gl2_add(gl2_add(beta, gl2{(uint64_t)tree, 0}), gl2_add(gl2_add(gl2_scale(gamma, g), gl2_scale(g2, j)), gl2_add(gl2_scale(g3, ff), tag_w)));
             m[5 + j] = send ? 2 : 0;
         }

@@ -32,7 +32,7 @@ SYMBOLS = [
 VX_AIR_FIBONACCI, VX_AIR_MIX, VX_AIR_BLAKE_CHAIN, VX_AIR_LOOKUP = 1, 2, 6, 5
 VX_BLAKE_AIR_COLS, VX_BLAKE_AIR_AUX_COLS = 740, 278
 VX_AIR_SHA_TREE = {256: 7, 512: 8, 16: 9}
-VX_AIR_SHA_CHAIN, VX_SHA_AIR_COLS = 4, 1444
+VX_AIR_SHA_CHAIN, VX_SHA_AIR_COLS = 4, 731
 
 
 class JustificationStruct(C.Structure):

@@ -394,7 +394,7 @@ def main():
                            "step but are not inside a proof, and the three STARKs are not aggregated into one",
             "config": {
                 "workload": f"header_range_{N_HEADERS}: {N_HEADERS} x 15,360-B synthetic Avail headers (P15k), 300 authorities, one input per GPU; "
-                            f"{120 * N_HEADERS:,} Blake2b compressions -> BlakeChainAir (byte-lookup AIR) trace 2^{19 if N_HEADERS == 256 else 20} rows x (740 main + 278 logUp) columns + ShaTreeAir (SHA-256 Merkle table, 2^{16 if N_HEADERS == 256 else 17} x 1460) on the same logUp bus",
+                            f"{120 * N_HEADERS:,} Blake2b compressions -> BlakeChainAir (byte-lookup AIR) trace 2^{19 if N_HEADERS == 256 else 20} rows x (740 main + 278 logUp) columns + ShaTreeAir (SHA-256 Merkle table, 2^{16 if N_HEADERS == 256 else 17} x 747) on the same logUp bus",
                 "complete_proof": False,
                 "stages": ["verify_subchain: Blake2b header hashes, SCALE decode, link + numbering checks, SHA-256 Merkle roots -> 96-B output (native on GPU)",
                            "verify_simple_justification: authority-set SHA-256 chain, precommit, 300 Ed25519 verifications, 2/3 threshold (native on GPU)",
@@ -403,7 +403,7 @@ def main():
                            "FRI batch/fold/PoW/queries, proof bytes",
                            "ShaTreeAir witness + STARK: both 256-leaf SHA-256 Merkle trees over the state roots / data roots the hash-chain table decodes "
                            "from the header bytes and sends over the bus (shared lookup challenges; the two roots are its public inputs)",
-                           "ShaChainAir witness + STARK: the 599-compression authority-set SHA-256 commitment (2^16 x 1444 trace)"],
+                           "ShaChainAir witness + STARK: the 599-compression authority-set SHA-256 commitment (2^16 x 731 trace)"],
                 "missing": ["EdDSA verification inside a STARK (checked natively on the GPU today); binding the committed keys to it",
                             "recursive aggregation into one proof"],
             },
@@ -429,7 +429,7 @@ def main():
                 "stages": ["BlakeChainAir witness + STARK over the header's 120 compressions (2^16 x 999: one copy of the XOR lookup tables)",
                            "verify_simple_justification (native on GPU: 201 Ed25519 verifications, precommit, threshold)",
                            "verify_epoch_end_header (native on GPU: prefix, 300 x (pubkey, weight), delay)",
-                           "two ShaChainAir witnesses + STARKs: current and new authority-set commitments (2^16 x 1444 each)"],
+                           "two ShaChainAir witnesses + STARKs: current and new authority-set commitments (2^16 x 731 each)"],
                 "missing": ["epoch-end header parsing and EdDSA inside a STARK", "recursive aggregation into one proof"],
             }
         elif not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only

@@ -219,10 +219,10 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
 
 /* ---- K8: ShaChainAir trace generation (compute_authority_set_commitment, justification.rs:127-162):
  * the chained SHA-256 commitment h_0 = SHA256(pk_0), h_i = SHA256(h_{i-1} || pk_i) over n_keys 32-byte
- * keys (host buffer).  Writes the 1444-column trace (64 rows per compression, 2*n_keys - 1
+ * keys (host buffer).  Writes the 731-column trace (64 rows per compression, 2*n_keys - 1
  * compressions, padded with idle blocks), the 8 public inputs (the commitment as big-endian words)
  * and optionally the 32 commitment bytes.  Prove with vx_stark_prove(ctx, VX_AIR_SHA_CHAIN, ...). */
-enum { VX_AIR_SHA_CHAIN = 4, VX_SHA_AIR_COLS = 1444 };
+enum { VX_AIR_SHA_CHAIN = 4, VX_SHA_AIR_COLS = 731 };
 int32_t vx_sha_chain_trace(vx_ctx* ctx, const uint8_t* pubkeys, size_t n_keys, int log_n, vx_buf* trace_out,
                            uint64_t public_inputs_out[8], uint8_t commitment_out[32]);
 

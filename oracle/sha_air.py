@@ -1,4 +1,4 @@
-"""ShaChainAir (AIR id 4), restated for the oracle -- TEST INFRASTRUCTURE.
+"""ShaChainAir (AIR id 4) and the compression rows every SHA-256 table shares, restated for the oracle -- TEST INFRASTRUCTURE.
 
 Statement: "authority_set_hash is the chained SHA-256 commitment of some sequence of 32-byte
 public keys":  h_0 = SHA256(pk_0), h_i = SHA256(h_{i-1} || pk_i)  -- compute_authority_set_commitment,
@@ -12,7 +12,8 @@ Block types (one-hot flags, constant inside a block):
   PAD    : the constant padding block of a 64-byte message (start state = DATA's output) -> digest h_i
   IDLE   : filler compressions after the chain (any message), digest register unchanged
 Row r holds the working state BEFORE round r, the 16-word schedule window w_r..w_{r+15}, the round
-outputs NA/NE (new a, new e), and at r = 63 the feed-forward FF = H_in + state_64.
+outputs NA/NE (new a, new e), and at r = 63 the feed-forward FF = H_in + state_64 (values: a digest word is range
+checked where it is consumed -- as message bits of a later block, or as a public input).
 """
 import numpy as np
 
@@ -31,35 +32,37 @@ IV = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x
 PAD64 = [0x80000000] + [0] * 14 + [512]  # second block of a 64-byte message
 TAIL32 = [0x80000000] + [0] * 6 + [256]  # words 8..15 of the single block of a 32-byte message
 
-# ---- column layout (all words are 32 little-endian bit columns)
-ST0 = 0            # state words a..h: ST(w, i) = 32*w + i, w = 0..7
-NA0, NE0 = 256, 288
-W0 = 320           # schedule window: WW(j, i) = W0 + 32*j + i, j = 0..15
-S0R, S0C, S1R, S1C = 832, 864, 896, 928      # sigma0(W[1]), sigma1(W[14]): result and carry bits
-E1R, E1C, A0R, A0C = 960, 992, 1024, 1056    # Sigma1(e), Sigma0(a)
-MAJ, PAR = 1088, 1120
-CE0, CA0, CW0 = 1152, 1155, 1158             # carries: 3 + 3 + 2 bits
-FF0 = 1160         # feed-forward words: FFB(w, i) = FF0 + 32*w + i
-FFC0 = 1416        # 8 feed-forward carry bits
-HIN0 = 1424        # 8 initial-state words (values)
-DG0 = 1432         # digest register, 8 words (values)
-T_FIRST, T_DATA, T_PAD, T_IDLE = 1440, 1441, 1442, 1443
-COLS = 1444
+# ---- column layout.  Only the words an XOR / AND needs exist as 32 little-endian bit columns: a, b, c, e, f, g of the
+# state (Sigma0, Maj / Sigma1, Ch), the new a and e, and positions 0, 1, 14 of the 16-word schedule window (w_r enters T1
+# and the bus, sigma0 reads w_{r+1}, sigma1 reads w_{r+14}).  d, h and the other 13 window positions are single VALUE
+# columns: every such value was, or will be, a bit-decomposed word on another row (d = c of the previous row, a window
+# word reaches position 14 and later position 1), and everything downstream works modulo 2^32.
+A_, B_, C_, E_, F_, G_ = 0, 32, 64, 96, 128, 160   # state words held as bits
+DV, HV = 192, 193                                  # state words d, h as values
+NA0, NE0 = 194, 226
+W0B, W1B, W14B = 258, 290, 322                     # window positions 0, 1, 14 as bits
+WV0 = 354                                          # WV(p) = WV0 + p - 2 for p = 2..13; position 15 at WV15
+WV15 = 366
+S0R, S0C, S1R, S1C = 367, 399, 431, 463            # sigma0(W[1]), sigma1(W[14]): result and carry bits
+E1R, E1C, A0R, A0C = 495, 527, 559, 591            # Sigma1(e), Sigma0(a)
+MAJ, PAR = 623, 655
+CE0, CA0, CW0 = 687, 690, 693                      # carries: 3 + 3 + 2 bits
+FFV0 = 695         # feed-forward words (values): H_in + state_64 - 2^32 carry
+FFC0 = 703         # 8 feed-forward carry bits
+HIN0 = 711         # 8 initial-state words (values)
+DG0 = 719          # digest register, 8 words (values)
+T_FIRST, T_DATA, T_PAD, T_IDLE = 727, 728, 729, 730
+COLS = 731
+BIT_RANGES = [(0, DV), (NA0, WV0), (S0R, FFV0), (FFC0, HIN0)]  # every boolean column
 PUB = 8
 PERIODIC = 4       # sel_0, sel_63, sched_on (r <= 47), K_r
 PERIOD_LOG = 6
+ST_BITS = {0: A_, 1: B_, 2: C_, 4: E_, 5: F_, 6: G_}
 
 
-def ST(w, i):
-    return 32 * w + i
-
-
-def WW(j, i):
-    return W0 + 32 * j + i
-
-
-def FFB(w, i):
-    return FF0 + 32 * w + i
+def WV(p):
+    """Value column of window position p (2..13, 15)."""
+    return WV15 if p == 15 else WV0 + p - 2
 
 
 def periodic_values():
@@ -116,59 +119,67 @@ def gen_blocks(pubkeys, n_blocks):
     return blocks, h
 
 
-def gen_trace(pubkeys, log_n):
-    n = 1 << log_n
-    blocks, final = gen_blocks(pubkeys, n // 64)
-    tr = np.zeros((COLS, n), dtype=np.uint64)
+def fill_block(tr, base, h_in, block):
+    """Rows base .. base+63 of one compression (everything but the registers a table adds); returns the output state."""
+    rows, st64, out = compress_rows(h_in, block)
 
     def bits(row, col0, val, nb=32):
         for i in range(nb):
             tr[col0 + i, row] = (val >> i) & 1
 
+    def xor3(row, x, y, z, colr, colc):
+        for i in range(32):
+            sm = ((x >> i) & 1) + ((y >> i) & 1) + ((z >> i) & 1)
+            tr[colr + i, row], tr[colc + i, row] = sm & 1, sm >> 1
+
+    for r in range(64):
+        row, rec = base + r, rows[r]
+        a, b, c, d, e, f, g, h = rec["st"]
+        for wd, col in ST_BITS.items():
+            bits(row, col, rec["st"][wd])
+        tr[DV, row], tr[HV, row] = d, h
+        bits(row, NA0, rec["na"])
+        bits(row, NE0, rec["ne"])
+        w = rec["w"]
+        bits(row, W0B, w[0])
+        bits(row, W1B, w[1])
+        bits(row, W14B, w[14])
+        for p in list(range(2, 14)) + [15]:
+            tr[WV(p), row] = w[p]
+        xor3(row, rotr(w[1], 7), rotr(w[1], 18), w[1] >> 3, S0R, S0C)
+        xor3(row, rotr(w[14], 17), rotr(w[14], 19), w[14] >> 10, S1R, S1C)
+        xor3(row, rotr(e, 6), rotr(e, 11), rotr(e, 25), E1R, E1C)
+        xor3(row, rotr(a, 2), rotr(a, 13), rotr(a, 22), A0R, A0C)
+        for i in range(32):
+            sm = ((a >> i) & 1) + ((b >> i) & 1) + ((c >> i) & 1)
+            tr[MAJ + i, row], tr[PAR + i, row] = sm >> 1, sm & 1
+        bits(row, CE0, rec["ce"], 3)
+        bits(row, CA0, rec["ca"], 3)
+        if r <= 47:
+            s0 = rotr(w[1], 7) ^ rotr(w[1], 18) ^ (w[1] >> 3)
+            s1 = rotr(w[14], 17) ^ rotr(w[14], 19) ^ (w[14] >> 10)
+            bits(row, CW0, (s1 + w[9] + s0 + w[0]) >> 32, 2)
+        if r == 63:
+            for wd in range(8):
+                tot = h_in[wd] + st64[wd]
+                tr[FFV0 + wd, row], tr[FFC0 + wd, row] = tot & M32, tot >> 32
+        for wd in range(8):
+            tr[HIN0 + wd, row] = h_in[wd]
+    return out
+
+
+def gen_trace(pubkeys, log_n):
+    n = 1 << log_n
+    blocks, final = gen_blocks(pubkeys, n // 64)
+    tr = np.zeros((COLS, n), dtype=np.uint64)
     final_words = [int.from_bytes(final[4 * j: 4 * j + 4], "big") for j in range(8)]
     dg = list(final_words)  # block 0 carries the final digest (the register wraps around cyclically)
     for bi, blk in enumerate(blocks):
-        rows, st64, out = compress_rows(blk["h_in"], blk["block"])
-        for r in range(64):
-            row = 64 * bi + r
-            rec = rows[r]
-            a, b, c, d, e, f, g, h = rec["st"]
-            for wd in range(8):
-                bits(row, ST(wd, 0), rec["st"][wd])
-            bits(row, NA0, rec["na"])
-            bits(row, NE0, rec["ne"])
-            for j in range(16):
-                bits(row, WW(j, 0), rec["w"][j])
-            w1, w14 = rec["w"][1], rec["w"][14]
-
-            def xor3(x, y, z, colr, colc):
-                for i in range(32):
-                    s = ((x >> i) & 1) + ((y >> i) & 1) + ((z >> i) & 1)
-                    tr[colr + i, row], tr[colc + i, row] = s & 1, s >> 1
-
-            xor3(rotr(w1, 7), rotr(w1, 18), w1 >> 3, S0R, S0C)
-            xor3(rotr(w14, 17), rotr(w14, 19), w14 >> 10, S1R, S1C)
-            xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25), E1R, E1C)
-            xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22), A0R, A0C)
-            for i in range(32):
-                s = ((a >> i) & 1) + ((b >> i) & 1) + ((c >> i) & 1)
-                tr[MAJ + i, row], tr[PAR + i, row] = s >> 1, s & 1
-            bits(row, CE0, rec["ce"], 3)
-            bits(row, CA0, rec["ca"], 3)
-            if r <= 47:
-                s0 = rotr(w1, 7) ^ rotr(w1, 18) ^ (w1 >> 3)
-                s1 = rotr(w14, 17) ^ rotr(w14, 19) ^ (w14 >> 10)
-                tot = s1 + rec["w"][9] + s0 + rec["w"][0]
-                bits(row, CW0, tot >> 32, 2)
-            if r == 63:
-                for wd in range(8):
-                    tot = blk["h_in"][wd] + st64[wd]
-                    bits(row, FFB(wd, 0), tot & M32)
-                    tr[FFC0 + wd, row] = tot >> 32
-            for wd in range(8):
-                tr[HIN0 + wd, row] = blk["h_in"][wd]
-                tr[DG0 + wd, row] = dg[wd]
-            tr[{"FIRST": T_FIRST, "DATA": T_DATA, "PAD": T_PAD, "IDLE": T_IDLE}[blk["type"]], row] = 1
+        out = fill_block(tr, 64 * bi, blk["h_in"], blk["block"])
+        rows = slice(64 * bi, 64 * bi + 64)
+        for wd in range(8):
+            tr[DG0 + wd, rows] = dg[wd]
+        tr[{"FIRST": T_FIRST, "DATA": T_DATA, "PAD": T_PAD, "IDLE": T_IDLE}[blk["type"]], rows] = 1
         if blk["type"] in ("FIRST", "PAD"):
             dg = list(out)
     assert dg == final_words
@@ -176,75 +187,108 @@ def gen_trace(pubkeys, log_n):
 
 
 # ----------------------------------------------------------------------------- constraints
+def val(row, col0, nb=32):
+    acc = row[col0 + nb - 1]
+    for i in range(nb - 2, -1, -1):
+        acc = acc + acc + row[col0 + i]
+    return acc
+
+
+def window(row, p):
+    """Value of window position p."""
+    if p == 0:
+        return val(row, W0B)
+    if p == 1:
+        return val(row, W1B)
+    if p == 14:
+        return val(row, W14B)
+    return row[WV(p)]
+
+
+def state_word(row, wd):
+    return row[DV] if wd == 3 else row[HV] if wd == 7 else val(row, ST_BITS[wd])
+
+
+def compression_constraints(loc, nxt, per, c, data_flag):
+    """Sections 1-7 shared by every SHA-256 table: the rows of a compression and the hand-over at a block boundary.
+    data_flag: 1 where the block AFTER the local one continues from its output (DATA -> PAD), else it starts from IV."""
+    sel0, sel63, sched_on, kr = per[0], per[1], per[2], per[3]
+    in_block = 1 - sel63
+    two32 = 1 << 32
+    # ---- 1. booleans
+    for lo, hi in BIT_RANGES:
+        for col in range(lo, hi):
+            c.constraint(loc[col] * (loc[col] - 1))
+
+    # ---- 2. three-input XORs as x + y + z = r + 2 c  (rotations; shifted-out bits are absent)
+    def xor3(col0, rots, shift, colr, colc):
+        for i in range(32):
+            acc = loc[col0 + (i + rots[0]) % 32] + loc[col0 + (i + rots[1]) % 32]
+            if shift is None:
+                acc = acc + loc[col0 + (i + rots[2]) % 32]
+            elif i + shift < 32:
+                acc = acc + loc[col0 + i + shift]
+            c.constraint(acc - loc[colr + i] - 2 * loc[colc + i])
+
+    xor3(W1B, (7, 18), 3, S0R, S0C)
+    xor3(W14B, (17, 19), 10, S1R, S1C)
+    xor3(E_, (6, 11, 25), None, E1R, E1C)
+    xor3(A_, (2, 13, 22), None, A0R, A0C)
+    for i in range(32):
+        c.constraint(loc[A_ + i] + loc[B_ + i] + loc[C_ + i] - 2 * loc[MAJ + i] - loc[PAR + i])
+    # ---- 3. the round (local): T1 = h + Sigma1(e) + Ch(e,f,g) + K_r + w_r
+    ch = None
+    for i in range(31, -1, -1):
+        e, f, g = loc[E_ + i], loc[F_ + i], loc[G_ + i]
+        bit = e * f + (1 - e) * g
+        ch = bit if ch is None else ch + ch + bit
+    t1 = loc[HV] + val(loc, E1R) + ch + kr + val(loc, W0B)
+    c.constraint(val(loc, NE0) + two32 * val(loc, CE0, 3) - (loc[DV] + t1))
+    c.constraint(val(loc, NA0) + two32 * val(loc, CA0, 3) - (t1 + val(loc, A0R) + val(loc, MAJ)))
+    # ---- 4. state shift inside a block
+    for i in range(32):
+        c.constraint(in_block * (nxt[A_ + i] - loc[NA0 + i]))
+        c.constraint(in_block * (nxt[E_ + i] - loc[NE0 + i]))
+        for dst, src in ((B_, A_), (C_, B_), (F_, E_), (G_, F_)):
+            c.constraint(in_block * (nxt[dst + i] - loc[src + i]))
+    c.constraint(in_block * (nxt[DV] - val(loc, C_)))
+    c.constraint(in_block * (nxt[HV] - val(loc, G_)))
+    # ---- 5. message schedule: window shift, and w_{r+16} while r <= 47
+    for i in range(32):
+        c.constraint(in_block * (nxt[W0B + i] - loc[W1B + i]))
+    for p in range(1, 15):
+        c.constraint(in_block * (window(nxt, p) - window(loc, p + 1)))
+    c.constraint(sched_on * (nxt[WV15] + two32 * val(loc, CW0, 2) - (val(loc, S1R) + loc[WV(9)] + val(loc, S0R) + val(loc, W0B))))
+    # ---- 6. feed-forward at r = 63: FF = H_in + (NA, a, b, c, NE, e, f, g)
+    s64 = [val(loc, NA0), val(loc, A_), val(loc, B_), val(loc, C_), val(loc, NE0), val(loc, E_), val(loc, F_), val(loc, G_)]
+    for wd in range(8):
+        c.constraint(sel63 * (loc[FFV0 + wd] + two32 * loc[FFC0 + wd] - (loc[HIN0 + wd] + s64[wd])))
+    # ---- 7. block boundary: next start state = FF where data_flag, IV otherwise; H_in register
+    for wd in range(8):
+        if wd in ST_BITS:
+            for i in range(32):
+                iv = (IV[wd] >> i) & 1
+                c.constraint(sel63 * (1 - data_flag) * (nxt[ST_BITS[wd] + i] - iv))
+            c.constraint(sel63 * data_flag * (val(nxt, ST_BITS[wd]) - loc[FFV0 + wd]))
+        else:
+            c.constraint(sel63 * (state_word(nxt, wd) - (data_flag * loc[FFV0 + wd] + (1 - data_flag) * IV[wd])))
+        c.constraint(sel0 * (loc[HIN0 + wd] - state_word(loc, wd)))
+        c.constraint(in_block * (nxt[HIN0 + wd] - loc[HIN0 + wd]))
+
+
 class ShaChainAir:
     ID, COLS, PUB, PERIODIC, PERIOD_LOG = ID, COLS, PUB, PERIODIC, PERIOD_LOG
     periodic_values = staticmethod(periodic_values)
 
     @staticmethod
     def eval(loc, nxt, per, pub, c):
-        sel0, sel63, sched_on, kr = per
+        sel0, sel63 = per[0], per[1]
         in_block = 1 - sel63
-
-        def val(row, col0, nb=32):
-            acc = row[col0 + nb - 1]
-            for i in range(nb - 2, -1, -1):
-                acc = acc + acc + row[col0 + i]
-            return acc
-
-        # ---- 1. booleans: every bit column and the four type flags
-        for col in list(range(0, HIN0)) + [T_FIRST, T_DATA, T_PAD, T_IDLE]:
+        # ---- 0. the four type flags
+        for col in (T_FIRST, T_DATA, T_PAD, T_IDLE):
             c.constraint(loc[col] * (loc[col] - 1))
         c.constraint(loc[T_FIRST] + loc[T_DATA] + loc[T_PAD] + loc[T_IDLE] - 1)
-
-        # ---- 2. three-input XORs as x + y + z = r + 2 c  (rotations; shifted-out bits are absent)
-        def xor3(col0, rots, shift, colr, colc):
-            for i in range(32):
-                acc = loc[col0 + (i + rots[0]) % 32] + loc[col0 + (i + rots[1]) % 32]
-                if shift is None:
-                    acc = acc + loc[col0 + (i + rots[2]) % 32]
-                elif i + shift < 32:
-                    acc = acc + loc[col0 + i + shift]
-                c.constraint(acc - loc[colr + i] - 2 * loc[colc + i])
-
-        xor3(WW(1, 0), (7, 18), 3, S0R, S0C)
-        xor3(WW(14, 0), (17, 19), 10, S1R, S1C)
-        xor3(ST(4, 0), (6, 11, 25), None, E1R, E1C)
-        xor3(ST(0, 0), (2, 13, 22), None, A0R, A0C)
-        for i in range(32):
-            c.constraint(loc[ST(0, i)] + loc[ST(1, i)] + loc[ST(2, i)] - 2 * loc[MAJ + i] - loc[PAR + i])
-        # ---- 3. the round (local): T1 = h + Sigma1(e) + Ch(e,f,g) + K_r + w_r
-        ch = None
-        for i in range(31, -1, -1):
-            e, f, g = loc[ST(4, i)], loc[ST(5, i)], loc[ST(6, i)]
-            bit = e * f + (1 - e) * g
-            ch = bit if ch is None else ch + ch + bit
-        t1 = val(loc, ST(7, 0)) + val(loc, E1R) + ch + kr + val(loc, WW(0, 0))
-        two32 = 1 << 32
-        c.constraint(val(loc, NE0) + two32 * val(loc, CE0, 3) - (val(loc, ST(3, 0)) + t1))
-        c.constraint(val(loc, NA0) + two32 * val(loc, CA0, 3) - (t1 + val(loc, A0R) + val(loc, MAJ)))
-        # ---- 4. state shift inside a block
-        for i in range(32):
-            c.constraint(in_block * (nxt[ST(0, i)] - loc[NA0 + i]))
-            c.constraint(in_block * (nxt[ST(4, i)] - loc[NE0 + i]))
-            for wd in (1, 2, 3, 5, 6, 7):
-                c.constraint(in_block * (nxt[ST(wd, i)] - loc[ST(wd - 1, i)]))
-        # ---- 5. message schedule: window shift, and w_{r+16} while r <= 47
-        for j in range(15):
-            for i in range(32):
-                c.constraint(in_block * (nxt[WW(j, i)] - loc[WW(j + 1, i)]))
-        c.constraint(sched_on * (val(nxt, WW(15, 0)) + two32 * val(loc, CW0, 2)
-                                 - (val(loc, S1R) + val(loc, WW(9, 0)) + val(loc, S0R) + val(loc, WW(0, 0)))))
-        # ---- 6. feed-forward at r = 63: FF = H_in + (NA, a, b, c, NE, e, f, g)
-        s64 = [NA0, ST(0, 0), ST(1, 0), ST(2, 0), NE0, ST(4, 0), ST(5, 0), ST(6, 0)]
-        for wd in range(8):
-            c.constraint(sel63 * (val(loc, FFB(wd, 0)) + two32 * loc[FFC0 + wd] - (loc[HIN0 + wd] + val(loc, s64[wd]))))
-        # ---- 7. block boundary: next start state = FF after a DATA block, IV otherwise; H_in register
-        for wd in range(8):
-            for i in range(32):
-                iv = (IV[wd] >> i) & 1
-                c.constraint(sel63 * (nxt[ST(wd, i)] - (loc[T_DATA] * loc[FFB(wd, i)] + (1 - loc[T_DATA]) * iv)))
-            c.constraint(sel0 * (loc[HIN0 + wd] - val(loc, ST(wd, 0))))
-            c.constraint(in_block * (nxt[HIN0 + wd] - loc[HIN0 + wd]))
+        compression_constraints(loc, nxt, per, c, loc[T_DATA])
         # ---- 8. block types: constant in a block; DATA is followed by PAD and PAD follows only DATA; one FIRST
         for col in (T_FIRST, T_DATA, T_PAD, T_IDLE):
             c.constraint(in_block * (nxt[col] - loc[col]))
@@ -254,81 +298,13 @@ class ShaChainAir:
         c.last_row(loc[T_DATA])
         # ---- 9. message contents at the first row of a block
         for j in range(8):
-            c.constraint(sel0 * loc[T_DATA] * (val(loc, WW(j, 0)) - loc[DG0 + j]))
-            c.constraint(sel0 * loc[T_FIRST] * (val(loc, WW(8 + j, 0)) - TAIL32[j]))
+            c.constraint(sel0 * loc[T_DATA] * (window(loc, j) - loc[DG0 + j]))
+            c.constraint(sel0 * loc[T_FIRST] * (window(loc, 8 + j) - TAIL32[j]))
         for j in range(16):
-            c.constraint(sel0 * loc[T_PAD] * (val(loc, WW(j, 0)) - PAD64[j]))
+            c.constraint(sel0 * loc[T_PAD] * (window(loc, j) - PAD64[j]))
         # ---- 10. digest register: takes FF after FIRST / PAD blocks
         upd = loc[T_FIRST] + loc[T_PAD]
         for wd in range(8):
             c.constraint(in_block * (nxt[DG0 + wd] - loc[DG0 + wd]))
-            c.constraint(sel63 * (nxt[DG0 + wd] - (upd * val(loc, FFB(wd, 0)) + (1 - upd) * loc[DG0 + wd])))
-            c.last_row(upd * val(loc, FFB(wd, 0)) + (1 - upd) * loc[DG0 + wd] - pub[wd])
-
-
-def first_violation(tr, pub, rows=None):
-    from .blake_air import P as _P  # noqa: F401
-
-    n = tr.shape[1]
-
-    class S:
-        __slots__ = ("v",)
-
-        def __init__(self, v):
-            self.v = v % P
-
-        def _c(self, o):
-            return o if isinstance(o, S) else S(int(o))
-
-        def __add__(self, o):
-            return S(self.v + self._c(o).v)
-
-        __radd__ = __add__
-
-        def __sub__(self, o):
-            return S(self.v - self._c(o).v)
-
-        def __rsub__(self, o):
-            return S(self._c(o).v - self.v)
-
-        def __mul__(self, o):
-            return S(self.v * self._c(o).v)
-
-        __rmul__ = __mul__
-
-    class Row:
-        def __init__(self, col):
-            self.col = col
-
-        def __getitem__(self, c):
-            return S(self.col[c])
-
-    class Cons:
-        def __init__(self, first, last):
-            self.first, self.last, self.idx, self.bad = first, last, 0, None
-
-        def _push(self, c, active):
-            if active and c.v != 0 and self.bad is None:
-                self.bad = self.idx
-            self.idx += 1
-
-        def constraint(self, c):
-            self._push(c, True)
-
-        def transition(self, c):
-            self._push(c, not self.last)
-
-        def first_row(self, c):
-            self._push(c, self.first)
-
-        def last_row(self, c):
-            self._push(c, self.last)
-
-    pv = periodic_values()
-    for i in (range(n) if rows is None else rows):
-        cons = Cons(i == 0, i == n - 1)
-        per = [S(pv[k][i % 64]) for k in range(4)]
-        ShaChainAir.eval(Row([int(x) for x in tr[:, i]]), Row([int(x) for x in tr[:, (i + 1) % n]]), per, [S(x) for x in pub], cons)
-        if cons.bad is not None:
-            return i, cons.bad
-    return None
+            c.constraint(sel63 * (nxt[DG0 + wd] - (upd * loc[FFV0 + wd] + (1 - upd) * loc[DG0 + wd])))
+            c.last_row(upd * loc[FFV0 + wd] + (1 - upd) * loc[DG0 + wd] - pub[wd])

@@ -11,7 +11,7 @@ Rows: a node takes 128 rows -- a DATA compression of l || r (start state IV) and
 64-byte message (start state = DATA's output); node g of tree t sits at rows 128 (t N + g), heap numbering (1 = root,
 children 2g, 2g+1, leaves N..2N-1, slot 0 = a dummy).  The compression rows are ShaChainAir's (oracle/sha_air.py:
 bit-decomposed, one round per row, same column layout); everything positional (which rows load message words, node
-ids, which tree) is a PERIODIC column, so the only witness besides the SHA state is the pair of leaf-enable flags
+ids, which tree) is a PERIODIC column, so the only witness besides the SHA rows is the pair of leaf-enable flags
 ENL / ENR of a bottom-level node: a disabled leaf must be zero and takes nothing from the bus.
 Bus (tuples (t0, t1, t2, t3, tag), see blake_air): row r < 16 of a DATA block receives message word r --
   inner nodes and the bottom level of tree 0:  (tree, child id, r mod 8, word)            [words]
@@ -79,7 +79,7 @@ def make_air(N):
         def lookups(loc, per):
             """13 (multiplicity, tag, tuple) of a row; receives carry a minus sign."""
             en_l, en_r = loc[ENL], loc[ENR]
-            w0 = [loc[H.WW(0, i)] for i in range(32)]
+            w0 = [loc[H.W0B + i] for i in range(32)]
 
             def val(bits):
                 acc = bits[-1]
@@ -92,7 +92,7 @@ def make_air(N):
             for q in range(4):
                 out.append((mb, TAG_BYTE, (per[P_CID], per[P_JJ] * 4 + q, val(w0[24 - 8 * q: 32 - 8 * q]))))
             for j in range(8):
-                out.append((per[P_PS], TAG_WORD, (per[P_TREE], per[P_GID], per[P_SEL0] * 0 + j, val([loc[H.FFB(j, i)] for i in range(32)]))))
+                out.append((per[P_PS], TAG_WORD, (per[P_TREE], per[P_GID], per[P_SEL0] * 0 + j, loc[H.FFV0 + j])))
             return out
 
         @staticmethod
@@ -112,74 +112,16 @@ def make_air(N):
         @staticmethod
         def eval(loc, nxt, per, pub, c, chal, aux_pub):
             X2 = S.X2
-            sel0, sel63, sched_on, kr, is_data = per[P_SEL0], per[P_SEL63], per[P_SCHED], per[P_K], per[P_DATA]
-            in_block = 1 - sel63
-            two32 = 1 << 32
-
-            def val(row, col0, nb=32):
-                acc = row[col0 + nb - 1]
-                for i in range(nb - 2, -1, -1):
-                    acc = acc + acc + row[col0 + i]
-                return acc
-
-            # ---- 1. booleans: every bit column
-            for col in range(0, H.HIN0):
-                c.constraint(loc[col] * (loc[col] - 1))
-
-            # ---- 2. three-input XORs as x + y + z = r + 2 c
-            def xor3(col0, rots, shift, colr, colc):
-                for i in range(32):
-                    acc = loc[col0 + (i + rots[0]) % 32] + loc[col0 + (i + rots[1]) % 32]
-                    if shift is None:
-                        acc = acc + loc[col0 + (i + rots[2]) % 32]
-                    elif i + shift < 32:
-                        acc = acc + loc[col0 + i + shift]
-                    c.constraint(acc - loc[colr + i] - 2 * loc[colc + i])
-
-            xor3(H.WW(1, 0), (7, 18), 3, H.S0R, H.S0C)
-            xor3(H.WW(14, 0), (17, 19), 10, H.S1R, H.S1C)
-            xor3(H.ST(4, 0), (6, 11, 25), None, H.E1R, H.E1C)
-            xor3(H.ST(0, 0), (2, 13, 22), None, H.A0R, H.A0C)
-            for i in range(32):
-                c.constraint(loc[H.ST(0, i)] + loc[H.ST(1, i)] + loc[H.ST(2, i)] - 2 * loc[H.MAJ + i] - loc[H.PAR + i])
-            # ---- 3. the round
-            ch = None
-            for i in range(31, -1, -1):
-                e, f, g = loc[H.ST(4, i)], loc[H.ST(5, i)], loc[H.ST(6, i)]
-                bit = e * f + (1 - e) * g
-                ch = bit if ch is None else ch + ch + bit
-            t1 = val(loc, H.ST(7, 0)) + val(loc, H.E1R) + ch + kr + val(loc, H.WW(0, 0))
-            c.constraint(val(loc, H.NE0) + two32 * val(loc, H.CE0, 3) - (val(loc, H.ST(3, 0)) + t1))
-            c.constraint(val(loc, H.NA0) + two32 * val(loc, H.CA0, 3) - (t1 + val(loc, H.A0R) + val(loc, H.MAJ)))
-            # ---- 4. state shift inside a block
-            for i in range(32):
-                c.constraint(in_block * (nxt[H.ST(0, i)] - loc[H.NA0 + i]))
-                c.constraint(in_block * (nxt[H.ST(4, i)] - loc[H.NE0 + i]))
-                for wd in (1, 2, 3, 5, 6, 7):
-                    c.constraint(in_block * (nxt[H.ST(wd, i)] - loc[H.ST(wd - 1, i)]))
-            # ---- 5. message schedule
-            for j in range(15):
-                for i in range(32):
-                    c.constraint(in_block * (nxt[H.WW(j, i)] - loc[H.WW(j + 1, i)]))
-            c.constraint(sched_on * (val(nxt, H.WW(15, 0)) + two32 * val(loc, H.CW0, 2)
-                                     - (val(loc, H.S1R) + val(loc, H.WW(9, 0)) + val(loc, H.S0R) + val(loc, H.WW(0, 0)))))
-            # ---- 6. feed-forward at r = 63
-            s64 = [H.NA0, H.ST(0, 0), H.ST(1, 0), H.ST(2, 0), H.NE0, H.ST(4, 0), H.ST(5, 0), H.ST(6, 0)]
-            for wd in range(8):
-                c.constraint(sel63 * (val(loc, H.FFB(wd, 0)) + two32 * loc[H.FFC0 + wd] - (loc[H.HIN0 + wd] + val(loc, s64[wd]))))
-            # ---- 7. block boundary: the PAD block starts from the DATA block's output, a DATA block from IV
-            for wd in range(8):
-                for i in range(32):
-                    iv = (H.IV[wd] >> i) & 1
-                    c.constraint(sel63 * (nxt[H.ST(wd, i)] - (is_data * loc[H.FFB(wd, i)] + (1 - is_data) * iv)))
-                c.constraint(sel0 * (loc[H.HIN0 + wd] - val(loc, H.ST(wd, 0))))
-                c.constraint(in_block * (nxt[H.HIN0 + wd] - loc[H.HIN0 + wd]))
+            sel0, is_data = per[P_SEL0], per[P_DATA]
+            val = H.val
+            # ---- 1-7. the compression rows (shared with ShaChainAir); a PAD block continues from its DATA block
+            H.compression_constraints(loc, nxt, per, c, is_data)
             # ---- 8. the PAD block's message, the root, zero leaves
             for j in range(16):
-                c.constraint(sel0 * (1 - is_data) * (val(loc, H.WW(j, 0)) - H.PAD64[j]))
+                c.constraint(sel0 * (1 - is_data) * (H.window(loc, j) - H.PAD64[j]))
             for j in range(8):
-                c.constraint(per[P_ROOT] * (val(loc, H.FFB(j, 0)) - (pub[j] + per[P_TREE] * (pub[8 + j] - pub[j]))))
-            w0 = val(loc, H.WW(0, 0))
+                c.constraint(per[P_ROOT] * (loc[H.FFV0 + j] - (pub[j] + per[P_TREE] * (pub[8 + j] - pub[j]))))
+            w0 = val(loc, H.W0B)
             c.constraint((per[P_PWL] + per[P_PBL]) * (1 - loc[ENL]) * w0)
             c.constraint((per[P_PWR] + per[P_PBR]) * (1 - loc[ENR]) * w0)
             # ---- 9. the bus (logUp): helpers and running sum of the local row
@@ -259,50 +201,9 @@ def gen_trace(state_roots, data_roots, N):
     tr = np.zeros((COLS, n), dtype=np.uint64)
     words = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "big") for j in range(len(b) // 4)]  # noqa: E731
 
-    def bits(row, col0, val, nb=32):
-        for i in range(nb):
-            tr[col0 + i, row] = (val >> i) & 1
-
     def fill_block(base, h_in, block, en):
-        rows, st64, out = H.compress_rows(h_in, block)
-        for r in range(64):
-            row, rec = base + r, rows[r]
-            a, b, c, d, e, f, g, h = rec["st"]
-            for wd in range(8):
-                bits(row, H.ST(wd, 0), rec["st"][wd])
-            bits(row, H.NA0, rec["na"])
-            bits(row, H.NE0, rec["ne"])
-            for j in range(16):
-                bits(row, H.WW(j, 0), rec["w"][j])
-            w1, w14 = rec["w"][1], rec["w"][14]
-
-            def xor3(x, y, z, colr, colc):
-                for i in range(32):
-                    s = ((x >> i) & 1) + ((y >> i) & 1) + ((z >> i) & 1)
-                    tr[colr + i, row], tr[colc + i, row] = s & 1, s >> 1
-
-            rr = H.rotr
-            xor3(rr(w1, 7), rr(w1, 18), w1 >> 3, H.S0R, H.S0C)
-            xor3(rr(w14, 17), rr(w14, 19), w14 >> 10, H.S1R, H.S1C)
-            xor3(rr(e, 6), rr(e, 11), rr(e, 25), H.E1R, H.E1C)
-            xor3(rr(a, 2), rr(a, 13), rr(a, 22), H.A0R, H.A0C)
-            for i in range(32):
-                s = ((a >> i) & 1) + ((b >> i) & 1) + ((c >> i) & 1)
-                tr[H.MAJ + i, row], tr[H.PAR + i, row] = s >> 1, s & 1
-            bits(row, H.CE0, rec["ce"], 3)
-            bits(row, H.CA0, rec["ca"], 3)
-            if r <= 47:
-                s0 = rr(w1, 7) ^ rr(w1, 18) ^ (w1 >> 3)
-                s1 = rr(w14, 17) ^ rr(w14, 19) ^ (w14 >> 10)
-                bits(row, H.CW0, (s1 + rec["w"][9] + s0 + rec["w"][0]) >> 32, 2)
-            if r == 63:
-                for wd in range(8):
-                    tot = h_in[wd] + st64[wd]
-                    bits(row, H.FFB(wd, 0), tot & H.M32)
-                    tr[H.FFC0 + wd, row] = tot >> 32
-            for wd in range(8):
-                tr[H.HIN0 + wd, row] = h_in[wd]
-            tr[ENL, row], tr[ENR, row] = en
+        out = H.fill_block(tr, base, h_in, block)
+        tr[ENL, base: base + 64], tr[ENR, base: base + 64] = en
         return out
 
     pub = []

@@ -28,13 +28,18 @@ def test_trace_satisfies_constraints_and_detects_corruption(oracle):
     tr, pub, final = A.gen_trace(pks, 9)
     assert final == chain(pks) == oracle.authority_set_hash(np.frombuffer(b"".join(pks), dtype=np.uint8))
     assert pub == [int.from_bytes(final[4 * j: 4 * j + 4], "big") for j in range(8)]
-    assert A.first_violation(tr, pub) is None
-    for col, row in ((A.ST(2, 5), 70), (A.WW(3, 1), 130), (A.NA0 + 7, 200), (A.FFB(1, 3), 127), (A.DG0 + 2, 300), (A.T_PAD, 140),
-                     (A.CE0, 10), (A.MAJ + 4, 99), (A.HIN0 + 1, 66), (A.S1R + 9, 20), (A.CW0, 5)):
+    assert S.check_trace(A.ShaChainAir, tr, pub) is None
+    # bit cells, value cells (d / h, window values, feed-forward), registers, flags, carries
+    for col, row in ((A.C_ + 5, 70), (A.DV, 100), (A.HV, 64), (A.WV(3), 130), (A.WV15, 10), (A.W14B + 7, 33), (A.NA0 + 7, 200), (A.FFV0 + 1, 127),
+                     (A.DG0 + 2, 300), (A.T_PAD, 140), (A.CE0, 10), (A.MAJ + 4, 99), (A.HIN0 + 1, 66), (A.S1R + 9, 20), (A.CW0, 5)):
         bad = tr.copy()
         bad[col, row] ^= np.uint64(1)
-        assert A.first_violation(bad, pub, rows=range(max(0, row - 1), row + 1)) is not None, (col, row)
-    assert A.first_violation(tr, [pub[0] ^ 1] + pub[1:], rows=[511]) is not None
+        assert S.check_trace(A.ShaChainAir, bad, pub, rows=(max(0, row - 2), row + 2)) is not None, (col, row)
+    # a value cell off by 2^32 (same word modulo 2^32) is caught where the value becomes bits
+    bad = tr.copy()
+    bad[A.WV(5), 200] += np.uint64(1 << 32)
+    assert S.check_trace(A.ShaChainAir, bad, pub, rows=(190, 210)) is not None
+    assert S.check_trace(A.ShaChainAir, tr, [pub[0] ^ 1] + pub[1:], rows=(510, 512)) is not None
 
 
 @pytest.mark.parametrize("n_keys,log_n", [(1, 6), (2, 8), (4, 9)])

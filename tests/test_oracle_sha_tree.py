@@ -69,7 +69,7 @@ def test_tree_constraints_roots_and_bus_balance(oracle):
         a2, ap2 = A.gen_aux(t2, CHAL, tpub)
         assert balance(apub_a, 1 << 16, ap2, 256 * N) != [0, 0] or S.check_trace(A, t2, tpub, CHAL, a2, ap2) is not None
     # single-cell corruptions of the tree trace
-    for col, row in ((T.H.ST(2, 7), 300), (T.H.WW(0, 3), 128 * 9 + 2), (T.H.FFB(1, 0), 128 * 3 + 127), (T.H.HIN0 + 2, 128 * 5 + 70)):
+    for col, row in ((T.H.C_ + 7, 300), (T.H.W0B + 3, 128 * 9 + 2), (T.H.FFV0 + 1, 128 * 3 + 127), (T.H.HIN0 + 2, 128 * 5 + 70), (T.H.DV, 128 * 2 + 9)):
         bad = ttr.copy()
         bad[col, row] ^= np.uint64(1)
         assert S.check_trace(A, bad, tpub, CHAL, taux, apub_b, rows=(max(0, row - 2), row + 2)) is not None, (col, row)
