@@ -645,6 +645,7 @@ def verify(proof, cfg=None, expect_air=None, expect_public=None, ext_chal=None):
 
     magic, air_id, L, c, nq, r, cap_h, n_queries, pow_bits, n_layers = take(10)
     _need(magic == MAGIC, "bad magic")
+    _need(2 <= L <= 26 and n_layers <= 16, "bad shape")  # before anything is sized by the (untrusted) degree bits
     _need((r, cap_h, n_queries, pow_bits) == (cfg["rate_bits"], cfg["cap_height"], cfg["num_queries"], cfg["pow_bits"]), "config mismatch")
     air = AIRS.get(air_id)
     _need(air is not None and (expect_air is None or air_id == expect_air), "unexpected AIR")
