@@ -117,12 +117,16 @@ def ntt_roofline(ctx, iters=10):
     alg_bytes = 16.0 * n * NTT_COLS
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r01_ntt_traffic.json")
-    if os.path.exists(tpath):  # PMC counters cannot be read from inside the bench: committed rocprofv3 --pmc result
+    for tag in ("r02", "r01"):  # PMC counters cannot be read from inside the bench: the committed rocprofv3 --pmc result of this kernel
+        tpath = os.path.join(ROOT, "profiles", f"{tag}_ntt_traffic.json")
+        if not os.path.exists(tpath):
+            continue
         t = json.load(open(tpath))
         if t["shape"].startswith(f"forward NTT 2^{NTT_LOG_N} x {NTT_COLS}"):
             traffic = round(t["hbm_bytes_per_transform"] / 1e9, 3)
-            traffic_src = "profiles/r01_ntt_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), calibrated on known 8-B/lane streams; GB per transform"
+            traffic_src = (f"profiles/{tag}_ntt_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/ntt_pmc.py), calibrated on known "
+                           "8-B/lane streams; GB per transform")
+            break
     return {
         "bound": "hbm", "kernel": "k_ntt_tile", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -149,18 +153,26 @@ def poseidon_roofline(ctx, vx, iters=3):
     buf.free()
     perms = n * ((cols + 7) // 8) + (n - 16)
     alg_bytes = 8.0 * n * cols + 32.0 * (2 * n - 16)
-    # VALU-issue peak: every vector instruction of a 64-lane wave-permutation issuing back to back on its SIMD --
-    # 11.3 k VALU instructions per wave-permutation (rocprofv3 --pmc SQ_INSTS_VALU, profiles/r01_pmc_valu_by_kernel_final.json)
-    # at 4.3 cycles each (the 64-bit / VOP3 class this code is made of, tools/isa_rate.hip -> profiles/r01_isa_issue_rates.json)
-    rates = json.load(open(os.path.join(ROOT, "profiles", "r01_isa_issue_rates.json")))
-    cyc = 11300 * rates["rates"]["v_lshl_add_u64@4wps"]
-    peak = rates["cus"] * 4 * rates["clock_hz"] * 64 / cyc / 1e9
+    # VALU-issue peak, measured in this run on this clock: the bare permutation kernel (vx_poseidon_permute_batch: one
+    # permutation per lane on 2^23 independent states, 96 B in / 96 B out per lane, no sponge, no tree) -- the same
+    # instruction stream without the leaf walk.  ISA accounting (profiles/README.md): ~16 k VALU instructions per
+    # wave-permutation at ~4.2 issue cycles each.
+    n_states = 1 << 23
+    st = ctx.alloc(12 * n_states)
+    ctx.fill_random(st, 12 * n_states, 13)
+    ctx.poseidon(st, n_states)
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(iters):
+        ctx.poseidon(st, n_states)
+    peak = n_states / (ctx.timer_stop() / iters * 1e-3) / 1e9
+    st.free()
     ach = perms / (ms * 1e-3) / 1e9
     return {"bound": "valu", "kernel": "k_hash_leaves + k_merkle_level (vx_merkle_build)", "achieved": round(ach, 3), "peak": round(peak, 3),
             "unit": "G permutations/s", "frac": round(ach / peak, 4),
             "per": f"Merkle tree over 2^{log_leaves} leaves x {cols} columns, cap height 4 = {perms / 1e6:.1f} M Poseidon permutations, {ms:.2f} ms",
-            "peak_source": "1024 SIMDs x 2.4 GHz x 64 lanes / (11.3 k VALU instructions per wave-permutation x 4.3 issue cycles): profiles/r01_pmc_valu_by_kernel_final.json, "
-                           "profiles/r01_isa_issue_rates.json (the same code with its state in registers and no loads measures 2.54 G/s)",
+            "peak_source": "measured in this run: vx_poseidon_permute_batch on 2^23 independent states (the bare permutation, one per lane: ~16 k VALU "
+                           "instructions per wave-permutation at ~4.2 issue cycles, profiles/r01_isa_issue_rates.json); the leaf kernel adds the sponge walk over the row",
             "hbm": {"achieved": round(alg_bytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "algorithmic_GB": round(alg_bytes / 1e9, 3)}}
 
