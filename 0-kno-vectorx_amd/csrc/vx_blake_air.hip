@@ -296,7 +296,10 @@ struct AuxArgs {
     gl2 beta, gamma;
     uint64_t first_number, tree_size, bus_on;  // public inputs 16, 18, 19: leaf = NUM - first, node id = tree_size + leaf
 };
-__global__ __launch_bounds__(256) void k_blake_aux(AuxArgs a) {
+#ifndef VX_AUX_WAVES
+#define VX_AUX_WAVES 4  // measured: 2 -> 6.7 ms, 3 -> 6.4, 4 -> 4.9 (64 VGPRs + scratch: the kernel lives on occupancy hiding its dependent multiply chains)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_AUX_WAVES, VX_AUX_WAVES))) void k_blake_aux(AuxArgs a) {
     using namespace blk;
     const size_t n = a.n, i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const int unit = blockIdx.y;

@@ -18,11 +18,15 @@ def short(k):
 def main(d, out):
     agg = defaultdict(lambda: defaultdict(float))
     launches = defaultdict(set)
+    seen_in = defaultdict(set)  # a counter collected in several passes (files) is averaged, not added up
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            seen_in[(k, r["Counter_Name"])].add(f)
             launches[k].add(r["Dispatch_Id"])
+    for (k, n), files in seen_in.items():
+        agg[k][n] /= len(files)
     res = {}
     for k, c in agg.items():
         e = {"launches": len(launches[k]), **{n: v for n, v in sorted(c.items())}}
