@@ -385,12 +385,13 @@ struct BlakeAir {
                 const F leaf = nxt[NUM] - pub[16], bus_on = pub[19];  // bus_on = 0: a stand-alone proof, nothing on the bus
                 const F pos0 = nxt[T] - nxt[INC] + r8n - nxt[SZ] + F::from(32);
                 const X2<F> base = beta + leaf + g4 * F::from(TAG_BYTE);
+                const F live = nxt[ACT] * bus_on;  // an inactive (padding / junk) message shares its block number with the last real header: it must not send
 #pragma unroll 1
                 for (int pair = 0; pair < 4; ++pair) {
                     const int e = HB0 + pair, b0 = 2 * pair, b1 = b0 + 1;
                     const X2<F> du = base + gamma * (pos0 + F::from(b0)) + g2 * nxt[MB0 + b0], dv = base + gamma * (pos0 + F::from(b1)) + g2 * nxt[MB0 + b1];
                     const X2<F> h{nxt[AX(e, 0)], nxt[AX(e, 1)]};
-                    c.constraint_x2(h * du * dv - dv * (nxt[E0 + b0] * bus_on) - du * (nxt[E0 + b1] * bus_on));
+                    c.constraint_x2(h * du * dv - dv * (nxt[E0 + b0] * live) - du * (nxt[E0 + b1] * live));
                     hsum = hsum + h;
                 }
                 // state root: big-endian words of bytes 0..3 (rows 5..8 -> words 1, 3, 5, 7) and 4..7 (rows 4..7 -> words 0, 2, 4, 6) of

@@ -96,6 +96,10 @@ __global__ __launch_bounds__(64) void k_blake_chain(const uint8_t* msgs, size_t 
 //   k_blake_expand  one block per (2048 rows, packed word): every cell is (word >> shift) & mask, and a block writes
 //                   16 KB runs of one column at a time.
 // Packed words: 8 per G (A1 D1 C1 B1 A2 D2 C2 X; L / T are the low 7 bits / top bit of X's bytes), then
+#ifndef VX_HIST_COPIES
+#define VX_HIST_COPIES 8
+#endif
+constexpr int HIST_COPIES = VX_HIST_COPIES;
 constexpr int SW_CAR = 64, SW_MS = 65, SW_MB = 81, SW_HL = 82, SW_D = 90, SW_FLAGS = 94, SW_TN = 95, N_STAGE = 96;
 // SW_CAR: 32 carries x 2 bits; SW_MS: the 16 message words in this row's order; SW_D: 4 words of two limbs;
 // SW_FLAGS: ACT FIN FIRST CAP FA (bits 0..4), INC (8..15), CNT (16..23), MK (24..31), E (32..39), SZ (40..63); SW_TN: T (low half), NUM (high half)
@@ -137,13 +141,16 @@ __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const 
     }
     auto st = [&](int w) -> uint64_t& { return stage[(size_t)w * n + row]; };
     auto gw = [&](int k, int slot) -> uint64_t& { return st(8 * k + slot); };  // slot 7 = X (L / T)
+    // HIST_COPIES private copies of the two histograms, picked by block index: consecutive blocks go to different XCDs (each
+    // with its own L2), and counters shared by all of them bounce between the L2s; k_blake_mult adds the copies up
+    uint32_t* const hc = hist + (size_t)(blockIdx.x % HIST_COPIES) * 131072;
     auto look1 = [&](uint64_t a, uint64_t bq) {  // 8 byte lookups (a_i, b_i, .) into T1
 #pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(&hist[((a >> (8 * j)) & 0xFF) | (((bq >> (8 * j)) & 0xFF) << 8)], 1u);
+        for (int j = 0; j < 8; ++j) atomicAdd(&hc[((a >> (8 * j)) & 0xFF) | (((bq >> (8 * j)) & 0xFF) << 8)], 1u);
     };
     auto look2 = [&](uint64_t a, uint64_t bq) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(&hist[65536 + (((a >> (8 * j)) & 0xFF) | (((bq >> (8 * j)) & 0xFF) << 8))], 1u);
+        for (int j = 0; j < 8; ++j) atomicAdd(&hc[65536 + (((a >> (8 * j)) & 0xFF) | (((bq >> (8 * j)) & 0xFF) << 8))], 1u);
     };
     // ---- G area + carries
     blake_init_v(v, h, d.t, d.fin);
@@ -275,11 +282,13 @@ static void blake_expand_table(std::vector<ExpandEntry>& ent, std::vector<uint32
 __global__ __launch_bounds__(256) void k_blake_mult(const uint32_t* hist, const uint32_t* rc_part, uint64_t* tr, size_t n) {
     const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (row >= n) return;
-    uint64_t m1 = row < 65536 ? hist[row] : 0;
+    uint64_t m1 = 0, m2 = 0;
+    if (row < 65536)
+        for (int cpy = 0; cpy < HIST_COPIES; ++cpy) m1 += hist[(size_t)cpy * 131072 + row], m2 += hist[(size_t)cpy * 131072 + 65536 + row];
     if (row < 256)  // table rows (a, b = 0): plus the per-block range-check counts
         for (size_t b = 0; b < n / 256; ++b) m1 += rc_part[b * 256 + row];
     tr[(size_t)blk::M1 * n + row] = m1;
-    tr[(size_t)blk::M2 * n + row] = row < 65536 ? hist[65536 + row] : 0;
+    tr[(size_t)blk::M2 * n + row] = m2;
 }
 
 // ---- auxiliary columns (logUp) --------------------------------------------------------------------------------------
@@ -436,7 +445,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_AUX_WAVE
 #pragma unroll 1
             for (int pair = 0; pair < 4; ++pair) {
                 gl2 h{0, 0};
-                const uint64_t e0 = a.bus_on ? N(E0 + 2 * pair) : 0, e1 = a.bus_on ? N(E0 + 2 * pair + 1) : 0;
+                const bool live = a.bus_on && N(ACT);
+                const uint64_t e0 = live ? N(E0 + 2 * pair) : 0, e1 = live ? N(E0 + 2 * pair + 1) : 0;
                 if (e0 | e1) {
                     const gl2 du = gl2_add(bbase, gl2_add(gl2_scale(gamma, gl_add(pos0, 2 * pair)), gl2_scale(g2, N(MB0 + 2 * pair))));
                     const gl2 dv = gl2_add(bbase, gl2_add(gl2_scale(gamma, gl_add(pos0, 2 * pair + 1)), gl2_scale(g2, N(MB0 + 2 * pair + 1))));
@@ -546,7 +556,7 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
     // device scratch: sizes | block_base | digests | hchain | descs
     const size_t w_sizes = (n_headers * 4 + 7) / 8, w_dig = n_headers * 4, w_hc = n_real * 8;
     const size_t w_desc = (n_blocks * sizeof(BlockDesc) + 7) / 8;
-    const size_t w_hist = 65536 + n / 2;  // two tables x 2^16 uint32 counters + 256 range-check counters per 256-row block
+    const size_t w_hist = (size_t)HIST_COPIES * 65536 + n / 2;  // HIST_COPIES x two tables x 2^16 uint32 counters + 256 range-check counters per 256-row block
     std::vector<ExpandEntry> ent;
     std::vector<uint32_t> eoff;
     blake_expand_table(ent, eoff);
@@ -606,14 +616,14 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
         memcpy(d.D, D, 32);
     }
     VX_HIP(hipMemcpyAsync(d_desc, descs.data(), n_blocks * sizeof(BlockDesc), hipMemcpyHostToDevice, ctx->stream));
-    VX_HIP(hipMemsetAsync(d_hist, 0, 65536 * 8, ctx->stream));
+    VX_HIP(hipMemsetAsync(d_hist, 0, (size_t)HIST_COPIES * 65536 * 8, ctx->stream));
     hipLaunchKernelGGL(k_blake_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t*)headers->d,
-                       (const BlockDesc*)d_desc, (const uint64_t*)d_hc, n_real, d_stage, d_hist, d_hist + 131072, n);
+                       (const BlockDesc*)d_desc, (const uint64_t*)d_hc, n_real, d_stage, d_hist, d_hist + (size_t)HIST_COPIES * 131072, n);
     VX_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_blake_expand, dim3((unsigned)((n + 256 * EXP_RPL - 1) / (256 * EXP_RPL)), N_STAGE), dim3(256), 0, ctx->stream,
                        (const uint64_t*)d_stage, trace_out->d, n, (const ExpandEntry*)d_ent, (const uint32_t*)d_eoff);
     VX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_blake_mult, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_hist, (const uint32_t*)(d_hist + 131072), trace_out->d, n);
+    hipLaunchKernelGGL(k_blake_mult, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_hist, (const uint32_t*)(d_hist + (size_t)HIST_COPIES * 131072), trace_out->d, n);
     VX_HIP(hipGetLastError());
     VX_HIP(hipStreamSynchronize(ctx->stream));  // descs must outlive the kernel
     for (int j = 0; j < 8; ++j) {
@@ -812,8 +822,7 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
     if (rc != VX_OK && rc != VX_ERR_BUFSZ) rv.fail();  // do not leave the Merkle prover waiting at its hook
     if (trace) (void)vx_free(ctx, trace);
     if (tree_thread.joinable()) tree_thread.join();
-    if (rc_tree != VX_OK && side2) (void)vx_fail(ctx, rc_tree, "%s", vx_last_error(side2));
-    if ((rc == VX_OK || rc == VX_ERR_BUFSZ) && rc_tree != VX_OK) rc = rc_tree;
+    if ((rc == VX_OK || rc == VX_ERR_BUFSZ) && rc_tree != VX_OK) rc = side2 ? vx_fail(ctx, rc_tree, "%s", vx_last_error(side2)) : rc_tree;
     if (sha_thread.joinable()) sha_thread.join();
     else if (just) rc_sha = prove_sha(ctx);  // no side context: one after the other
     if (just) {

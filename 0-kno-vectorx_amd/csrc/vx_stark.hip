@@ -705,7 +705,8 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
         if (hook) {
             // lookup challenges SHARED with other tables (a bus between AIRs): the caller derives them once every
             // table's trace cap exists; this transcript absorbs them so that everything after depends on them
-            VX_TRY(hook->fn(hook->user, public_inputs, n_public, proof.data() + proof.size() - cap_words, cap_words, chal, (size_t)air->chal));
+            const int32_t hr = hook->fn(hook->user, public_inputs, n_public, proof.data() + proof.size() - cap_words, cap_words, chal, (size_t)air->chal);
+            if (hr != VX_OK) return vx_fail(ctx, hr, "stark prove: no shared challenges (the prover of the other table on the bus gave up)");
             for (int q = 0; q < air->chal; ++q) VX_CHECK(chal[q] < glh::P, "stark prove: shared challenge %d is not canonical", q);
             ch.observe(chal, (size_t)air->chal);
         } else

@@ -184,7 +184,8 @@ def lookups(loc, nxt, sel, pub=None):
     leaf = nxt[NUM] - pub[16]
     pos0 = nxt[T] - nxt[INC] + r8n - nxt[SZ] + 32
     bus_on = pub[19]  # 0 for a stand-alone proof (nothing on the bus, published total 0), 1 next to the Merkle AIR
-    out += [(nxt[E0 + b] * bus_on, TAG_BYTE, (leaf, pos0 + b, nxt[MB0 + b])) for b in range(8)]
+    live = nxt[ACT] * bus_on  # an inactive (padding / junk) message shares its block number with the last real header: it must not send
+    out += [(nxt[E0 + b] * live, TAG_BYTE, (leaf, pos0 + b, nxt[MB0 + b])) for b in range(8)]
     su, ju = sel[4] + sel[5] + sel[6] + sel[7], sel[4] + sel[5] * 3 + sel[6] * 5 + sel[7] * 7   # next row 5..8: words 1, 3, 5, 7 (bytes 0..3)
     sv, jv = sel[3] + sel[4] + sel[5] + sel[6], sel[4] * 2 + sel[5] * 4 + sel[6] * 6             # next row 4..7: words 0, 2, 4, 6 (bytes 4..7)
     be = lambda o: ((nxt[MB0 + o] * 256 + nxt[MB0 + o + 1]) * 256 + nxt[MB0 + o + 2]) * 256 + nxt[MB0 + o + 3]  # noqa: E731

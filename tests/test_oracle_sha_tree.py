@@ -96,3 +96,17 @@ def test_tree_prove_verify_under_shared_challenges(oracle):
         S.verify(proof, cfg)
     with pytest.raises(S.VerifyError):  # and other challenges do not fit the transcript
         S.verify(proof, cfg, ext_chal=[c ^ 1 for c in chal])
+
+
+def test_inactive_messages_cannot_send_on_the_bus(oracle):
+    """Soundness: a padding / junk message (ACT = 0) carries the block number of the last real header, so its data-root flags
+    must not count -- otherwise it could feed the Merkle table bytes of its own in place of that header's data root."""
+    msgs, trusted, _ = make([200, 90])
+    tr, pub, _ = B.gen_trace(msgs, 16, trusted, tree_size=N)
+    aux, apub = B.BlakeChainAir.gen_aux(tr, CHAL, pub)
+    forged = tr.copy()
+    pad_rows = slice(16 * 3, 16 * 3 + 16)  # block 3 is the first padding block (2 + 1 chunks before it)
+    assert int(forged[B.ACT, 16 * 3]) == 0
+    forged[B.E0:B.E0 + 8, pad_rows] = 1
+    aux2, apub2 = B.BlakeChainAir.gen_aux(forged, CHAL, pub)
+    assert apub2 == apub and S.check_trace(B.BlakeChainAir, forged, pub, CHAL, aux2, apub2, rows=(30, 80)) is None
