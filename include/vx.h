@@ -226,6 +226,16 @@ enum { VX_AIR_SHA_CHAIN = 4, VX_SHA_AIR_COLS = 731 };
 int32_t vx_sha_chain_trace(vx_ctx* ctx, const uint8_t* pubkeys, size_t n_keys, int log_n, vx_buf* trace_out,
                            uint64_t public_inputs_out[8], uint8_t commitment_out[32]);
 
+/* ---- K8: EdAir trace generation (the curve half of the 300 conditional EdDSA verifications, justification.rs:229-243):
+ * n_signatures slots (pubkey 32 B, signature R || S 64 B, flag), all over the same message (the 53-byte precommit); a slot
+ * whose flag is 0 stays idle.  2^log_n rows hold 2^log_n / 256 slots (300 signatures need log_n = 17).  Writes the
+ * 838-column trace and the 2 public inputs (number of signed slots, bus_on); VX_ERR_STATEMENT when a signed slot does
+ * not verify.  bus_on = 0 makes a stand-alone table (nothing sent to the SHA-512 / authority-set tables).
+ * Prove with vx_stark_prove(ctx, VX_AIR_ED25519 (2^17 rows) or VX_AIR_ED25519_16 (2^16 rows), ...). */
+enum { VX_AIR_ED25519 = 10, VX_AIR_ED25519_16 = 12, VX_ED_AIR_COLS = 838, VX_ED_AIR_AUX_COLS = 688 };
+int32_t vx_ed_trace(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* signatures, const uint8_t* message, uint32_t message_len, const uint8_t* signed_flags,
+                    size_t n_signatures, int log_n, uint32_t bus_on, vx_buf* trace_out, uint64_t public_inputs_out[2]);
+
 /* ---- statement level: verify_subchain (circuits/builder/subchain_verification.rs:56-303)
  * headers: n_fetched encoded headers (blocks trusted+1 .. target) resident in HBM at `stride`
  * bytes each (zero padded), sizes on the host.  max_headers = 256 / 512

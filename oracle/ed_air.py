@@ -1,0 +1,664 @@
+"""EdAir (AIR id 10): Ed25519 verification of the justification's signed precommits -- TEST INFRASTRUCTURE.
+
+Statement per signed slot i: "[S_i] B = R_i + [h_i] A_i on edwards25519, with h_i = H_i mod l" -- the curve half of
+verify_simple_justification's conditional signature checks (/root/reference circuits/builder/justification.rs:229-243,
+native mirror circuits/input/mod.rs:241-247; curta's EdDSA gadget, starkyx v1.0.0, is not vendored, so this is a
+from-scratch arithmetisation, not a restatement of it).  A_i (compressed) arrives over the bus from the authority-set
+SHA-256 chain, R_i || A_i goes to, and the 64-byte digest H_i comes back from, the SHA-512 table (oracle/sha512_air.py).
+
+Field elements mod q = 2^255 - 19 are 16 limbs of 16 bits.  One GADGET proves c = a * b (mod q) for limb vectors a, b
+that are LINEAR in trace cells (sums / differences of earlier results need no cells of their own):
+    F_k = sum_{i+j=k} a_i b_j + 38 sum_{i+j=k+16} a_i b_j                       (2^256 = 38 mod q)
+    F_k + rin_k - c_k = 2^16 r_k,   rin_0 = 38 r_15,  rin_k = r_(k-1)           k = 0..15
+which sums to  F(2^16) - c = 2 q r_15.  c_k and the two halves of r_k = rlo + 2^16 rhi - 2^31 are range-checked 16-bit
+cells (logUp into a periodic table 0..65535), so |every term| < 2^49 and the identity holds over the integers.  A
+ZERO-CHECK is the same gadget without c on twice the expression (2 e = 0 mod 2q iff e = 0 mod q); its c cells are
+free range-checked storage.  48 cells and 48 lookups per gadget, 14 gadgets per row.
+
+A slot is 256 rows:  row 0 SETUP-A, row 1 SETUP-B, rows 2..254 STEP (scalar bit 252 - (r - 2)), row 255 FINAL.
+  STEP   (X, Y, Z) = the previous row's gadgets 11..13:  Q' = 2 Q + addend (dbl-2008-hwcd, madd-2008-hwcd-3, a = -1),
+         addend = (identity, B, -A, B - A) selected by the bits (bs, bh) of S and h, in cached form (y - x, y + x, 2d x y):
+         g0 X^2  g1 Y^2  g2 Z^2  g3 (X+Y)^2 | E = g3-g0-g1, G = g1-g0, F = G-2 g2, H = -g0-g1 | g4 E F  g5 G H  g6 E H  g7 F G
+         g8 (g5-g4) ym  g9 (g5+g4) yp  g10 g6 t2d | D = 2 g7, E' = g9-g8, F' = D-g10, G' = D+g10, H' = g9+g8 | g11 E'F'  g12 G'H'  g13 F'G'
+  SETUP-A  A = (xA, yA) on the curve, both canonical, sign bit; -A and B - A in cached form (the slot's carried columns)
+  SETUP-B  H = qq l + hr, hr < l (the scalar whose bits the STEP rows consume); the accumulator starts at (0, 1, 1)
+  FINAL    (xR Z, yR Z) = (X, Y): the result is the point whose compressed form is R; xR, yR canonical, sign bit.
+Unsigned slots run on all-zero bits (identity throughout) and touch no bus.
+Bus tuples (t0, t1, t2, t3, tag) carry 8 limbs as (index, l0 + 2^16 l1 + 2^32 l2, l3 + .., l6 + 2^16 l7):
+  TAG_KEY   (4 slot + j)      compressed A, quarters j = 0..3 (4 limbs: (index, l0 + 2^16 l1, l2 + 2^16 l3, 0))   received (sent by ShaChainAir for signed keys)
+  TAG_EDMSG (4 slot + part)   R halves (part 0, 1), A halves (2, 3)    sent     (the SHA-512 table's message words 0..7)
+  TAG_EDH   (4 slot + j)      the digest as 32 little-endian limbs     received
+Public inputs: (number of signed slots, bus_on).  Constraint ORDER is protocol (0-kno-vectorx_amd/csrc/air_ed.cuh).
+"""
+import numpy as np
+
+from . import oracle as O
+from . import pyref
+from . import stark_ref as S
+
+P = 2**64 - 2**32 + 1
+ID = 10
+IDS = {17: 10, 16: 12}  # AIR id by log2(rows)
+Q = 2**255 - 19
+ELL = 2**252 + 27742317777372353535851937790883648493
+D_ED = pyref._d
+BX, BY = pyref._Bx, pyref._By
+NG = 14
+CELLS = NG * 48
+XA0, YA0, NT0, X30, Y30, BT0, HR0, SEL0 = 672, 688, 704, 720, 736, 752, 768, 784
+BS, BH, LAH, SG, CNT, MULT, COLS = 832, 833, 834, 835, 836, 837, 838
+N_RANGE, N_BUS = CELLS // 2, 6
+HB0, HT, ZZ = N_RANGE, N_RANGE + N_BUS, N_RANGE + N_BUS + 1
+N_HELP = N_RANGE + N_BUS + 2
+AUX, CHAL, AUXPUB, PUB = 2 * N_HELP, 4, 1, 2
+TAG_R16, TAG_KEY, TAG_EDMSG, TAG_EDH = 4, 5, 6, 7
+# periodic columns (selectors named ..N describe the NEXT row by the local row's position)
+P_S0N, P_S1N, P_STN, P_FINN, P_KEEP, P_STEP, P_LST, P_R0, P_R1, P_R255, P_LE0 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+P_SLOT, P_T, PERIODIC = 26, 27, 28
+
+
+def limbs(x, n=16):
+    return [(x >> (16 * i)) & 0xFFFF for i in range(n)]
+
+
+K2D = limbs(2 * D_ED % Q)
+K2DN = limbs(-2 * D_ED % Q)
+KD = limbs(D_ED)
+KBD = limbs(-D_ED * BX * BY % Q)
+XB, YB = limbs(BX), limbs(BY)
+ONE = [1] + [0] * 15
+ID_C = (ONE, ONE, [0] * 16)  # cached identity
+B_C = (limbs((BY - BX) % Q), limbs((BY + BX) % Q), limbs(2 * D_ED * BX * BY % Q))
+QM1, LM1, LL = limbs(Q - 1), limbs(ELL - 1), limbs(ELL)
+
+
+def C(g, k):
+    return g * 48 + k
+
+
+def RL(g, k):
+    return g * 48 + 16 + k
+
+
+def RH(g, k):
+    return g * 48 + 32 + k
+
+
+def period_logs(L):
+    return [8] * 26 + [L, 16]
+
+
+def periodic_values(n):
+    r = np.arange(256)
+    cols = [None] * PERIODIC
+    cols[P_S0N], cols[P_S1N] = (r == 255), (r == 0)
+    cols[P_STN], cols[P_FINN] = (r >= 1) & (r <= 253), (r == 254)
+    cols[P_KEEP], cols[P_STEP] = (r != 255), (r >= 2) & (r <= 254)
+    nb = 252 - (r + 1 - 2)  # the NEXT row's scalar bit
+    cols[P_LST] = cols[P_STN] & ((nb == 252) | (nb % 16 == 15))
+    cols[P_R0], cols[P_R1], cols[P_R255] = (r == 0), (r == 1), (r == 255)
+    for k in range(16):
+        cols[P_LE0 + k] = cols[P_STN] & (nb == 16 * k)
+    out = [c.astype(np.int64).tolist() for c in cols[:P_SLOT]]
+    out.append((np.arange(n) // 256).tolist())
+    out.append(list(range(65536)))
+    return out
+
+
+def fold(a, b, k):
+    """Coefficient k of a * b folded at 2^256 = 38."""
+    acc = None
+    for i in range(16):
+        j = k - i
+        t = a[i] * b[j] if j >= 0 else (a[i] * b[j + 16]) * 38
+        acc = t if acc is None else acc + t
+    return acc
+
+
+def vadd(a, b):
+    return [x + y for x, y in zip(a, b)]
+
+
+def vsub(a, b):
+    return [x - y for x, y in zip(a, b)]
+
+
+def vscale(a, s):
+    return [x * s for x in a]
+
+
+def cells(row, g):
+    return [row[C(g, k)] for k in range(16)]
+
+
+def carries(row, g):
+    return [row[RL(g, k)] + row[RH(g, k)] * 65536 - (1 << 31) for k in range(16)]
+
+
+def gadget_types(loc, nxt):
+    """Per row type of the NEXT row: {gadget: (F coefficient function, has an output c)}."""
+    X, Y, Z = cells(loc, 11), cells(loc, 12), cells(loc, 13)
+    c = [cells(nxt, g) for g in range(NG)]
+    sel = [[nxt[SEL0 + 16 * t + k] for k in range(16)] for t in range(3)]
+    mul = lambda a, b: (lambda k: fold(a, b, k), True)  # noqa: E731
+    # ---- STEP
+    XY = vadd(X, Y)
+    E, G = vsub(vsub(c[3], c[0]), c[1]), vsub(c[1], c[0])
+    F, H = vsub(G, vscale(c[2], 2)), vsub(vscale(c[0], -1), c[1])
+    Dd = vscale(c[7], 2)
+    E2, F2, G2, H2 = vsub(c[9], c[8]), vsub(Dd, c[10]), vadd(Dd, c[10]), vadd(c[9], c[8])
+    step = {0: mul(X, X), 1: mul(Y, Y), 2: mul(Z, Z), 3: mul(XY, XY), 4: mul(E, F), 5: mul(G, H), 6: mul(E, H), 7: mul(F, G),
+            8: mul(vsub(c[5], c[4]), sel[0]), 9: mul(vadd(c[5], c[4]), sel[1]), 10: mul(c[6], sel[2]),
+            11: mul(E2, F2), 12: mul(G2, H2), 13: mul(F2, G2)}
+    # ---- SETUP-A: xA = c5, yA = c7, x3 = c8, y3 = c11 (B - A = (x3, y3) by the complete addition law, verified crosswise)
+    xa, ya, x3, y3 = c[5], c[7], c[8], c[11]
+    u, xx, yy, dxx, t = c[0], c[2], c[3], c[4], c[6]
+    onep, onem = vadd(ONE, t), vsub(ONE, t)
+    s0 = {0: mul(xa, ya), 1: mul(u, K2DN), 2: mul(xa, xa), 3: mul(ya, ya), 4: mul(xx, KD),
+          5: (lambda k: (yy[k] - xx[k] - ONE[k] - fold(dxx, yy, k)) * 2, False),
+          6: mul(u, KBD),
+          7: (lambda k: (fold(x3, onep, k) - fold(ya, XB, k) + fold(xa, YB, k)) * 2, False),
+          8: (lambda k: (fold(y3, onem, k) - fold(ya, YB, k) + fold(xa, XB, k)) * 2, False),
+          9: mul(x3, y3), 10: mul(c[9], K2D)}
+    # ---- FINAL: xR = c0, yR = c1
+    fin = {0: (lambda k: (fold(c[0], Z, k) - X[k]) * 2, False), 1: (lambda k: (fold(c[1], Z, k) - Y[k]) * 2, False)}
+    return step, s0, fin
+
+
+def canonical_chain(x, w, cy, top):
+    """x + w = top (limb vectors; cy = the 15 carry cells): residuals of the 16 limb identities."""
+    out = []
+    for k in range(16):
+        e = x[k] + w[k] - top[k]
+        if k:
+            e = e + cy[k - 1]
+        if k < 15:
+            e = e - cy[k] * 65536
+        out.append(e)
+    return out
+
+
+def pack8(l, i):
+    return l[i] + l[i + 1] * (1 << 16) + l[i + 2] * (1 << 32), l[i + 3] + l[i + 4] * (1 << 16) + l[i + 5] * (1 << 32), l[i + 6] + l[i + 7] * (1 << 16)
+
+
+def bus_lookups(loc, per, pub):
+    """The six bus lookups of the local row: (multiplicity, tag, (t0, t1, t2, t3)), every entry of degree <= 2.
+    Helpers 0..3: row 0 receives key quarter b (4 limbs), row 1 receives digest part b (8 limbs);
+    helpers 4, 5: row 0 sends A half b - 4 (message parts 2, 3), row 255 sends R half b - 4 (parts 0, 1)."""
+    r0, r1, r255, slot = per[P_R0], per[P_R1], per[P_R255], per[P_SLOT]
+    on = loc[SG] * pub[1]
+    enc_a = [loc[C(7, k)] for k in range(15)] + [loc[C(7, 15)] + loc[BS] * 32768]
+    enc_r = [loc[C(1, k)] for k in range(15)] + [loc[C(1, 15)] + loc[BS] * 32768]
+    hl = [loc[C(0, k)] for k in range(16)] + [loc[RL(0, k)] for k in range(16)]
+    out = []
+    for b in range(4):
+        th = pack8(hl, 8 * b)
+        tk = (enc_a[4 * b] + enc_a[4 * b + 1] * 65536, enc_a[4 * b + 2] + enc_a[4 * b + 3] * 65536)
+        m = on * (0 - r0 - r1)
+        tag = r0 * TAG_KEY + r1 * TAG_EDH
+        out.append((m, tag, ((r0 + r1) * (slot * 4 + b), r0 * tk[0] + r1 * th[0], r0 * tk[1] + r1 * th[1], r1 * th[2])))
+    for b in range(2):
+        ta, tr = pack8(enc_a, 8 * b), pack8(enc_r, 8 * b)
+        m = on * (r0 + r255)
+        tag = (r0 + r255) * TAG_EDMSG
+        t0 = r0 * (slot * 4 + b + 2) + r255 * (slot * 4 + b)
+        out.append((m, tag, (t0, r0 * ta[0] + r255 * tr[0], r0 * ta[1] + r255 * tr[1], r0 * ta[2] + r255 * tr[2])))
+    return out
+
+
+def eval(loc, nxt, per, pub, c, chal, aux_pub):  # noqa: A001
+    X2 = S.X2
+    s0n, s1n, stn, finn, keep = per[P_S0N], per[P_S1N], per[P_STN], per[P_FINN], per[P_KEEP]
+    # ---- 1. booleans
+    for col in (BS, BH, SG):
+        c.constraint(loc[col] * (loc[col] - 1))
+    # ---- 2. the 14 gadgets of the next row, by its type
+    step, s0, fin = gadget_types(loc, nxt)
+    for g in range(NG):
+        r = carries(nxt, g)
+        cg = cells(nxt, g)
+        for k in range(16):
+            tail = (r[15] * 38 if k == 0 else r[k - 1]) - r[k] * 65536
+            acc = None
+            for sel, typ in ((stn, step), (s0n, s0), (finn, fin)):
+                if g in typ:
+                    f, has_c = typ[g]
+                    e = f(k) + tail
+                    if has_c:
+                        e = e - cg[k]
+                    acc = sel * e if acc is None else acc + sel * e
+            c.constraint(acc)
+    # ---- 3. SETUP-A extras: canonical xA, yA; the sign bit; the carried columns take their values
+    xa, ya = cells(nxt, 5), cells(nxt, 7)
+    for x, g in ((xa, 12), (ya, 13)):
+        cy = [nxt[RL(g, k)] for k in range(15)]
+        for e in canonical_chain(x, cells(nxt, g), cy, QM1):
+            c.constraint(s0n * e)
+        for k in range(15):
+            c.constraint(s0n * cy[k] * (cy[k] - 1))
+    c.constraint(s0n * (xa[0] - nxt[RH(12, 0)] * 2 - nxt[BS]))
+    for col0, src in ((XA0, xa), (YA0, ya), (NT0, cells(nxt, 1)), (X30, cells(nxt, 8)), (Y30, cells(nxt, 11)), (BT0, cells(nxt, 10))):
+        for k in range(16):
+            c.constraint(s0n * (nxt[col0 + k] - src[k]))
+    # ---- 4. SETUP-B: H = qq l + hr with hr < l; the accumulator starts at the identity
+    hl = cells(nxt, 0) + [nxt[RL(0, k)] for k in range(16)]
+    qq = [nxt[RH(0, k)] for k in range(16)] + [nxt[C(1, 0)]]
+    hr, hw = [nxt[RL(1, k)] for k in range(16)], [nxt[RH(1, k)] for k in range(16)]
+    lo = cells(nxt, 2) + [nxt[RL(2, k)] for k in range(16)]
+    hi = cells(nxt, 3) + [nxt[RL(3, k)] for k in range(16)]
+    cr = [lo[k] + hi[k] * 65536 - (1 << 31) for k in range(32)]
+    for k in range(33):
+        e = 0
+        for i in range(17):
+            j = k - i
+            if 0 <= j < 16 and LL[j]:
+                e = e + qq[i] * LL[j]
+        if k < 16:
+            e = e + hr[k]
+        if k < 32:
+            e = e - hl[k] - cr[k] * 65536
+        if k:
+            e = e + cr[k - 1]
+        c.constraint(s1n * e)
+    cy = [nxt[C(4, k)] for k in range(15)]
+    for e in canonical_chain(hr, hw, cy, LM1):
+        c.constraint(s1n * e)
+    for k in range(15):
+        c.constraint(s1n * cy[k] * (cy[k] - 1))
+    for k in range(16):
+        c.constraint(s1n * (nxt[HR0 + k] - hr[k]))
+    for g, want in ((11, [0] * 16), (12, ONE), (13, ONE)):
+        for k in range(16):
+            c.constraint(s1n * (nxt[C(g, k)] - want[k]))
+    # ---- 5. FINAL extras: canonical xR, yR, the sign bit
+    xr, yr = cells(nxt, 0), cells(nxt, 1)
+    for x, g in ((xr, 2), (yr, 3)):
+        cy = [nxt[RL(g, k)] for k in range(15)]
+        for e in canonical_chain(x, cells(nxt, g), cy, QM1):
+            c.constraint(finn * e)
+        for k in range(15):
+            c.constraint(finn * cy[k] * (cy[k] - 1))
+    c.constraint(finn * (xr[0] - nxt[RH(2, 0)] * 2 - nxt[BS]))
+    # ---- 6. slot registers, the addend selection, the scalar bits
+    for col in list(range(XA0, SEL0)) + [SG]:
+        c.constraint(keep * (nxt[col] - loc[col]))
+    bs, bh = loc[BS], loc[BH]
+    w11 = bs * bh
+    w10, w01 = bs - w11, bh - w11
+    w00 = 1 - bs - bh + w11
+    na = (vadd([loc[YA0 + k] for k in range(16)], [loc[XA0 + k] for k in range(16)]),
+          vsub([loc[YA0 + k] for k in range(16)], [loc[XA0 + k] for k in range(16)]), [loc[NT0 + k] for k in range(16)])
+    ba = (vsub([loc[Y30 + k] for k in range(16)], [loc[X30 + k] for k in range(16)]),
+          vadd([loc[Y30 + k] for k in range(16)], [loc[X30 + k] for k in range(16)]), [loc[BT0 + k] for k in range(16)])
+    for t in range(3):
+        for k in range(16):
+            c.constraint(loc[SEL0 + 16 * t + k] - (w00 * ID_C[t][k] + w10 * B_C[t][k] + w01 * na[t][k] + w11 * ba[t][k]))
+    c.constraint((1 - loc[SG]) * bh)
+    c.constraint((1 - loc[SG]) * per[P_STEP] * bs)
+    c.constraint(stn * (nxt[LAH] - (1 - per[P_LST]) * (loc[LAH] * 2) - nxt[BH]))
+    acc = None
+    for k in range(16):
+        t = per[P_LE0 + k] * (nxt[LAH] - nxt[HR0 + k])
+        acc = t if acc is None else acc + t
+    c.constraint(acc)
+    # ---- 7. the count of signed slots
+    c.transition(nxt[CNT] - loc[CNT] - s0n * nxt[SG])
+    c.first_row(loc[CNT] - loc[SG])
+    c.last_row(loc[CNT] - pub[0])
+    # ---- 8. lookups of the local row: 672 range checks, 6 bus lookups, the table, the running sum
+    beta, gamma = X2(chal[0], chal[1]), X2(chal[2], chal[3])
+    g2 = gamma * gamma
+    g3, g4 = g2 * gamma, g2 * g2
+    br = beta + g4 * TAG_R16
+    hsum = None
+    for e in range(N_RANGE):
+        h = X2(loc[COLS + 2 * e], loc[COLS + 2 * e + 1])
+        du, dv = br + loc[2 * e], br + loc[2 * e + 1]
+        c.constraint_x2(h * du * dv - du - dv)
+        hsum = h if hsum is None else hsum + h
+    for b, (m, tag, tup) in enumerate(bus_lookups(loc, per, pub)):
+        h = X2(loc[COLS + 2 * (HB0 + b)], loc[COLS + 2 * (HB0 + b) + 1])
+        d = beta + tup[0] + gamma * tup[1] + g2 * tup[2] + g3 * tup[3] + g4 * tag
+        c.constraint_x2(h * d - m)
+        hsum = hsum + h
+    ht = X2(loc[COLS + 2 * HT], loc[COLS + 2 * HT + 1])
+    c.constraint_x2(ht * (br + per[P_T]) - loc[MULT])
+    z, zn = X2(loc[COLS + 2 * ZZ], loc[COLS + 2 * ZZ + 1]), X2(nxt[COLS + 2 * ZZ], nxt[COLS + 2 * ZZ + 1])
+    c.constraint_x2(zn - z - hsum + ht + X2(aux_pub[0], aux_pub[1]))
+
+
+# ----------------------------------------------------------------------------- witness
+def _normalise(Fk):
+    """Vectorised over slots: Fk [16][m] int64 coefficients -> (c [16][m], r [16][m]) with F(2^16) - c = 2 q r_15, 0 <= c < 2q."""
+    m = Fk[0].shape[0]
+    L = [None] * 16
+    carry = np.zeros(m, dtype=np.int64)
+    for k in range(16):
+        v = Fk[k] + carry
+        L[k], carry = v & 0xFFFF, v >> 16
+    tot = np.zeros(m, dtype=np.int64)
+    while carry.any():  # 2^256 = 2q + 38: fold the overflow back in
+        tot += carry
+        add, carry = carry * 38, np.zeros(m, dtype=np.int64)
+        for k in range(16):
+            v = L[k] + (add if k == 0 else 0) + carry
+            L[k], carry = v & 0xFFFF, v >> 16
+    big = (L[0] >= 0xFFDA)
+    for k in range(1, 16):
+        big &= (L[k] == 0xFFFF)
+    if big.any():  # c >= 2q: take 2q off (add 38, drop 2^256)
+        L[0] = np.where(big, L[0] + 38 - 65536, L[0])
+        for k in range(1, 16):
+            L[k] = np.where(big, 0, L[k])
+        tot += big.astype(np.int64)
+    r = [None] * 16
+    prev = tot * 38
+    for k in range(16):
+        v = Fk[k] + prev - L[k]
+        assert not (v & 0xFFFF).any()
+        r[k] = v >> 16
+        prev = r[k]
+    assert (r[15] == tot).all()
+    return L, r
+
+
+def _fold_np(a, b):
+    out = []
+    for k in range(16):
+        acc = np.zeros(a[0].shape, dtype=np.int64)
+        for i in range(16):
+            j = k - i
+            acc += a[i] * b[j] if j >= 0 else a[i] * b[j + 16] * 38
+        out.append(acc)
+    return out
+
+
+class _Rows:
+    """Column-major int64 scratch for one row position of every slot."""
+
+    def __init__(self, m):
+        self.v = np.zeros((COLS, m), dtype=np.int64)
+
+    def gadget(self, g, a, b=None, F=None, has_c=True, store=None):
+        if F is None:
+            F = _fold_np(a, b)
+        if not has_c:
+            F = [f * 2 for f in F]
+        c, r = _normalise(F)
+        if has_c:
+            for k in range(16):
+                self.v[C(g, k)] = c[k]
+        else:
+            assert all(not ck.any() for ck in c), "zero-check gadget %d does not vanish" % g
+            if store is not None:
+                for k in range(16):
+                    self.v[C(g, k)] = store[k]
+        for k in range(16):
+            rr = r[k] + (1 << 31)
+            assert (rr >= 0).all() and (rr < (1 << 32)).all()
+            self.v[RL(g, k)], self.v[RH(g, k)] = rr & 0xFFFF, rr >> 16
+        return c
+
+    def cells(self, g):
+        return [self.v[C(g, k)] for k in range(16)]
+
+
+def _np_limbs(values, n=16):
+    return [np.array([(int(v) >> (16 * i)) & 0xFFFF for v in values], dtype=np.int64) for i in range(n)]
+
+
+def _const(l, m):
+    return [np.full(m, x, dtype=np.int64) for x in l]
+
+
+def _canon_cells(row, g, xs, top, col_of=None):
+    """w = top - x and the carries of x + w = top into gadget g's c / rl cells (Python ints per slot)."""
+    topv = sum(t << (16 * i) for i, t in enumerate(top))
+    for s, x in enumerate(xs):
+        w = topv - x
+        assert w >= 0, "value is not canonical"
+        xl, wl = limbs(x), limbs(w)
+        cy = 0
+        for k in range(16):
+            v = xl[k] + wl[k] + cy
+            cy = v >> 16
+            assert (v & 0xFFFF) == top[k]
+            row.v[C(g, k), s] = wl[k]
+            if k < 15:
+                (row.v[RL(g, k)] if col_of is None else row.v[col_of(k)])[s] = cy
+        assert cy == 0
+
+
+def gen_trace(sigs, log_n, bus_on=1):
+    """sigs: per slot dict(A=32 B, R=32 B, S=int, H=64-byte digest, signed=bool) (missing slots are unsigned).
+    -> trace [COLS][n], public inputs [number signed, bus_on]."""
+    n = 1 << log_n
+    m = n // 256
+    assert log_n >= 16 and len(sigs) <= m
+    tr = np.zeros((COLS, n), dtype=np.uint64)
+    xa_v, ya_v, sa_v, xr_v, yr_v, sr_v, hh_v, s_v, sg_v = [], [], [], [], [], [], [], [], []
+    for s in range(m):
+        sig = sigs[s] if s < len(sigs) and sigs[s]["signed"] else None
+        if sig is None:
+            xa_v.append(BX), ya_v.append(BY), sa_v.append(BX & 1), xr_v.append(0), yr_v.append(1), sr_v.append(0), hh_v.append(0), s_v.append(0), sg_v.append(0)
+            continue
+        A, R = pyref._decompress(sig["A"]), pyref._decompress(sig["R"])
+        assert A is not None and R is not None, "signed slot %d does not decode" % s
+        xa_v.append(A[0]), ya_v.append(A[1]), sa_v.append(A[0] & 1), xr_v.append(R[0]), yr_v.append(R[1]), sr_v.append(R[0] & 1)
+        hh_v.append(int.from_bytes(sig["H"], "little")), s_v.append(sig["S"]), sg_v.append(1)
+    # ---- row 0
+    r0 = _Rows(m)
+    xa, ya = _np_limbs(xa_v), _np_limbs(ya_v)
+    x3_v, y3_v = [], []
+    for x, y in zip(xa_v, ya_v):
+        p3 = pyref._add((BX, BY, 1, BX * BY % Q), ((-x) % Q, y, 1, (-x) * y % Q))
+        zi = pow(p3[2], Q - 2, Q)
+        x3_v.append(p3[0] * zi % Q), y3_v.append(p3[1] * zi % Q)
+    x3, y3 = _np_limbs(x3_v), _np_limbs(y3_v)
+    one = _const(ONE, m)
+    u = r0.gadget(0, xa, ya)
+    nt = r0.gadget(1, u, _const(K2DN, m))
+    xx = r0.gadget(2, xa, xa)
+    yy = r0.gadget(3, ya, ya)
+    dxx = r0.gadget(4, xx, _const(KD, m))
+    f = _fold_np(dxx, yy)
+    r0.gadget(5, None, F=[yy[k] - xx[k] - one[k] - f[k] for k in range(16)], has_c=False, store=xa)
+    t = r0.gadget(6, u, _const(KBD, m))
+    onep, onem = [one[k] + t[k] for k in range(16)], [one[k] - t[k] for k in range(16)]
+    f1, f2, f3 = _fold_np(x3, onep), _fold_np(ya, _const(XB, m)), _fold_np(xa, _const(YB, m))
+    r0.gadget(7, None, F=[f1[k] - f2[k] + f3[k] for k in range(16)], has_c=False, store=ya)
+    f1, f2, f3 = _fold_np(y3, onem), _fold_np(ya, _const(YB, m)), _fold_np(xa, _const(XB, m))
+    r0.gadget(8, None, F=[f1[k] - f2[k] + f3[k] for k in range(16)], has_c=False, store=x3)
+    v = r0.gadget(9, x3, y3)
+    bt = r0.gadget(10, v, _const(K2D, m))
+    for k in range(16):
+        r0.v[C(11, k)] = y3[k]
+    _canon_cells(r0, 12, xa_v, QM1)
+    _canon_cells(r0, 13, ya_v, QM1)
+    r0.v[RH(12, 0)] = xa[0] >> 1
+    r0.v[BS] = np.array(sa_v)
+    carried = np.zeros((SEL0 - XA0, m), dtype=np.int64)
+    for col0, src in ((XA0, xa), (YA0, ya), (NT0, nt), (X30, x3), (Y30, y3), (BT0, bt)):
+        for k in range(16):
+            carried[col0 - XA0 + k] = src[k]
+    # ---- row 1
+    r1 = _Rows(m)
+    hr_v = []
+    for s, hh in enumerate(hh_v):
+        qq, hr = divmod(hh, ELL)
+        hr_v.append(hr)
+        hl, ql, rl_ = limbs(hh, 32), limbs(qq, 17), limbs(hr)
+        for k in range(16):
+            r1.v[C(0, k), s], r1.v[RL(0, k), s], r1.v[RH(0, k), s] = hl[k], hl[16 + k], ql[k]
+            r1.v[RL(1, k), s] = rl_[k]
+        r1.v[C(1, 0), s] = ql[16]
+        cr = 0
+        for k in range(33):
+            e = sum(ql[i] * LL[k - i] for i in range(17) if 0 <= k - i < 16) + (rl_[k] if k < 16 else 0) - (hl[k] if k < 32 else 0) + cr
+            if k == 32:
+                assert e == 0
+                break
+            assert e % 65536 == 0
+            cr = e >> 16
+            v32 = cr + (1 << 31)
+            assert 0 <= v32 < (1 << 32)
+            (r1.v[C(2, k)] if k < 16 else r1.v[RL(2, k - 16)])[s] = v32 & 0xFFFF
+            (r1.v[C(3, k)] if k < 16 else r1.v[RL(3, k - 16)])[s] = v32 >> 16
+    hrl = _np_limbs(hr_v)
+    for k in range(16):
+        carried[HR0 - XA0 + k] = hrl[k]
+    # w = l - 1 - hr into rh(1), the carries into c(4)
+    for s, hr in enumerate(hr_v):
+        w = ELL - 1 - hr
+        xl, wl = limbs(hr), limbs(w)
+        cy = 0
+        for k in range(16):
+            v16 = xl[k] + wl[k] + cy
+            cy = v16 >> 16
+            r1.v[RH(1, k), s] = wl[k]
+            if k < 15:
+                r1.v[C(4, k), s] = cy
+    r1.v[C(12, 0)] = 1
+    r1.v[C(13, 0)] = 1
+    # ---- rows 2..254
+    sgn = np.array(sg_v, dtype=np.int64)
+    prev = r1
+    na = ([ya[k] + xa[k] for k in range(16)], [ya[k] - xa[k] for k in range(16)], nt)
+    ba = ([y3[k] - x3[k] for k in range(16)], [y3[k] + x3[k] for k in range(16)], bt)
+    idc, bc = [_const(v_, m) for v_ in ID_C], [_const(v_, m) for v_ in B_C]
+    lah = np.zeros(m, dtype=np.int64)
+    rows = {0: r0, 1: r1}
+    for r in range(2, 255):
+        bit = 252 - (r - 2)
+        bs = np.array([(int(x) >> bit) & 1 for x in s_v], dtype=np.int64)
+        bh = np.array([(int(x) >> bit) & 1 for x in hr_v], dtype=np.int64)
+        row = _Rows(m)
+        X, Y, Z = prev.cells(11), prev.cells(12), prev.cells(13)
+        w11 = bs * bh
+        w10, w01, w00 = bs - w11, bh - w11, 1 - bs - bh + w11
+        sel = [[w00 * idc[t][k] + w10 * bc[t][k] + w01 * na[t][k] + w11 * ba[t][k] for k in range(16)] for t in range(3)]
+        for t in range(3):
+            for k in range(16):
+                row.v[SEL0 + 16 * t + k] = sel[t][k]
+        c0, c1, c2 = row.gadget(0, X, X), row.gadget(1, Y, Y), row.gadget(2, Z, Z)
+        XY = [X[k] + Y[k] for k in range(16)]
+        c3 = row.gadget(3, XY, XY)
+        E, G = [c3[k] - c0[k] - c1[k] for k in range(16)], [c1[k] - c0[k] for k in range(16)]
+        F, H = [G[k] - 2 * c2[k] for k in range(16)], [-c0[k] - c1[k] for k in range(16)]
+        c4, c5, c6, c7 = row.gadget(4, E, F), row.gadget(5, G, H), row.gadget(6, E, H), row.gadget(7, F, G)
+        c8 = row.gadget(8, [c5[k] - c4[k] for k in range(16)], sel[0])
+        c9 = row.gadget(9, [c5[k] + c4[k] for k in range(16)], sel[1])
+        c10 = row.gadget(10, c6, sel[2])
+        E2, F2 = [c9[k] - c8[k] for k in range(16)], [2 * c7[k] - c10[k] for k in range(16)]
+        G2, H2 = [2 * c7[k] + c10[k] for k in range(16)], [c9[k] + c8[k] for k in range(16)]
+        row.gadget(11, E2, F2), row.gadget(12, G2, H2), row.gadget(13, F2, G2)
+        row.v[BS], row.v[BH] = bs, bh
+        lah = (0 if (bit == 252 or bit % 16 == 15) else 2 * lah) + bh
+        row.v[LAH] = lah
+        rows[r] = row
+        prev = row
+    # ---- row 255
+    rf = _Rows(m)
+    X, Y, Z = prev.cells(11), prev.cells(12), prev.cells(13)
+    xr, yr = _np_limbs(xr_v), _np_limbs(yr_v)
+    f = _fold_np(xr, Z)
+    rf.gadget(0, None, F=[f[k] - X[k] for k in range(16)], has_c=False, store=xr)
+    f = _fold_np(yr, Z)
+    rf.gadget(1, None, F=[f[k] - Y[k] for k in range(16)], has_c=False, store=yr)
+    _canon_cells(rf, 2, xr_v, QM1)
+    _canon_cells(rf, 3, yr_v, QM1)
+    rf.v[RH(2, 0)] = xr[0] >> 1
+    rf.v[BS] = np.array(sr_v)
+    rows[255] = rf
+    cnt = np.cumsum(sgn)
+    for r, row in rows.items():
+        row.v[XA0:SEL0] = carried
+        row.v[SG], row.v[CNT] = sgn, cnt
+        if r < 2 or r == 255:
+            bs, bh = row.v[BS], row.v[BH]
+            w11 = bs * bh
+            w10, w01, w00 = bs - w11, bh - w11, 1 - bs - bh + w11
+            for t in range(3):
+                for k in range(16):
+                    row.v[SEL0 + 16 * t + k] = w00 * idc[t][k] + w10 * bc[t][k] + w01 * na[t][k] + w11 * ba[t][k]
+        if r < 2:
+            row.v[LAH] = 0
+        elif r == 255:
+            row.v[LAH] = rows[254].v[LAH]
+        u = row.v.astype(np.uint64)
+        u[row.v < 0] -= np.uint64(2**32 - 1)  # -x mod p = 2^64 - x - (2^32 - 1)
+        tr[:, r:n:256] = u
+    # multiplicities of the range table: all of it in the first copy
+    counts = np.bincount(tr[:CELLS].astype(np.int64).ravel(), minlength=65536)
+    tr[MULT, :65536] = counts
+    return tr, [int(sgn.sum()), bus_on]
+
+
+def fingerprints(loc, per, chal, pub):
+    """(multiplicity, denominator) of every lookup of the local row, the table denominator."""
+    X2 = S.X2
+    beta, gamma = X2(chal[0], chal[1]), X2(chal[2], chal[3])
+    g2 = gamma * gamma
+    g3, g4 = g2 * gamma, g2 * g2
+    br = beta + g4 * TAG_R16
+    ds = [(1, br + loc[j]) for j in range(CELLS)]
+    for m, tag, tup in bus_lookups(loc, per, pub):
+        ds.append((m, beta + tup[0] + gamma * tup[1] + g2 * tup[2] + g3 * tup[3] + g4 * tag))
+    return ds, br + per[P_T]
+
+
+def gen_aux(trace, chal, pub):
+    tr = np.ascontiguousarray(trace, dtype=np.uint64)
+    n = tr.shape[1]
+    VecF = S.VecF
+    loc = [VecF(tr[j]) for j in range(COLS)]
+    per = [VecF(np.tile(np.array(v, dtype=np.uint64), n // len(v))) for v in periodic_values(n)]
+    ds, dt = fingerprints(loc, per, [VecF.const(x, loc[0]) for x in chal], [VecF.const(x, loc[0]) for x in pub])
+    aux = np.zeros((AUX, n), dtype=np.uint64)
+
+    def inv(x):
+        buf = np.empty(2 * n, dtype=np.uint64)
+        buf[0::2], buf[1::2] = x.a.v, x.b.v
+        out = O.ext_inv(buf)
+        return S.X2(VecF(out[0::2].copy()), VecF(out[1::2].copy()))
+
+    sa, sb = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+    for e in range(N_RANGE + N_BUS):
+        if e < N_RANGE:
+            (_, du), (_, dv) = ds[2 * e], ds[2 * e + 1]
+            h = (du + dv) * inv(du * dv)
+        else:
+            m, d = ds[CELLS + e - N_RANGE]
+            h = inv(d) * m
+        aux[2 * e], aux[2 * e + 1] = h.a.v, h.b.v
+        sa, sb = O.batch_op("add", sa, h.a.v), O.batch_op("add", sb, h.b.v)
+    ht = inv(dt) * loc[MULT]
+    aux[2 * HT], aux[2 * HT + 1] = ht.a.v, ht.b.v
+    da, db = O.batch_op("sub", sa, ht.a.v), O.batch_op("sub", sb, ht.b.v)
+    ninv = pow(n, P - 2, P)
+    apub = []
+    for comp, d in ((0, da), (1, db)):
+        dl = d.tolist()
+        sp = sum(dl) % P * ninv % P
+        z = np.zeros(n, dtype=np.uint64)
+        acc = 0
+        for i in range(n - 1):
+            acc = (acc + dl[i] - sp) % P
+            z[i + 1] = acc
+        aux[2 * ZZ + comp] = z
+        apub.append(sp)
+    return aux, apub
+
+
+def make_air(L):
+    class EdAir:
+        pass
+
+    EdAir.ID, EdAir.COLS, EdAir.PUB, EdAir.PERIODIC, EdAir.PERIOD_LOG = IDS[L], COLS, PUB, PERIODIC, L
+    EdAir.PERIOD_LOGS = period_logs(L)
+    EdAir.AUX, EdAir.CHAL, EdAir.AUXPUB = AUX, CHAL, AUXPUB
+    EdAir.periodic_values = staticmethod(lambda: periodic_values(1 << L))
+    EdAir.eval = staticmethod(eval)
+    EdAir.gen_aux = staticmethod(gen_aux)
+    return EdAir

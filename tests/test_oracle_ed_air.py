@@ -1,0 +1,136 @@
+"""oracle/ed_air.py and oracle/sha512_air.py (CPU tier): the EdDSA tables' constraints accept honest witnesses, reject forged
+ones, and their bus totals cancel.  Parity: there is no reference-held vector for these AIRs (curta's EdDSA gadget is not
+vendored and arithmetises differently) -- the pin is RFC 8032 / FIPS 180-4 behaviour through oracle/pyref.py and hashlib."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import ed_air as E
+from oracle import pyref
+from oracle import sha512_air as H
+from oracle import stark_ref as S
+from oracle.stark_ref import ExtS
+
+P = E.P
+MSG = b"\x01" + bytes(range(32)) + (100000).to_bytes(4, "little") + (7).to_bytes(8, "little") + (3).to_bytes(8, "little")
+CHAL = [3, 5, 7, 11]
+
+
+def signatures(n, unsigned=(2,)):
+    sigs, slots = [], []
+    for i in range(n):
+        sec = bytes([i + 1]) * 32
+        A = pyref.ed25519_public(sec)
+        sg = pyref.ed25519_sign(sec, MSG)
+        assert pyref.ed25519_verify(A, MSG, sg)
+        on = i not in unsigned
+        sigs.append(dict(A=A, R=sg[:32], S=int.from_bytes(sg[32:], "little"), H=hashlib.sha512(sg[:32] + A + MSG).digest(), signed=on))
+        slots.append((sg[:32], A) if on else None)
+    return sigs, slots
+
+
+@pytest.fixture(scope="module")
+def ed():
+    sigs, slots = signatures(5)
+    tr, pub = E.gen_trace(sigs, 16)
+    aux, apub = E.gen_aux(tr, CHAL, pub)
+    return dict(sigs=sigs, slots=slots, tr=tr, pub=pub, aux=aux, apub=apub, air=E.make_air(16))
+
+
+def test_ed_trace_satisfies_every_constraint(ed):
+    assert ed["pub"] == [4, 1]
+    # the first 8 slots (5 real, one of them unsigned, 3 idle) and the wrap-around pair
+    assert S.check_trace(ed["air"], ed["tr"], ed["pub"], chal=CHAL, aux=ed["aux"], aux_pub=ed["apub"], rows=(0, 2048)) is None
+    assert S.check_trace(ed["air"], ed["tr"], ed["pub"], chal=CHAL, aux=ed["aux"], aux_pub=ed["apub"], rows=(65536 - 300, 65536)) is None
+
+
+def test_ed_result_is_the_signature_equation(ed):
+    """Row 254's accumulator is [S]B - [h]A = R projectively (independent big-int arithmetic)."""
+    tr = ed["tr"]
+    for s, sig in enumerate(ed["sigs"]):
+        if not sig["signed"]:
+            continue
+        val = lambda g: sum(int(tr[E.C(g, k), 256 * s + 254]) << (16 * k) for k in range(16)) % E.Q  # noqa: E731
+        X, Y, Z = val(11), val(12), val(13)
+        zi = pow(Z, E.Q - 2, E.Q)
+        R = pyref._decompress(sig["R"])
+        assert (X * zi % E.Q, Y * zi % E.Q) == (R[0], R[1])
+
+
+@pytest.mark.parametrize("what", ["s_bit", "h_bit", "x_r", "h_limb", "claim_signed", "carry", "count"])
+def test_ed_forgeries_violate_a_constraint(ed, what):
+    t2, pub, rows = ed["tr"].copy(), list(ed["pub"]), (0, 520)
+    if what == "s_bit":
+        t2[E.BS, 100] ^= 1
+    elif what == "h_bit":
+        t2[E.BH, 100] ^= 1
+    elif what == "x_r":
+        t2[E.C(0, 0), 255] ^= 1
+    elif what == "h_limb":
+        t2[E.C(0, 3), 257] ^= 1
+    elif what == "claim_signed":
+        t2[E.SG, 512:768] = 1
+        rows = (500, 800)
+    elif what == "carry":
+        t2[E.RL(4, 5), 40] ^= 1
+    else:
+        pub[0] += 1
+        rows = (65536 - 4, 65536)
+    assert S.check_trace(ed["air"], t2, pub, chal=CHAL, aux=ed["aux"], aux_pub=ed["apub"], rows=rows) is not None
+
+
+def test_a_bad_signature_has_no_witness(ed):
+    sigs = [dict(s) for s in ed["sigs"][:1]]
+    sigs[0]["S"] ^= 1
+    with pytest.raises(AssertionError, match="zero-check"):
+        E.gen_trace(sigs, 16)
+
+
+def test_sha512_table_and_its_forgeries():
+    _, slots = signatures(5)
+    tr, pub, dig = H.gen_trace(slots, MSG, 10)
+    air = H.make_air(10)
+    aux, apub = H.gen_aux(tr, CHAL, pub)
+    assert S.check_trace(air, tr, pub, chal=CHAL, aux=aux, aux_pub=apub) is None
+    assert dig[0] == hashlib.sha512(slots[0][0] + slots[0][1] + MSG).digest() and dig[2] is None
+    for col, row in ((H.W0B + 5, 3), (H.W0B + 5, 161), (H.NA0 + 9, 40), (H.SGF, 170)):
+        t2 = tr.copy()
+        t2[col, row] ^= 1
+        assert S.check_trace(air, t2, pub, chal=CHAL, aux=aux, aux_pub=apub) is not None
+    p2 = list(pub)
+    p2[0] ^= 1  # another message
+    assert S.check_trace(air, tr, p2, chal=CHAL, aux=aux, aux_pub=apub) is not None
+
+
+def test_bus_between_the_two_tables_balances(ed):
+    """What EdAir sends (R || A) and receives (the digest) is exactly what Sha512Air receives and sends: the totals of the two
+    tables cancel once the key receives (the authority-set table's side of the bus) are left out."""
+    ts, pubs, _ = H.gen_trace(ed["slots"], MSG, 10)
+    beta, gamma = ExtS(CHAL[0], CHAL[1]), ExtS(CHAL[2], CHAL[3])
+    g2 = gamma * gamma
+    g3, g4 = g2 * gamma, g2 * g2
+
+    def total(lookups):
+        acc = ExtS(0)
+        for m, tag, tup in lookups:
+            if m % P:
+                acc = acc + (beta + tup[0] + gamma * tup[1] + g2 * tup[2] + g3 * tup[3] + g4 * tag).inv() * (m % P)
+        return acc
+
+    per_e, per_s = E.periodic_values(1 << 16), H.periodic_values(1 << 10)
+    rows_e, rows_s, keys = [], [], 0
+    for s in range(6):
+        for r in (0, 1, 255):
+            i = 256 * s + r
+            for lk in E.bus_lookups([int(ed["tr"][j, i]) for j in range(E.COLS)], [v[i % len(v)] for v in per_e], ed["pub"]):
+                if lk[1] == E.TAG_KEY:
+                    keys += 1 if lk[0] % P else 0
+                else:
+                    rows_e.append(lk)
+    for i in range(1 << 10):
+        if per_s[H.P_RCV][i] or per_s[H.P_SND][i]:
+            rows_s.append(H.bus_lookup([int(ts[j, i]) for j in range(H.COLS)], [v[i] for v in per_s], pubs))
+    te, tsum = total(rows_e), total(rows_s)
+    assert keys == 16 and (te.a, te.b) != (0, 0)
+    assert ((te + tsum).a, (te + tsum).b) == (0, 0)
