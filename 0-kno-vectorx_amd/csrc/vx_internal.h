@@ -156,4 +156,7 @@ int32_t vx_sha_tree_gen_aux_512(vx_ctx* ctx, const uint64_t* trace, int log_n, c
 int32_t vx_ed_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub);
 int32_t vx_ed_trace_dev(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* sigs, const uint8_t* msg, uint32_t msg_len, const uint8_t* signed_flags, size_t n_sigs,
                         int log_n, uint64_t bus_on, uint64_t* trace_d, uint64_t pub_out[2]);
+int32_t vx_sha512_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub);
+int32_t vx_sha512_trace_dev(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* sigs, const uint8_t* msg, const uint8_t* flags, size_t n_sigs, int log_n, uint64_t bus_on,
+                            uint64_t* trace_d, uint64_t pub_out[15]);
 void vx_merkle_levels_launch(vx_ctx* ctx, uint64_t* levels, size_t n_leaves, size_t cap);

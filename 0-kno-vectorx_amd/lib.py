@@ -27,7 +27,7 @@ SYMBOLS = [
     "vx_ed25519_verify_batch", "vx_verify_simple_justification", "vx_sha_chain_trace",
     "vx_verify_epoch_end_header", "vx_rotate_proof_bound", "vx_rotate_prove", "vx_rotate_verify",
     "vx_gather_proofs", "vx_quotient_eval", "vx_decode_header_batch", "vx_decode_precommit_batch", "vx_stark_aux_trace",
-    "vx_ed_trace",
+    "vx_ed_trace", "vx_sha512_trace",
 ]
 
 VX_AIR_FIBONACCI, VX_AIR_MIX, VX_AIR_BLAKE_CHAIN, VX_AIR_LOOKUP = 1, 2, 6, 5
@@ -36,6 +36,8 @@ VX_AIR_SHA_TREE = {256: 7, 512: 8, 16: 9}
 VX_AIR_SHA_CHAIN, VX_SHA_AIR_COLS = 4, 731
 VX_AIR_ED25519 = {17: 10, 16: 12}
 VX_ED_AIR_COLS, VX_ED_AIR_AUX_COLS = 838, 688
+VX_AIR_SHA512 = {16: 11, 10: 13}
+VX_SHA512_AIR_COLS, VX_SHA512_AIR_AUX_COLS = 1055, 4
 
 
 class JustificationStruct(C.Structure):
@@ -121,6 +123,7 @@ def load_library():
         "vx_ed25519_verify_batch": [vp, vp, vp, vp, C.c_uint32, vp, sz, vp],
         "vx_sha_chain_trace": [vp, vp, sz, C.c_int, vp, vp, vp],
         "vx_ed_trace": [vp, vp, vp, vp, C.c_uint32, vp, sz, C.c_int, C.c_uint32, vp, vp],
+        "vx_sha512_trace": [vp, vp, vp, vp, C.c_uint32, vp, sz, C.c_int, C.c_uint32, vp, vp],
         "vx_verify_simple_justification": [vp, C.c_uint32, vp, u64, vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32],
         "vx_verify_epoch_end_header": [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32],
         "vx_rotate_proof_bound": [C.POINTER(StarkConfig), sz, sz, sz, C.POINTER(sz)],
@@ -488,6 +491,18 @@ class Context:
         trace_buf = trace_buf or self.alloc(VX_ED_AIR_COLS << log_n)
         pub = np.zeros(2, dtype=np.uint64)
         self._ck(self.L.vx_ed_trace(self.h, _ptr(pk) if n else None, _ptr(sg) if n else None, _ptr(m), m.size, _ptr(en) if n else None, n, log_n, bus_on, trace_buf.h, _ptr(pub)))
+        return trace_buf, pub
+
+    def sha512_trace(self, pubkeys, sigs, msg, signed, log_n, bus_on=0, trace_buf=None):
+        """Sha512Air trace (H = SHA-512(R || A || msg) per signed slot) -> (Buffer [1055][2^log_n], public inputs)."""
+        n = len(pubkeys)
+        pk = np.ascontiguousarray(np.frombuffer(b"".join(pubkeys), dtype=np.uint8)) if n else None
+        sg = np.ascontiguousarray(np.frombuffer(b"".join(sigs), dtype=np.uint8)) if n else None
+        en = np.ascontiguousarray(signed, dtype=np.uint8) if n else None
+        m = np.frombuffer(bytes(msg), dtype=np.uint8).copy()
+        trace_buf = trace_buf or self.alloc(VX_SHA512_AIR_COLS << log_n)
+        pub = np.zeros(15, dtype=np.uint64)
+        self._ck(self.L.vx_sha512_trace(self.h, _ptr(pk) if n else None, _ptr(sg) if n else None, _ptr(m), m.size, _ptr(en) if n else None, n, log_n, bus_on, trace_buf.h, _ptr(pub)))
         return trace_buf, pub
 
     def ed25519_verify_batch(self, pubkeys, sigs, msg, enabled=None):

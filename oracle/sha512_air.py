@@ -27,6 +27,7 @@ from .ed_air import TAG_EDH, TAG_EDMSG
 
 P = 2**64 - 2**32 + 1
 ID = 11
+IDS = {16: 11, 10: 13}  # AIR id by log2(rows)
 M64, M32 = (1 << 64) - 1, 0xFFFFFFFF
 K = [
     0x428a2f98d728ae22, 0x7137449123ef65cd, 0xb5c0fbcfec4d3b2f, 0xe9b5dba58189dbbc, 0x3956c25bf348b538, 0x59f111f1b605d019, 0x923f82a4af194f9b, 0xab1c5ed5da6d8118,
@@ -458,7 +459,7 @@ def make_air(L):
     class Sha512Air:
         pass
 
-    Sha512Air.ID, Sha512Air.COLS, Sha512Air.PUB, Sha512Air.PERIODIC, Sha512Air.PERIOD_LOG = ID, COLS, PUB, PERIODIC, L
+    Sha512Air.ID, Sha512Air.COLS, Sha512Air.PUB, Sha512Air.PERIODIC, Sha512Air.PERIOD_LOG = IDS[L], COLS, PUB, PERIODIC, L
     Sha512Air.PERIOD_LOGS = [L] * PERIODIC
     Sha512Air.AUX, Sha512Air.CHAL, Sha512Air.AUXPUB = AUX, CHAL, AUXPUB
     Sha512Air.periodic_values = staticmethod(lambda: periodic_values(1 << L))

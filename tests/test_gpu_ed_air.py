@@ -77,3 +77,66 @@ def test_300_signatures_full_size(ctx, vx):
     flags[k] = 0
     _, pub2 = ctx.ed_trace(just.pubkeys, sigs, just.precommit, flags, 17)
     assert int(pub2[0]) == sum(just.signed) - 1
+
+
+def test_sha512_table_matches_oracle(ctx, vx):
+    from oracle import sha512_air as H
+
+    air = H.make_air(10)
+    S.register_air(air)
+    keys, sigs, flags, _ = signatures(5)
+    slots = [(sg[:32], k) if f else None for k, sg, f in zip(keys, sigs, flags)]
+    for bus_on in (1, 0):
+        buf, pub = ctx.sha512_trace(keys, sigs, MSG, flags, 10, bus_on=bus_on)
+        want, wpub, dig = H.gen_trace(slots, MSG, 10, bus_on=bus_on)
+        bad = np.argwhere(buf.download().reshape(H.COLS, 1 << 10) != want)
+        assert bad.size == 0, f"first differing cells (col,row): {bad[:5].tolist()}"
+        assert [int(x) for x in pub] == wpub
+        chal = [3, 5, 7, 11]
+        aux, apub = ctx.stark_aux_trace(H.IDS[10], buf, 10, chal, H.AUX, public_inputs=pub)
+        waux, wapub = H.gen_aux(want, chal, wpub)
+        assert (aux.download().reshape(H.AUX, 1 << 10) == waux).all() and [int(x) for x in apub[:2]] == wapub
+    cfg = dict(S.DEFAULT_CFG, num_queries=6)
+    proof = ctx.stark_prove(H.IDS[10], buf, 10, pub, ctx.stark_config(num_queries=6))
+    assert (proof == S.prove(air, want, wpub, cfg)).all()
+    S.verify(proof, cfg, expect_air=H.IDS[10], expect_public=wpub)
+    vx.lib.stark_verify(proof, ctx.stark_config(num_queries=6), expect_air=H.IDS[10], expect_public=wpub)
+
+
+def test_sha512_300_slots_and_bus_against_the_curve_table(ctx, vx):
+    """Full size: both tables proven under the SAME lookup challenges; what one sends the other receives (the key receives of
+    EdAir are the authority-set table's side and stay open here)."""
+    from oracle import sha512_air as H
+
+    just = vx.synth.Justification(100256, hashlib.blake2b(b"t", digest_size=32).digest())
+    t0 = time.time()
+    hb, hpub = ctx.sha512_trace(just.pubkeys, just.signatures, just.precommit, just.signed, 16, bus_on=1)
+    ctx.sync()
+    t1 = time.time()
+    proof = ctx.stark_prove(H.IDS[16], hb, 16, hpub)
+    t2 = time.time()
+    print(f"sha512 trace {1e3 * (t1 - t0):.1f} ms, prove {1e3 * (t2 - t1):.1f} ms, proof {proof.size * 8 / 1e6:.2f} MB")
+    # a proof that publishes a non-zero bus total is not acceptable stand-alone
+    with pytest.raises(vx.VxError):
+        vx.lib.stark_verify(proof, expect_air=H.IDS[16], expect_public=hpub)
+    chal = [11, 13, 17, 19]
+    _, apub_h = ctx.stark_aux_trace(H.IDS[16], hb, 16, chal, H.AUX, public_inputs=hpub)
+    eb, epub = ctx.ed_trace(just.pubkeys, just.signatures, just.precommit, just.signed, 17, bus_on=1)
+    aux_e, apub_e = ctx.stark_aux_trace(E.IDS[17], eb, 17, chal, E.AUX, public_inputs=epub)
+    # the key receives alone, recomputed on the host from the keys
+    P = E.P
+    ExtS = S.ExtS
+    beta, gamma = ExtS(chal[0], chal[1]), ExtS(chal[2], chal[3])
+    g2 = gamma * gamma
+    g4 = g2 * g2
+    keys_total = ExtS(0)
+    for s, (pk, f) in enumerate(zip(just.pubkeys, just.signed)):
+        if f:
+            l = [int.from_bytes(pk[2 * k: 2 * k + 2], "little") for k in range(16)]
+            for b in range(4):
+                d = beta + (4 * s + b) + gamma * (l[4 * b] + (l[4 * b + 1] << 16)) + g2 * (l[4 * b + 2] + (l[4 * b + 3] << 16)) + g4 * E.TAG_KEY
+                keys_total = keys_total + d.inv()
+    tot_e = ExtS(int(apub_e[0]), int(apub_e[1])) * (1 << 17)
+    tot_h = ExtS(int(apub_h[0]), int(apub_h[1])) * (1 << 16)
+    rest = tot_e + tot_h + keys_total  # EdAir's total holds the key receives with a minus sign
+    assert (rest.a, rest.b) == (0, 0)
