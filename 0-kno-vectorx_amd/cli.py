@@ -138,7 +138,9 @@ def cmd_build(vx, name, args):
     os.makedirs(args.build_dir, exist_ok=True)
     cfg = vx.lib.default_stark_config()
     desc = {"entrypoint": name, "circuit": kind, "max_headers": n, "backend": "libvxprove (gfx950)",
-            "stark_config": {f: getattr(cfg, f) for f, _ in cfg._fields_}, "airs": {"blake_chain": [vx.lib.VX_AIR_BLAKE_CHAIN, vx.lib.VX_BLAKE_AIR_COLS, vx.lib.VX_BLAKE_AIR_AUX_COLS], "sha_chain": [4, vx.lib.VX_SHA_AIR_COLS]}}
+            "stark_config": {f: getattr(cfg, f) for f, _ in cfg._fields_}, "airs": {"blake_chain": [vx.lib.VX_AIR_BLAKE_CHAIN, vx.lib.VX_BLAKE_AIR_COLS, vx.lib.VX_BLAKE_AIR_AUX_COLS], "sha_chain": [4, vx.lib.VX_SHA_AIR_COLS, vx.lib.VX_SHA_AIR_AUX_COLS],
+                                                                                 "ed25519": [vx.lib.VX_AIR_ED25519[17], vx.lib.VX_ED_AIR_COLS, vx.lib.VX_ED_AIR_AUX_COLS],
+                                                                                 "sha512": [vx.lib.VX_AIR_SHA512[16], vx.lib.VX_SHA512_AIR_COLS, vx.lib.VX_SHA512_AIR_AUX_COLS]}}
     path = os.path.join(args.build_dir, name + ".circuit.json")
     json.dump(desc, open(path, "w"), indent=1)
     print(f"[vx] wrote {path}")
@@ -212,7 +214,8 @@ def cmd_verify(vx, name, args):
         raise CliError("result carries no proof (a dummy_* entrypoint?)")
     if kind == "header_range":
         req = unpack_header_range_input(raw)
-        vx.lib.header_range_verify(words, n_max, req["trusted_block"], req["trusted_hash"], req["target_block"], out, authority_set_hash=req["authority_set_hash"])
+        vx.lib.header_range_verify(words, n_max, req["trusted_block"], req["trusted_hash"], req["target_block"], out, authority_set_hash=req["authority_set_hash"],
+                                   authority_set_id=req["authority_set_id"])
     elif kind == "rotate":
         req = unpack_rotate_input(raw)
         vx.lib.rotate_verify(words, req["authority_set_id"], req["authority_set_hash"], out)

@@ -6,8 +6,14 @@
 // one row per round, 64 rows per compression; three-input XORs as x + y + z = r + 2c, Ch as a
 // degree-2 expression, Maj through (maj, parity) bits; block types FIRST / DATA / PAD / IDLE.  731 columns: only the
 // words an XOR / AND reads are bit-decomposed (see the layout note); the compression rows are shared with ShaTreeAir.
+// Bus to EdAir (air_ed.cuh): a key's block carries a witness flag SGC ("this authority signed"); the key is sent as four
+// tuples (4 index + j, l0 + 2^16 l1, l2 + 2^16 l3, 0, TAG_KEY) of little-endian 16-bit limbs from the rows where its words
+// 2j / 2j+1 sit in window positions 0 / 1 (rows 0, 2, 4, 6 of FIRST, rows 8, 10, 12, 14 of DATA); index = key counter KC - 1,
+// and KC ends as the number of committed keys (public input 8; the denominator of the 2/3 threshold, justification.rs:164-186).
 // Constraint ORDER is protocol: oracle/sha_air.py restates it independently.
 #pragma once
+#include <vector>
+
 #include "air.cuh"
 
 namespace shc {
@@ -19,7 +25,8 @@ constexpr int A_ = 0, B_ = 32, C_ = 64, E_ = 96, F_ = 128, G_ = 160, DV = 192, H
 constexpr int W0B = 258, W1B = 290, W14B = 322, WV0 = 354, WV15 = 366;
 constexpr int S0R = 367, S0C = 399, S1R = 431, S1C = 463, E1R = 495, E1C = 527, A0R = 559, A0C = 591, MAJ = 623, PAR = 655;
 constexpr int CE0 = 687, CA0 = 690, CW0 = 693, FFV0 = 695, FFC0 = 703, HIN0 = 711, DG0 = 719;
-constexpr int T_FIRST = 727, T_DATA = 728, T_PAD = 729, T_IDLE = 730, COLS = 731;
+constexpr int T_FIRST = 727, T_DATA = 728, T_PAD = 729, T_IDLE = 730, COLS = 731;  // COLS: the compression layout every SHA-256 table shares
+constexpr int SGC = 731, KC = 732, CHAIN_COLS = 733, TAG_KEY = 5;                    // ShaChainAir only
 VX_HD constexpr int WV(int p) { return p == 15 ? WV15 : WV0 + p - 2; }  // value column of window position p (2..13, 15)
 VX_HD constexpr int st_bits(int wd) { return wd == 0 ? A_ : wd == 1 ? B_ : wd == 2 ? C_ : wd == 4 ? E_ : wd == 5 ? F_ : wd == 6 ? G_ : -1; }
 #define SHC_IV_INIT {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19}
@@ -140,11 +147,19 @@ __host__ __device__ inline void sha_compression_constraints(const Row& loc, cons
 }
 
 struct ShaAir {
-    static constexpr int ID = 4, COLS = shc::COLS, PUB = 8, PERIODIC = 4, PERIOD_LOG = 6, QUOT_ROWS_PER_LANE = 1, AUX = 0, CHAL = 0, AUXPUB = 0;
+    static constexpr int ID = 4, COLS = shc::CHAIN_COLS, PUB = 10, PERIODIC = 7, PERIOD_LOG = 6, QUOT_ROWS_PER_LANE = 1, AUX = 4, CHAL = 4, AUXPUB = 1;
     static constexpr int plog(int) { return 6; }
+    static void periodic_values(std::vector<uint64_t>& v) {
+        v.assign(7 * 64, 0);
+        v[0] = 1;                                      // sel_0
+        v[64 + 63] = 1;                                // sel_63
+        for (int r = 0; r <= 47; ++r) v[128 + r] = 1;  // schedule active
+        for (int r = 0; r < 64; ++r) v[192 + r] = shc::K_H[r];
+        for (int r = 0; r < 16; r += 2) v[(r < 8 ? 256 : 320) + r] = 1, v[384 + r] = (r & 7) >> 1;  // key-send rows of FIRST / DATA blocks, j
+    }
 
     template <class F, class Row, class C>
-    __host__ __device__ static void eval(const Row& loc, const Row& nxt, const F* per, const F* pub, const F*, const F*, C& c) {
+    __host__ __device__ static void eval(const Row& loc, const Row& nxt, const F* per, const F* pub, const F* chal, const F* apub, C& c) {
         using namespace shc;
         const F sel0 = per[0], sel63 = per[1];
         const F one = F::from(1);
@@ -190,6 +205,28 @@ struct ShaAir {
             c.constraint(in_block * (nxt[DG0 + wd] - dg));
             c.constraint(sel63 * (nxt[DG0 + wd] - nd));
             c.last_row(nd - pub[wd]);
+        }
+        // ---- 11. the "signed" flag of a key's block and the key counter
+        const F sgc = loc[SGC], kc = loc[KC];
+        c.constraint(sgc * (sgc - one));
+        c.constraint(in_block * (nxt[SGC] - sgc));
+        c.constraint(sgc * (loc[T_PAD] + loc[T_IDLE]));
+        c.constraint(in_block * (nxt[KC] - kc));
+        c.transition(sel63 * (nxt[KC] - kc - nxt[T_DATA]));
+        c.first_row(kc - one);
+        c.last_row(kc - pub[8]);
+        // ---- 12. the bus: signed keys go to EdAir
+        {
+            const X2<F> beta{chal[0], chal[1]}, gamma{chal[2], chal[3]}, g2 = gamma * gamma, g4 = g2 * g2;
+            const F k8 = F::from(256), k16 = F::from(65536);
+            auto limbs = [&](int col0) -> F {  // bytes b0 b1 b2 b3 of the big-endian word: (b0 + 256 b1) + 2^16 (b2 + 256 b3)
+                return val(loc, col0 + 24, 8) + val(loc, col0 + 16, 8) * k8 + (val(loc, col0 + 8, 8) + val(loc, col0, 8) * k8) * k16;
+            };
+            const F m = sgc * pub[9] * (per[4] * loc[T_FIRST] + per[5] * tdata);
+            const X2<F> d = beta + ((kc - one) * F::from(4) + per[6]) + gamma * limbs(W0B) + g2 * limbs(W1B) + g4 * F::from(TAG_KEY);
+            const X2<F> h{loc[CHAIN_COLS], loc[CHAIN_COLS + 1]}, z{loc[CHAIN_COLS + 2], loc[CHAIN_COLS + 3]}, zn{nxt[CHAIN_COLS + 2], nxt[CHAIN_COLS + 3]};
+            c.constraint_x2(h * d - m);
+            c.constraint_x2(zn - z - h + X2<F>{apub[0], apub[1]});
         }
     }
 };

@@ -641,33 +641,91 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
     return VX_OK;
 }
 
-static const uint64_t VX_HR_MAGIC = 0x3445474e41525248ULL;  // "HRRANGE4"
-static const size_t VX_HR_HDR = 19;  // magic, max_headers, trusted, target, out96 (12), len(blake proof), len(sha-chain proof), len(Merkle proof)
+static const uint64_t VX_HR_MAGIC = 0x3545474e41525248ULL;  // "HRRANGE5"
+// magic, max_headers, trusted, target, out96 (12), proof lengths: hash chain, authority-set commitment, Merkle, Ed25519, SHA-512; the precommit's round
+static const size_t VX_HR_HDR = 22;
 
 static int sha_log_n(size_t n_keys) {
     int log_n = 6;
     while (((size_t)1 << log_n) < 64 * (2 * n_keys - 1)) ++log_n;
     return log_n;
 }
-
 static int tree_air_id(uint32_t max_headers) { return max_headers == 256 ? 7 : max_headers == 512 ? 8 : max_headers == 16 ? 9 : 0; }
 static int tree_log_n(uint32_t max_headers) {
     int l = 8;
     while ((1u << (l - 8)) < max_headers) ++l;
     return l;
 }
+// the EdDSA tables by the size of the authority set: 256 rows per signature / 164 rows per hash
+static int ed_log_n(size_t n_auth) { return n_auth <= 256 ? 16 : 17; }
+static int ed_air_id(size_t n_auth) { return n_auth <= 256 ? VX_AIR_ED25519_16 : VX_AIR_ED25519; }
+static int s512_log_n(size_t n_auth) { return n_auth <= 6 ? 10 : 16; }
+static int s512_air_id(size_t n_auth) { return n_auth <= 6 ? VX_AIR_SHA512_10 : VX_AIR_SHA512; }
 
 int32_t vx_header_range_proof_bound(const vx_stark_config* cfg, size_t n_chunks, size_t n_authorities, size_t* n_words) {
     if (!cfg || !n_words || n_chunks == 0) return VX_ERR_ARG;
     int log_n = blk::TABLE_LOG;
     while (((size_t)1 << log_n) < 16 * n_chunks) ++log_n;
-    size_t w1 = 0, w2 = 0, w3 = 0;
+    size_t w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0;
     int32_t rc = vx_stark_proof_bound(VX_AIR_BLAKE_CHAIN, cfg, log_n, &w1);
     if (rc == VX_OK && n_authorities) rc = vx_stark_proof_bound(VX_AIR_SHA_CHAIN, cfg, sha_log_n(n_authorities), &w2);
     if (rc == VX_OK) rc = vx_stark_proof_bound(8, cfg, tree_log_n(512), &w3);  // the largest Merkle AIR (the request's max_headers is not known here)
-    *n_words = w1 + w2 + w3 + VX_HR_HDR;
+    if (rc == VX_OK && n_authorities) rc = vx_stark_proof_bound(ed_air_id(n_authorities), cfg, ed_log_n(n_authorities), &w4);
+    if (rc == VX_OK && n_authorities) rc = vx_stark_proof_bound(s512_air_id(n_authorities), cfg, s512_log_n(n_authorities), &w5);
+    *n_words = w1 + w2 + w3 + w4 + w5 + VX_HR_HDR;
     return rc;
 }
+
+namespace {
+// The tables of one statement share their lookup challenges: every prover stops after its trace cap (the challenge hook)
+// and waits for the caps of all the others; each then derives the same challenges from the transcript of all (public
+// inputs, cap) pairs in table order.  A rendezvous of host threads, one per table, each with its own context and stream.
+struct BusMeet {
+    static constexpr int MAX = 5;
+    std::mutex m;
+    std::condition_variable cv;
+    int n_parties = 0, arrived = 0;
+    bool failed = false;
+    std::vector<uint64_t> pub[MAX], cap[MAX];
+    static int32_t meet(BusMeet* r, int who, const uint64_t* pub, size_t n_pub, const uint64_t* cap, size_t cap_words, uint64_t* chal, size_t n_chal) {
+        std::unique_lock<std::mutex> lk(r->m);
+        r->pub[who].assign(pub, pub + n_pub);
+        r->cap[who].assign(cap, cap + cap_words);
+        ++r->arrived;
+        r->cv.notify_all();
+        r->cv.wait(lk, [&] { return r->arrived == r->n_parties || r->failed; });
+        if (r->arrived != r->n_parties) return VX_ERR_STATEMENT;  // another table's prover gave up
+        const uint64_t *pubs[MAX], *caps[MAX];
+        size_t ns[MAX];
+        for (int t = 0; t < r->n_parties; ++t) pubs[t] = r->pub[t].data(), ns[t] = r->pub[t].size(), caps[t] = r->cap[t].data();
+        uint64_t c[4];
+        vx_shared_challenges_n(pubs, ns, caps, (size_t)r->n_parties, cap_words, c, 4);
+        for (size_t q = 0; q < n_chal && q < 4; ++q) chal[q] = c[q];
+        return VX_OK;
+    }
+    void fail() {
+        std::lock_guard<std::mutex> lk(m);
+        failed = true;
+        cv.notify_all();
+    }
+};
+struct BusParty {
+    BusMeet* rv;
+    int who;
+};
+int32_t bus_hook(void* u, const uint64_t* pub, size_t n_pub, const uint64_t* cap, size_t cw, uint64_t* chal, size_t n_chal) {
+    BusParty* p = (BusParty*)u;
+    return BusMeet::meet(p->rv, p->who, pub, n_pub, cap, cw, chal, n_chal);
+}
+// one table of the statement, proven from its own host thread on its own context
+struct TableJob {
+    vx_ctx* c = nullptr;
+    std::thread th;
+    int32_t rc = VX_OK;
+    std::vector<uint64_t> proof;
+    size_t len = 0;
+};
+}  // namespace
 
 int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_fetched,
                               uint32_t max_headers, uint32_t trusted_block, const uint8_t trusted_hash[32], uint32_t target_block,
@@ -676,164 +734,161 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
     if (!ctx || !cfg || !proof_len || !out96) return VX_ERR_ARG;
     const int tree_id = tree_air_id(max_headers);
     VX_CHECK(tree_id, "header_range: max_headers %u has no Merkle AIR (16, 256 or 512)", max_headers);
+    VX_CHECK(!just || (just->num_authorities >= 1 && just->num_authorities <= 512), "header_range: %u authorities (the EdDSA table holds 512)", just ? just->num_authorities : 0);
     // 1. statement + public outputs (map/reduce chain rules, Merkle roots)
     VX_TRY(vx_verify_subchain(ctx, headers, stride, sizes, n_fetched, max_headers, trusted_block, trusted_hash, target_block, out96));
-    // 1b. the target header is justified by > 2/3 of the committed authority set (header_range.rs:49-54): checked on
-    //     the side context together with the commitment proof (below), while this context proves the hash chain
     const bool room = proof_out && proof_cap > VX_HR_HDR;
-    // 3. authority-set commitment STARK (compute_authority_set_commitment, justification.rs:127-162): independent of
-    //    the hash-chain proof and small, so it runs on the side context from a host thread while this one proves
-    std::vector<uint64_t> sha_proof;
-    size_t len1 = 0, len2 = 0;
-    int32_t rc_sha = VX_OK;
-    std::thread sha_thread;
-    vx_ctx* side = just ? vx_side_ctx(ctx) : nullptr;
-    auto prove_sha = [&](vx_ctx* c) -> int32_t {
-        (void)hipSetDevice(c->device);
-        int32_t rj = vx_verify_simple_justification(c, target_block, out96, just->authority_set_id, just->authority_set_hash, just->precommit,
-                                                    just->pubkeys, just->signatures, just->validator_signed, just->num_authorities,
-                                                    just->max_authorities);
-        if (rj != VX_OK) return rj;
-        const int sl = sha_log_n(just->num_authorities);
-        size_t bound = 0;
-        int32_t r = vx_stark_proof_bound(VX_AIR_SHA_CHAIN, cfg, sl, &bound);
-        if (r != VX_OK) return r;
-        sha_proof.resize(bound);
-        vx_buf* st = nullptr;
-        r = vx_alloc(c, ((size_t)VX_SHA_AIR_COLS) << sl, &st);
-        if (r != VX_OK) return r;
-        uint64_t spub[8];
-        uint8_t com[32];
-        r = vx_sha_chain_trace(c, just->pubkeys, just->num_authorities, sl, st, spub, com);
-        if (r == VX_OK && memcmp(com, just->authority_set_hash, 32) != 0) r = vx_fail(c, VX_ERR_STATEMENT, "header_range: authority-set commitment mismatch");
-        if (r == VX_OK) r = vx_stark_prove_impl(c, VX_AIR_SHA_CHAIN, cfg, st->d, st->n, /*consume_trace=*/1, sl, spub, 8, sha_proof.data(), sha_proof.size(), &len2);
-        (void)vx_free(c, st);
-        return r;
-    };
-    if (side) {
-        try {
-            sha_thread = std::thread([&] { rc_sha = prove_sha(side); });
-        } catch (...) {  // no thread to be had: prove one after the other below
-            side = nullptr;
-        }
-    }
-    // 2. Blake2b parent-hash-chain STARK over every compression of every header, and -- on the same logUp bus, under
-    //    shared lookup challenges -- the SHA-256 Merkle AIR that turns the state / data roots of those very header bytes
-    //    (decoder.rs:121-149) into the two output roots (subchain_verification.rs:213-220, 268-274)
     size_t chunks = 0;
     for (size_t i = 0; i < n_fetched; ++i) chunks += (sizes[i] + 127) / 128;
     int log_n = blk::TABLE_LOG;  // at least one copy of the lookup tables
     while (((size_t)1 << log_n) < 16 * chunks) ++log_n;
     const int tl = tree_log_n(max_headers);
-    // the leaves: decode_header on the GPU (all four compact modes natively; the AIR covers mode 2)
+    // the leaves of the two Merkle trees: decode_header on the GPU (all four compact modes natively; the AIR covers mode 2)
     std::vector<uint32_t> numbers(n_fetched);
     std::vector<uint8_t> modes(n_fetched), oks(n_fetched), parents(32 * n_fetched), sroots(32 * n_fetched), droots(32 * n_fetched);
-    int32_t rc = vx_decode_header_batch(ctx, headers, stride, sizes, n_fetched, numbers.data(), modes.data(), oks.data(), parents.data(), sroots.data(), droots.data());
-    // The two tables share their lookup challenges: each prover stops after its trace cap (the challenge hook) and waits
-    // for the other's cap; both then derive the same challenges from (hash-chain pub, cap, Merkle pub, cap).  The Merkle
-    // table is small, so it is proven on a further side context from its own host thread while this context proves the
-    // hash chain -- a rendezvous, not a nesting.
-    struct Rendezvous {
-        std::mutex m;
-        std::condition_variable cv;
-        bool have[2] = {false, false}, failed = false;
-        std::vector<uint64_t> pub[2], cap[2];
-        static int32_t meet(Rendezvous* r, int who, const uint64_t* pub, size_t n_pub, const uint64_t* cap, size_t cap_words, uint64_t* chal, size_t n_chal) {
-            std::unique_lock<std::mutex> lk(r->m);
-            r->pub[who].assign(pub, pub + n_pub);
-            r->cap[who].assign(cap, cap + cap_words);
-            r->have[who] = true;
-            r->cv.notify_all();
-            r->cv.wait(lk, [&] { return r->have[1 - who] || r->failed; });
-            if (!r->have[1 - who]) return VX_ERR_STATEMENT;  // the other table's prover gave up
-            uint64_t c[4];
-            vx_shared_challenges(r->pub[0].data(), r->pub[0].size(), r->cap[0].data(), r->pub[1].data(), r->pub[1].size(), r->cap[1].data(), cap_words, c, 4);
-            for (size_t q = 0; q < n_chal && q < 4; ++q) chal[q] = c[q];
-            return VX_OK;
+    VX_TRY(vx_decode_header_batch(ctx, headers, stride, sizes, n_fetched, numbers.data(), modes.data(), oks.data(), parents.data(), sroots.data(), droots.data()));
+    // 2. the tables, all on ONE logUp bus under shared lookup challenges (BusMeet):
+    //    0 BlakeChainAir  (this context)  every compression of every header; sends state-root words and data-root bytes
+    //    1 ShaTreeAir     the two SHA-256 Merkle trees over exactly those roots (subchain_verification.rs:213-220, 268-274)
+    //   with a justification (header_range.rs:49-54 -> justification.rs:195-257):
+    //    2 ShaChainAir    the authority-set commitment (justification.rs:127-162); sends the keys of the signed authorities
+    //    3 EdAir          [S]B = R + [h]A for every signed authority (:229-243); receives the keys, exchanges R || A / H with
+    //    4 Sha512Air      H = SHA-512(R || A || precommit)
+    BusMeet rv;
+    rv.n_parties = just ? 5 : 2;
+    BusParty party[BusMeet::MAX];
+    vx_chal_hook hooks[BusMeet::MAX];
+    for (int t = 0; t < BusMeet::MAX; ++t) party[t] = {&rv, t}, hooks[t] = {bus_hook, &party[t]};
+    TableJob job[BusMeet::MAX];
+    {   // contexts: a chain of side contexts, one per table
+        vx_ctx* c = ctx;
+        for (int t = 1; t < rv.n_parties; ++t) {
+            c = c ? vx_side_ctx(c) : nullptr;
+            job[t].c = c;
         }
-        void fail() {
-            std::lock_guard<std::mutex> lk(m);
-            failed = true;
-            cv.notify_all();
-        }
-    } rv;
-    const vx_chal_hook hook_a{[](void* u, const uint64_t* pub, size_t n_pub, const uint64_t* cap, size_t cw, uint64_t* chal, size_t n_chal) -> int32_t {
-                                  return Rendezvous::meet((Rendezvous*)u, 0, pub, n_pub, cap, cw, chal, n_chal);
-                              },
-                              &rv};
-    const vx_chal_hook hook_b{[](void* u, const uint64_t* pub, size_t n_pub, const uint64_t* cap, size_t cw, uint64_t* chal, size_t n_chal) -> int32_t {
-                                  return Rendezvous::meet((Rendezvous*)u, 1, pub, n_pub, cap, cw, chal, n_chal);
-                              },
-                              &rv};
-    std::vector<uint64_t> tree_proof;
-    size_t len3 = 0;
+        VX_CHECK(c, "header_range: no side context for every table (the provers meet at their challenge hooks, each on its own context)");
+    }
     uint64_t tpub[16];
-    int32_t rc_tree = VX_OK;
-    auto prove_tree = [&](vx_ctx* c) -> int32_t {
-        (void)hipSetDevice(c->device);
+    auto prove_tree = [&](vx_ctx* c, TableJob& j) -> int32_t {
         vx_buf* tt = nullptr;
-        int32_t r = vx_alloc(c, ((size_t)VX_SHA_AIR_COLS) << tl, &tt);
+        int32_t r = vx_alloc(c, ((size_t)VX_SHA_TREE_AIR_COLS) << tl, &tt);
         if (r == VX_OK) r = vx_sha_tree_trace_dev(c, sroots.data(), droots.data(), n_fetched, tl - 8, tt->d, tpub);
         if (r == VX_OK) {
             uint8_t roots[64];
-            for (int j = 0; j < 16; ++j)
-                for (int b = 0; b < 4; ++b) roots[4 * j + b] = (uint8_t)(tpub[j] >> (24 - 8 * b));
+            for (int q = 0; q < 16; ++q)
+                for (int b = 0; b < 4; ++b) roots[4 * q + b] = (uint8_t)(tpub[q] >> (24 - 8 * b));
             if (memcmp(roots, out96 + 32, 64) != 0) r = vx_fail(c, VX_ERR_STATEMENT, "header_range: Merkle AIR roots differ from the subchain roots");
         }
         size_t bound = 0;
         if (r == VX_OK) r = vx_stark_proof_bound(tree_id, cfg, tl, &bound);
         if (r == VX_OK) {
-            tree_proof.resize(bound);
-            r = vx_stark_prove_impl(c, tree_id, cfg, tt->d, tt->n, /*consume_trace=*/0, tl, tpub, 16, tree_proof.data(), tree_proof.size(), &len3, &hook_b);
+            j.proof.resize(bound);
+            r = vx_stark_prove_impl(c, tree_id, cfg, tt->d, tt->n, /*consume_trace=*/0, tl, tpub, 16, j.proof.data(), j.proof.size(), &j.len, &hooks[1]);
         }
         if (tt) (void)vx_free(c, tt);
-        if (r != VX_OK) rv.fail();
         return r;
     };
-    std::thread tree_thread;
-    vx_ctx* side2 = nullptr;
-    if (rc == VX_OK) {
-        vx_ctx* s1 = vx_side_ctx(ctx);
-        side2 = s1 ? vx_side_ctx(s1) : nullptr;
-        if (side2) {
-            try {
-                tree_thread = std::thread([&] { rc_tree = prove_tree(side2); });
-            } catch (...) {
-                side2 = nullptr;
-            }
+    auto prove_chain = [&](vx_ctx* c, TableJob& j) -> int32_t {
+        // the target header is justified by > 2/3 of the committed authority set: every rule natively first (error behaviour of
+        // the reference's hint, justification.rs:29-83), then the commitment table
+        VX_TRY(vx_verify_simple_justification(c, target_block, out96, just->authority_set_id, just->authority_set_hash, just->precommit, just->pubkeys, just->signatures,
+                                              just->validator_signed, just->num_authorities, just->max_authorities));
+        const int sl = sha_log_n(just->num_authorities);
+        size_t bound = 0;
+        VX_TRY(vx_stark_proof_bound(VX_AIR_SHA_CHAIN, cfg, sl, &bound));
+        j.proof.resize(bound);
+        vx_buf* st = nullptr;
+        VX_TRY(vx_alloc(c, ((size_t)VX_SHA_AIR_COLS) << sl, &st));
+        uint64_t spub[10];
+        uint8_t com[32];
+        int32_t r = vx_sha_chain_trace_dev(c, just->pubkeys, just->num_authorities, just->validator_signed, 1, sl, st->d, spub, com);
+        if (r == VX_OK && memcmp(com, just->authority_set_hash, 32) != 0) r = vx_fail(c, VX_ERR_STATEMENT, "header_range: authority-set commitment mismatch");
+        if (r == VX_OK) r = vx_stark_prove_impl(c, VX_AIR_SHA_CHAIN, cfg, st->d, st->n, /*consume_trace=*/0, sl, spub, 10, j.proof.data(), j.proof.size(), &j.len, &hooks[2]);
+        (void)vx_free(c, st);
+        return r;
+    };
+    auto prove_ed = [&](vx_ctx* c, TableJob& j) -> int32_t {
+        const int el = ed_log_n(just->num_authorities), id = ed_air_id(just->num_authorities);
+        size_t bound = 0;
+        VX_TRY(vx_stark_proof_bound(id, cfg, el, &bound));
+        j.proof.resize(bound);
+        vx_buf* et = nullptr;
+        VX_TRY(vx_alloc(c, ((size_t)VX_ED_AIR_COLS) << el, &et));
+        uint64_t epub[2];
+        int32_t r = vx_ed_trace_dev(c, just->pubkeys, just->signatures, just->precommit, 53, just->validator_signed, just->num_authorities, el, 1, et->d, epub);
+        if (r == VX_OK) r = vx_stark_prove_impl(c, id, cfg, et->d, et->n, /*consume_trace=*/0, el, epub, 2, j.proof.data(), j.proof.size(), &j.len, &hooks[3]);
+        (void)vx_free(c, et);
+        return r;
+    };
+    auto prove_s512 = [&](vx_ctx* c, TableJob& j) -> int32_t {
+        const int hl = s512_log_n(just->num_authorities), id = s512_air_id(just->num_authorities);
+        size_t bound = 0;
+        VX_TRY(vx_stark_proof_bound(id, cfg, hl, &bound));
+        j.proof.resize(bound);
+        vx_buf* ht = nullptr;
+        VX_TRY(vx_alloc(c, ((size_t)VX_SHA512_AIR_COLS) << hl, &ht));
+        uint64_t hpub[15];
+        int32_t r = vx_sha512_trace_dev(c, just->pubkeys, just->signatures, just->precommit, just->validator_signed, just->num_authorities, hl, 1, ht->d, hpub);
+        if (r == VX_OK) r = vx_stark_prove_impl(c, id, cfg, ht->d, ht->n, /*consume_trace=*/0, hl, hpub, 15, j.proof.data(), j.proof.size(), &j.len, &hooks[4]);
+        (void)vx_free(c, ht);
+        return r;
+    };
+    int32_t rc = VX_OK;
+    for (int t = 1; t < rv.n_parties && rc == VX_OK; ++t) {
+        TableJob* j = &job[t];
+        try {
+            j->th = std::thread([&, j, t] {
+                (void)hipSetDevice(j->c->device);
+                j->rc = t == 1 ? prove_tree(j->c, *j) : t == 2 ? prove_chain(j->c, *j) : t == 3 ? prove_ed(j->c, *j) : prove_s512(j->c, *j);
+                if (j->rc != VX_OK) rv.fail();  // do not leave the other provers waiting at their hooks
+            });
+        } catch (...) {
+            rc = vx_fail(ctx, VX_ERR_DEVICE, "header_range: no host thread for table %d", t);
         }
-        if (!side2) rc = vx_fail(ctx, VX_ERR_DEVICE, "header_range: no side context / host thread for the Merkle table (the two provers meet at their challenge hooks)");
     }
     vx_buf* trace = nullptr;
+    size_t len1 = 0;
     if (rc == VX_OK) rc = vx_alloc(ctx, ((size_t)blk::COLS) << log_n, &trace);
     uint64_t pub[20];
     if (rc == VX_OK) rc = vx_blake_chain_trace(ctx, headers, stride, sizes, n_fetched, trusted_hash, trusted_block + 1, max_headers, log_n, trace, pub, nullptr);
     if (rc == VX_OK) {
         uint8_t tgt[32];
-        for (int j = 0; j < 8; ++j) {
-            uint32_t l = (uint32_t)pub[8 + j];
-            memcpy(tgt + 4 * j, &l, 4);
+        for (int q = 0; q < 8; ++q) {
+            uint32_t l = (uint32_t)pub[8 + q];
+            memcpy(tgt + 4 * q, &l, 4);
         }
         if (memcmp(tgt, out96, 32) != 0) rc = vx_fail(ctx, VX_ERR_STATEMENT, "header_range: chain digest differs from the subchain target hash");
     }
     if (rc == VX_OK)
         rc = vx_stark_prove_impl(ctx, VX_AIR_BLAKE_CHAIN, cfg, trace->d, trace->n, /*consume_trace=*/1, log_n, pub, 20, room ? proof_out + VX_HR_HDR : nullptr,
-                                 room ? proof_cap - VX_HR_HDR : 0, &len1, &hook_a);
-    if (rc != VX_OK && rc != VX_ERR_BUFSZ) rv.fail();  // do not leave the Merkle prover waiting at its hook
+                                 room ? proof_cap - VX_HR_HDR : 0, &len1, &hooks[0]);
+    if (rc != VX_OK && rc != VX_ERR_BUFSZ) rv.fail();
     if (trace) (void)vx_free(ctx, trace);
-    if (tree_thread.joinable()) tree_thread.join();
-    if ((rc == VX_OK || rc == VX_ERR_BUFSZ) && rc_tree != VX_OK) rc = side2 ? vx_fail(ctx, rc_tree, "%s", vx_last_error(side2)) : rc_tree;
-    if (sha_thread.joinable()) sha_thread.join();
-    else if (just) rc_sha = prove_sha(ctx);  // no side context: one after the other
-    if (just) {
-        if (rc_sha != VX_OK && side) (void)vx_fail(ctx, rc_sha, "%s", vx_last_error(side));
-        if ((rc == VX_OK || rc == VX_ERR_BUFSZ) && rc_sha != VX_OK) rc = rc_sha;
+    for (int t = 1; t < BusMeet::MAX; ++t)
+        if (job[t].th.joinable()) job[t].th.join();
+    // the first table that failed for a reason of its own names the error (a prover released from the rendezvous by
+    // somebody else's failure reports VX_ERR_STATEMENT without a message); the justification's own rules come first
+    if (rc == VX_OK || rc == VX_ERR_BUFSZ) {
+        const int order[4] = {2, 3, 4, 1};
+        for (int q = 0; q < 4; ++q) {
+            const TableJob& j = job[order[q]];
+            if (order[q] < rv.n_parties && j.rc != VX_OK && vx_last_error(j.c)[0]) {
+                rc = vx_fail(ctx, j.rc, "%s", vx_last_error(j.c));
+                break;
+            }
+        }
+        if (rc == VX_OK || rc == VX_ERR_BUFSZ)
+            for (int t = 1; t < rv.n_parties; ++t)
+                if (job[t].rc != VX_OK) rc = vx_fail(ctx, job[t].rc, "header_range: table %d failed", t);
     }
-    *proof_len = VX_HR_HDR + len1 + len2 + len3;
+    *proof_len = VX_HR_HDR + len1;
+    for (int t = 1; t < rv.n_parties; ++t) *proof_len += job[t].len;
     if (rc == VX_OK) {
         if (proof_out && proof_cap >= *proof_len) {
-            if (len2) memcpy(proof_out + VX_HR_HDR + len1, sha_proof.data(), len2 * 8);
-            memcpy(proof_out + VX_HR_HDR + len1 + len2, tree_proof.data(), len3 * 8);
+            size_t off = VX_HR_HDR + len1;
+            const int order[4] = {2, 1, 3, 4};  // commitment, Merkle, Ed25519, SHA-512
+            for (int q = 0; q < 4; ++q)
+                if (order[q] < rv.n_parties) memcpy(proof_out + off, job[order[q]].proof.data(), job[order[q]].len * 8), off += job[order[q]].len;
         } else rc = vx_fail(ctx, VX_ERR_BUFSZ, "header_range: proof needs %zu words, buffer has %zu", *proof_len, proof_cap);
     }
     if (rc != VX_OK) return rc;
@@ -842,9 +897,14 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
     proof_out[2] = trusted_block;
     proof_out[3] = target_block;
     memcpy(proof_out + 4, out96, 96);
-    proof_out[18] = len3;
     proof_out[16] = len1;
-    proof_out[17] = len2;
+    proof_out[17] = job[2].len;
+    proof_out[18] = job[1].len;
+    proof_out[19] = job[3].len;
+    proof_out[20] = job[4].len;
+    uint64_t round = 0;
+    if (just) memcpy(&round, just->precommit + 37, 8);  // 0x01 || hash 32 || block 4 || round 8 || set id 8 (decoder.rs:159-200)
+    proof_out[21] = round;
     return VX_OK;
 }
 }

@@ -134,6 +134,7 @@ struct vx_chal_hook {
 int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg, uint64_t* trace_d, size_t trace_len, int consume_trace,
                             int log_n, const uint64_t* public_inputs, size_t n_public, uint64_t* proof_out, size_t proof_cap,
                             size_t* proof_len, const vx_chal_hook* hook = nullptr);
+void vx_shared_challenges_n(const uint64_t* const* pubs, const size_t* n_pubs, const uint64_t* const* caps, size_t k, size_t cap_words, uint64_t* out, size_t n_out);
 void vx_shared_challenges(const uint64_t* pub_a, size_t n_a, const uint64_t* cap_a, const uint64_t* pub_b, size_t n_b, const uint64_t* cap_b,
                           size_t cap_words, uint64_t* out, size_t n_out);
 // verifier with externally derived lookup challenges (nullptr = drawn from the proof's own transcript); apub_out (optional)
@@ -159,4 +160,7 @@ int32_t vx_ed_trace_dev(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* sigs
 int32_t vx_sha512_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub);
 int32_t vx_sha512_trace_dev(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* sigs, const uint8_t* msg, const uint8_t* flags, size_t n_sigs, int log_n, uint64_t bus_on,
                             uint64_t* trace_d, uint64_t pub_out[15]);
+int32_t vx_sha_chain_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub);
+int32_t vx_sha_chain_trace_dev(vx_ctx* ctx, const uint8_t* pubkeys, size_t n_keys, const uint8_t* signed_flags, uint64_t bus_on, int log_n, uint64_t* trace_d,
+                               uint64_t public_inputs_out[10], uint8_t commitment_out[32]);
 void vx_merkle_levels_launch(vx_ctx* ctx, uint64_t* levels, size_t n_leaves, size_t cap);

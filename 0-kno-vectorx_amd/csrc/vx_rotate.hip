@@ -146,9 +146,9 @@ int32_t vx_rotate_prove(vx_ctx* ctx, const vx_buf* header, uint32_t header_size,
         vx_buf* st = nullptr;
         int32_t r = vx_alloc(c, ((size_t)VX_SHA_AIR_COLS) << sl, &st);
         if (r != VX_OK) return r;
-        uint64_t spub[8];
-        r = vx_sha_chain_trace(c, keys, nk, sl, st, spub, com);
-        if (r == VX_OK) r = vx_stark_prove_impl(c, VX_AIR_SHA_CHAIN, cfg, st->d, st->n, 1, sl, spub, 8, dst, cap, len);
+        uint64_t spub[10];
+        r = vx_sha_chain_trace_dev(c, keys, nk, nullptr, 0, sl, st->d, spub, com);  // stand-alone: nothing on the bus
+        if (r == VX_OK) r = vx_stark_prove_impl(c, VX_AIR_SHA_CHAIN, cfg, st->d, st->n, 1, sl, spub, 10, dst, cap, len);
         (void)vx_free(c, st);
         return r;
     };
@@ -278,12 +278,22 @@ int32_t vx_rotate_verify(const vx_stark_config* cfg, const uint64_t* blob, size_
     pub[18] = pub[19] = 0;
     int32_t rc = vx_stark_verify(cfg, p0, l0, VX_AIR_BLAKE_CHAIN, pub, 20, err, errlen);
     if (rc != VX_OK) return rc;
-    uint64_t spub[8];
-    be_limbs(authority_set_hash, spub);
-    rc = vx_stark_verify(cfg, p0 + l0, l1, VX_AIR_SHA_CHAIN, spub, 8, err, errlen);
+    // public inputs of a commitment proof: the hash, the number of keys (bound by the hash; taken from the proof), bus off
+    auto verify_set = [&](const uint64_t* proof, size_t plen, const uint8_t* hash) -> int32_t {
+        uint64_t spub[10];
+        be_limbs(hash, spub);
+        const uint64_t *ppub, *pcap;
+        size_t n_ppub;
+        if (!vx_stark_proof_peek(proof, plen, cfg->cap_height, &ppub, &n_ppub, &pcap) || n_ppub != 10) {
+            if (err && errlen) snprintf(err, errlen, "authority-set commitment proof is malformed");
+            return VX_ERR_STATEMENT;
+        }
+        spub[8] = ppub[8], spub[9] = 0;
+        return vx_stark_verify(cfg, proof, plen, VX_AIR_SHA_CHAIN, spub, 10, err, errlen);
+    };
+    rc = verify_set(p0 + l0, l1, authority_set_hash);
     if (rc != VX_OK) return rc;
-    be_limbs(out32, spub);
-    return vx_stark_verify(cfg, p0 + l0 + l1, l2, VX_AIR_SHA_CHAIN, spub, 8, err, errlen);
+    return verify_set(p0 + l0 + l1, l2, out32);
 }
 
 }  // extern "C"

@@ -7,7 +7,7 @@
 #include "vx_internal.h"
 
 struct ShaBlock {
-    uint32_t h_in[8], block[16], dg[8], type, pad[3];
+    uint32_t h_in[8], block[16], dg[8], type, sgc, kc, pad;  // sgc / kc: ShaChainAir's signed flag and key counter
 };
 enum { SB_FIRST = 0, SB_DATA = 1, SB_PAD = 2, SB_IDLE = 3, SB_TREE = 4 /* ShaTreeAir: block kinds are periodic there, no type flags */ };
 
@@ -105,16 +105,42 @@ __global__ __launch_bounds__(256) void k_sha_trace(const ShaBlock* blocks, uint6
     tr[(size_t)T_DATA * n + row] = b.type == SB_DATA;
     tr[(size_t)T_PAD * n + row] = b.type == SB_PAD;
     tr[(size_t)T_IDLE * n + row] = b.type == SB_IDLE;
+    if (b.type != SB_TREE) tr[(size_t)SGC * n + row] = b.sgc, tr[(size_t)KC * n + row] = b.kc;  // (the tree table has 731 columns)
 }
 
-extern "C" {
-int32_t vx_sha_chain_trace(vx_ctx* ctx, const uint8_t* pubkeys, size_t n_keys, int log_n, vx_buf* trace_out,
-                           uint64_t public_inputs_out[8], uint8_t commitment_out[32]) {
-    if (!ctx || !pubkeys || !trace_out || !public_inputs_out) return VX_ERR_ARG;
+// auxiliary columns of ShaChainAir: the key sends of signed blocks, one lane per row
+__global__ __launch_bounds__(256) void k_sha_chain_aux(const uint64_t* tr, uint64_t* aux, size_t n, gl2 beta, gl2 gamma, uint64_t bus_on) {
+    using namespace shc;
+    const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const int r = (int)(row & 63);
+    gl2 h{0, 0};
+    if (bus_on && r < 16 && !(r & 1) && tr[(size_t)SGC * n + row] && tr[(size_t)(r < 8 ? T_FIRST : T_DATA) * n + row]) {
+        auto limbs = [&](int col0) -> uint64_t {
+            uint32_t w = 0;
+            for (int i = 0; i < 32; ++i) w |= (uint32_t)tr[(size_t)(col0 + i) * n + row] << i;
+            return (uint64_t)((w >> 24) | ((w >> 8) & 0xFF00)) | ((uint64_t)(((w >> 8) & 0xFF) | ((w & 0xFF) << 8)) << 16);
+        };
+        const gl2 g2 = gl2_mul(gamma, gamma), g4 = gl2_mul(g2, g2);
+        gl2 d = gl2_add(beta, gl2_add(gl2_scale(gamma, limbs(W0B)), gl2_add(gl2_scale(g2, limbs(W1B)), gl2_scale(g4, TAG_KEY))));
+        d.a = gl_add(d.a, 4 * (tr[(size_t)KC * n + row] - 1) + ((r & 7) >> 1));
+        h = gl2_inv(d);
+    }
+    aux[row] = h.a, aux[n + row] = h.b;
+    aux[2 * n + row] = h.a, aux[3 * n + row] = h.b;  // increments; the scan makes them the running sum
+}
+int32_t vx_sha_chain_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub) {
+    const size_t n = (size_t)1 << log_n;
+    hipLaunchKernelGGL(k_sha_chain_aux, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, trace, aux, n, gl2{chal[0], chal[1]}, gl2{chal[2], chal[3]}, pub[9]);
+    VX_HIP(hipGetLastError());
+    return vx_bus_close_dev(ctx, aux + 2 * n, log_n, aux_pub);
+}
+
+int32_t vx_sha_chain_trace_dev(vx_ctx* ctx, const uint8_t* pubkeys, size_t n_keys, const uint8_t* signed_flags, uint64_t bus_on, int log_n, uint64_t* trace_d,
+                               uint64_t public_inputs_out[10], uint8_t commitment_out[32]) {
     VX_CHECK(n_keys >= 1 && log_n >= 6 && log_n <= 24, "sha trace: bad shape");
     const size_t n = (size_t)1 << log_n, n_blocks = n >> 6;
     VX_CHECK(2 * n_keys - 1 <= n_blocks, "sha trace: %zu keys need %zu compressions, 2^%d rows hold %zu", n_keys, 2 * n_keys - 1, log_n, n_blocks);
-    VX_CHECK(trace_out->n >= n * (size_t)shc::COLS, "sha trace: trace buffer too small");
     std::vector<ShaBlock> blocks(n_blocks);
     memset(blocks.data(), 0, n_blocks * sizeof(ShaBlock));
     auto be32 = [](const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; };
@@ -126,17 +152,17 @@ int32_t vx_sha_chain_trace(vx_ctx* ctx, const uint8_t* pubkeys, size_t n_keys, i
         const uint8_t* pk = pubkeys + 32 * i;
         if (i == 0) {
             ShaBlock& b = blocks[bi++];
-            b.type = SB_FIRST;
+            b.type = SB_FIRST, b.sgc = signed_flags && signed_flags[0], b.kc = 1;
             for (int j = 0; j < 8; ++j) b.h_in[j] = shc::IV_H[j], b.block[j] = be32(pk + 4 * j), b.block[8 + j] = shc::tail32(j);
             h_compress(b.h_in, b.block, dig);
         } else {
             ShaBlock& d = blocks[bi++];
-            d.type = SB_DATA;
+            d.type = SB_DATA, d.sgc = signed_flags && signed_flags[i], d.kc = (uint32_t)(i + 1);
             for (int j = 0; j < 8; ++j) d.h_in[j] = shc::IV_H[j], d.block[j] = dig[j], d.block[8 + j] = be32(pk + 4 * j);
             uint32_t mid[8];
             h_compress(d.h_in, d.block, mid);
             ShaBlock& p = blocks[bi++];
-            p.type = SB_PAD;
+            p.type = SB_PAD, p.kc = (uint32_t)(i + 1);
             for (int j = 0; j < 8; ++j) p.h_in[j] = mid[j];
             for (int j = 0; j < 16; ++j) p.block[j] = shc::pad64(j);
             h_compress(p.h_in, p.block, dig);
@@ -145,7 +171,7 @@ int32_t vx_sha_chain_trace(vx_ctx* ctx, const uint8_t* pubkeys, size_t n_keys, i
         dig_hist.emplace_back(dig, dig + 8);
     }
     for (; bi < n_blocks; ++bi) {
-        blocks[bi].type = SB_IDLE;
+        blocks[bi].type = SB_IDLE, blocks[bi].kc = (uint32_t)n_keys;
         for (int j = 0; j < 8; ++j) blocks[bi].h_in[j] = shc::IV_H[j];
     }
     // digest register per block: the final digest in block 0 (cyclic wrap), then the running value
@@ -160,7 +186,7 @@ int32_t vx_sha_chain_trace(vx_ctx* ctx, const uint8_t* pubkeys, size_t n_keys, i
     uint64_t* sc;
     VX_TRY(vx_scratch(ctx, (n_blocks * sizeof(ShaBlock) + 7) / 8, &sc));
     VX_HIP(hipMemcpyAsync(sc, blocks.data(), n_blocks * sizeof(ShaBlock), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_sha_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const ShaBlock*)sc, trace_out->d, n);
+    hipLaunchKernelGGL(k_sha_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const ShaBlock*)sc, trace_d, n);
     VX_HIP(hipGetLastError());
     VX_HIP(hipStreamSynchronize(ctx->stream));
     for (int j = 0; j < 8; ++j) {
@@ -168,8 +194,14 @@ int32_t vx_sha_chain_trace(vx_ctx* ctx, const uint8_t* pubkeys, size_t n_keys, i
         if (commitment_out)
             for (int b = 0; b < 4; ++b) commitment_out[4 * j + b] = (uint8_t)(dig[j] >> (24 - 8 * b));
     }
+    public_inputs_out[8] = n_keys, public_inputs_out[9] = bus_on;
     return VX_OK;
 }
+extern "C" int32_t vx_sha_chain_trace(vx_ctx* ctx, const uint8_t* pubkeys, size_t n_keys, const uint8_t* signed_flags, uint32_t bus_on, int log_n, vx_buf* trace_out,
+                                      uint64_t public_inputs_out[10], uint8_t commitment_out[32]) {
+    if (!ctx || !pubkeys || !trace_out || !public_inputs_out) return VX_ERR_ARG;
+    VX_CHECK(log_n >= 6 && log_n <= 24 && trace_out->n >= ((size_t)shc::CHAIN_COLS << log_n), "sha trace: trace buffer too small");
+    return vx_sha_chain_trace_dev(ctx, pubkeys, n_keys, signed_flags, bus_on ? 1 : 0, log_n, trace_out->d, public_inputs_out, commitment_out);
 }
 
 // ---- ShaTreeAir: the two SHA-256 Merkle trees over state roots and data roots ------------------------------------------

@@ -358,13 +358,6 @@ static void blake_periodic(std::vector<uint64_t>& v) {
         v[256 + i] = a, v[256 + 65536 + i] = b, v[256 + 2 * 65536 + i] = (a ^ b) & 127, v[256 + 3 * 65536 + i] = (a ^ b) >> 7;
     }
 }
-static void sha_periodic(std::vector<uint64_t>& v) {
-    v.assign(4 * 64, 0);
-    v[0] = 1;                                     // sel_0
-    v[64 + 63] = 1;                               // sel_63
-    for (int r = 0; r <= 47; ++r) v[128 + r] = 1;  // schedule active
-    for (int r = 0; r < 64; ++r) v[192 + r] = shc::K_H[r];
-}
 static void lookup_periodic(std::vector<uint64_t>& v) {
     v.resize(3 * 256);
     for (int i = 0; i < 256; ++i) v[i] = i & 15, v[256 + i] = i >> 4, v[512 + i] = (i & 15) ^ (i >> 4);
@@ -374,7 +367,7 @@ static AirDesc desc(void (*pv)(std::vector<uint64_t>&), gen_aux_fn ga = nullptr)
     return {Air::ID, Air::COLS, Air::PUB, Air::PERIODIC, Air::PERIOD_LOG, pv, launch_q<Air>, count_q<Air>, Air::AUX, Air::CHAL, Air::AUXPUB, Air::plog, ga};
 }
 static const AirDesc AIRS[] = {
-    desc<ShaAir>(sha_periodic), desc<BlakeAir>(blake_periodic, vx_blake_air_gen_aux), desc<FibAir>(no_periodic), desc<MixAir>(mix_periodic),
+    desc<ShaAir>(ShaAir::periodic_values, vx_sha_chain_gen_aux), desc<BlakeAir>(blake_periodic, vx_blake_air_gen_aux), desc<FibAir>(no_periodic), desc<MixAir>(mix_periodic),
     desc<LookupAir>(lookup_periodic, vx_lookup_air_gen_aux),
     desc<ShaTreeAir256>(ShaTreeAir256::periodic_values, vx_sha_tree_gen_aux_256), desc<ShaTreeAir512>(ShaTreeAir512::periodic_values, vx_sha_tree_gen_aux_512),
     desc<ShaTreeAir16>(ShaTreeAir16::periodic_values, vx_sha_tree_gen_aux_16),
@@ -628,14 +621,19 @@ static int32_t quotient_eval_dev(vx_ctx* ctx, const AirDesc* air, int L, int r, 
 }
 
 // Lookup challenges shared by two tables: a transcript of both tables' public inputs and trace caps.
+void vx_shared_challenges_n(const uint64_t* const* pubs, const size_t* n_pubs, const uint64_t* const* caps, size_t k, size_t cap_words, uint64_t* out, size_t n_out) {
+    Challenger sc;
+    for (size_t t = 0; t < k; ++t) {
+        sc.observe(pubs[t], n_pubs[t]);
+        sc.observe(caps[t], cap_words);
+    }
+    for (size_t q = 0; q < n_out; ++q) out[q] = sc.challenge();
+}
 void vx_shared_challenges(const uint64_t* pub_a, size_t n_a, const uint64_t* cap_a, const uint64_t* pub_b, size_t n_b, const uint64_t* cap_b,
                           size_t cap_words, uint64_t* out, size_t n_out) {
-    Challenger sc;
-    sc.observe(pub_a, n_a);
-    sc.observe(cap_a, cap_words);
-    sc.observe(pub_b, n_b);
-    sc.observe(cap_b, cap_words);
-    for (size_t q = 0; q < n_out; ++q) out[q] = sc.challenge();
+    const uint64_t *pubs[2] = {pub_a, pub_b}, *caps[2] = {cap_a, cap_b};
+    const size_t ns[2] = {n_a, n_b};
+    vx_shared_challenges_n(pubs, ns, caps, 2, cap_words, out, n_out);
 }
 
 // consume_trace != 0: the trace buffer is overwritten (it ends up holding the bit-reversed coefficients);

@@ -164,19 +164,12 @@ void v_blake_periodic(std::vector<uint64_t>& v) {
         v[256 + i] = a, v[256 + 65536 + i] = b, v[256 + 2 * 65536 + i] = (a ^ b) & 127, v[256 + 3 * 65536 + i] = (a ^ b) >> 7;
     }
 }
-void v_sha_periodic(std::vector<uint64_t>& v) {
-    v.assign(4 * 64, 0);
-    v[0] = 1;
-    v[64 + 63] = 1;
-    for (int r = 0; r <= 47; ++r) v[128 + r] = 1;
-    for (int r = 0; r < 64; ++r) v[192 + r] = shc::K_H[r];
-}
 void v_lookup_periodic(std::vector<uint64_t>& v) {
     v.resize(3 * 256);
     for (int i = 0; i < 256; ++i) v[i] = i & 15, v[256 + i] = i >> 4, v[512 + i] = (i & 15) ^ (i >> 4);
 }
 const AirV V_AIRS[] = {
-    vdesc<ShaAir>(v_sha_periodic), vdesc<FibAir>(v_no_periodic), vdesc<MixAir>(v_mix_periodic), vdesc<BlakeAir>(v_blake_periodic),
+    vdesc<ShaAir>(ShaAir::periodic_values), vdesc<FibAir>(v_no_periodic), vdesc<MixAir>(v_mix_periodic), vdesc<BlakeAir>(v_blake_periodic),
     vdesc<LookupAir>(v_lookup_periodic), vdesc<ShaTreeAir256>(ShaTreeAir256::periodic_values), vdesc<ShaTreeAir512>(ShaTreeAir512::periodic_values),
     vdesc<ShaTreeAir16>(ShaTreeAir16::periodic_values), vdesc<EdAir17>(EdAir17::periodic_values), vdesc<EdAir16>(EdAir16::periodic_values), vdesc<Sha512Air16>(Sha512Air16::periodic_values), vdesc<Sha512Air10>(Sha512Air10::periodic_values),
 };
@@ -217,13 +210,12 @@ bool vx_stark_proof_peek(const uint64_t* pr, size_t len, int cap_height, const u
     *pub = pr + pos + 2, *n_pub = np, *cap = pr + pos + 2 + np;
     return true;
 }
-void v_shared_challenges(const uint64_t* pub_a, size_t n_a, const uint64_t* cap_a, const uint64_t* pub_b, size_t n_b, const uint64_t* cap_b, size_t cap_words,
-                         uint64_t* out, size_t n_out) {
+void v_shared_challenges_n(const uint64_t* const* pubs, const size_t* n_pubs, const uint64_t* const* caps, size_t k, size_t cap_words, uint64_t* out, size_t n_out) {
     VChallenger sc;
-    sc.observe(pub_a, n_a);
-    sc.observe(cap_a, cap_words);
-    sc.observe(pub_b, n_b);
-    sc.observe(cap_b, cap_words);
+    for (size_t t = 0; t < k; ++t) {
+        sc.observe(pubs[t], n_pubs[t]);
+        sc.observe(caps[t], cap_words);
+    }
     for (size_t q = 0; q < n_out; ++q) out[q] = sc.challenge();
 }
 
@@ -484,20 +476,38 @@ int32_t vx_stark_verify_ext(const vx_stark_config* cfg, const uint64_t* pr, size
 extern "C" {
 
 int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob, size_t len, uint32_t max_headers,
-                               uint32_t trusted_block, const uint8_t trusted_hash[32], const uint8_t* authority_set_hash,
+                               uint32_t trusted_block, const uint8_t trusted_hash[32], uint64_t authority_set_id, const uint8_t* authority_set_hash,
                                uint32_t target_block, const uint8_t out96[96], char* err, size_t errlen) {
     if (!cfg || !blob || !trusted_hash || !out96) return VX_ERR_ARG;
-    NEED(len > 19 && blob[0] == 0x3445474e41525248ULL, "bad header_range blob");
+    const size_t HDR = 22;
+    NEED(len > HDR && blob[0] == 0x3545474e41525248ULL, "bad header_range blob");
     NEED(blob[1] == max_headers && blob[2] == trusted_block && blob[3] == target_block, "blob is for a different request");
     NEED(memcmp(blob + 4, out96, 96) == 0, "public outputs differ from the blob");
     NEED(target_block > trusted_block, "empty block range");
-    const size_t len1 = blob[16], len2 = blob[17], len3 = blob[18];
-    NEED(len1 <= len && len2 <= len && len3 <= len && 19 + len1 + len2 + len3 == len, "blob lengths are inconsistent");
+    // proofs in blob order: hash chain, authority-set commitment, Merkle, Ed25519, SHA-512
+    size_t plen[5], off[5], tot = HDR;
+    for (int t = 0; t < 5; ++t) {
+        plen[t] = blob[16 + t];
+        NEED(plen[t] <= len, "blob lengths are inconsistent");
+        off[t] = tot, tot += plen[t];
+    }
+    NEED(tot == len, "blob lengths are inconsistent");
+    const bool justified = plen[1] > 0;
+    NEED(justified ? (plen[3] > 0 && plen[4] > 0) : (plen[3] == 0 && plen[4] == 0), "blob carries part of a justification");
+    NEED(!authority_set_hash || justified, "blob carries no authority-set commitment proof");
+    NEED(!justified || authority_set_hash, "blob carries a justification: the request's authority_set_hash is needed to check it");
     const int tree_id = max_headers == 256 ? 7 : max_headers == 512 ? 8 : max_headers == 16 ? 9 : 0;
     NEED(tree_id, "max_headers %u has no Merkle AIR", max_headers);
-    const uint64_t *pa = blob + 19, *pb = blob + 19 + len1 + len2;
-    // public inputs of the two tables, rebuilt from the request and the claimed outputs
-    uint64_t pub[20], tpub[16];
+    // bus order (the order of the shared-challenge transcript): hash chain, Merkle, commitment, Ed25519, SHA-512
+    const int n_tab = justified ? 5 : 2, blob_idx[5] = {0, 2, 1, 3, 4};
+    const uint64_t *proof[5], *ppub[5], *pcap[5];
+    size_t pl[5], npub[5];
+    for (int t = 0; t < n_tab; ++t) {
+        proof[t] = blob + off[blob_idx[t]], pl[t] = plen[blob_idx[t]];
+        NEED(vx_stark_proof_peek(proof[t], pl[t], cfg->cap_height, &ppub[t], &npub[t], &pcap[t]), "proofs are too short to hold a trace cap");
+    }
+    // public inputs of every table, rebuilt from the request and the claimed outputs
+    uint64_t pub[20], tpub[16], spub[10], epub[2], hpub[15];
     for (int j = 0; j < 8; ++j) {
         uint32_t a, b;
         memcpy(&a, trusted_hash + 4 * j, 4);
@@ -511,33 +521,53 @@ int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob,
     pub[19] = 1;            // bus on
     for (int j = 0; j < 16; ++j)  // state_root_merkle_root || data_root_merkle_root as big-endian words
         tpub[j] = ((uint64_t)out96[32 + 4 * j] << 24) | ((uint64_t)out96[33 + 4 * j] << 16) | ((uint64_t)out96[34 + 4 * j] << 8) | out96[35 + 4 * j];
-    // the lookup challenges both proofs must have used: a transcript of both trace caps
-    const uint64_t *ppa, *ppb, *cap_a, *cap_b;
-    size_t npa, npb;
-    NEED(vx_stark_proof_peek(pa, len1, cfg->cap_height, &ppa, &npa, &cap_a) && vx_stark_proof_peek(pb, len3, cfg->cap_height, &ppb, &npb, &cap_b),
-         "proofs are too short to hold a trace cap");
-    uint64_t chal[4];
-    v_shared_challenges(ppa, npa, cap_a, ppb, npb, cap_b, (size_t)4 << cfg->cap_height, chal, 4);
-    const uint64_t *apub_a = nullptr, *apub_b = nullptr;
-    int la = 0, lb = 0;
-    int32_t rc = vx_stark_verify_ext(cfg, pa, len1, VX_AIR_BLAKE_CHAIN, pub, 20, chal, &apub_a, &la, err, errlen);
-    if (rc != VX_OK) return rc;
-    rc = vx_stark_verify_ext(cfg, pb, len3, tree_id, tpub, 16, chal, &apub_b, &lb, err, errlen);
-    if (rc != VX_OK) return rc;
-    // the bus closes: what the hash-chain table sent (state-root words, data-root bytes of every header) is exactly what
-    // the Merkle table received.  Each table publishes its total divided by its row count.
-    for (int q = 0; q < 2; ++q) {
-        const uint64_t sa = glh::mul(apub_a[q], ((uint64_t)1 << la) % glh::P), sb = glh::mul(apub_b[q], ((uint64_t)1 << lb) % glh::P);
-        NEED(glh::add(sa, sb) == 0, "the bus between the hash-chain table and the Merkle table does not balance");
-    }
-    if (authority_set_hash) {  // the EVM input `authority_set_hash` (header_range.rs:35) must be the proven commitment
-        NEED(len2 > 0, "blob carries no authority-set commitment proof");
-        uint64_t spub[8];
+    int air[5] = {VX_AIR_BLAKE_CHAIN, tree_id, VX_AIR_SHA_CHAIN, 0, 0};
+    const uint64_t* want[5] = {pub, tpub, spub, epub, hpub};
+    const size_t n_want[5] = {20, 16, 10, 2, 15};
+    if (justified) {
+        NEED(npub[2] == 10 && npub[3] == 2 && npub[4] == 15, "justification proofs have the wrong number of public inputs");
+        // the EVM input `authority_set_hash` (header_range.rs:35) must be the proven commitment; the number of authorities it binds
+        // and the number of verified signatures are read from the proofs: signed * 3 > authorities * 2 (justification.rs:164-186)
         for (int j = 0; j < 8; ++j)
-            spub[j] = ((uint64_t)authority_set_hash[4 * j] << 24) | ((uint64_t)authority_set_hash[4 * j + 1] << 16) |
-                      ((uint64_t)authority_set_hash[4 * j + 2] << 8) | authority_set_hash[4 * j + 3];
-        rc = vx_stark_verify(cfg, blob + 19 + len1, len2, VX_AIR_SHA_CHAIN, spub, 8, err, errlen);
+            spub[j] = ((uint64_t)authority_set_hash[4 * j] << 24) | ((uint64_t)authority_set_hash[4 * j + 1] << 16) | ((uint64_t)authority_set_hash[4 * j + 2] << 8) |
+                      authority_set_hash[4 * j + 3];
+        const uint64_t n_auth = ppub[2][8], n_signed = ppub[3][0];
+        NEED(n_auth >= 1 && n_auth <= 512 && n_signed <= n_auth, "implausible authority counts");
+        NEED(n_signed * 3 > n_auth * 2, "fewer than 2/3 of the authority set signed (%llu of %llu)", (unsigned long long)n_signed, (unsigned long long)n_auth);
+        spub[8] = n_auth, spub[9] = 1;
+        epub[0] = n_signed, epub[1] = 1;
+        air[3] = n_auth <= 256 ? VX_AIR_ED25519_16 : VX_AIR_ED25519;
+        air[4] = n_auth <= 6 ? VX_AIR_SHA512_10 : VX_AIR_SHA512;
+        // the signed message: the precommit for (target header hash, target block, round, set id) -- decoder.rs:159-200
+        uint8_t msg[64];
+        memset(msg, 0, sizeof msg);
+        msg[0] = 1;
+        memcpy(msg + 1, out96, 32);
+        const uint64_t round = blob[21];
+        for (int b = 0; b < 4; ++b) msg[33 + b] = (uint8_t)(target_block >> (8 * b));
+        for (int b = 0; b < 8; ++b) msg[37 + b] = (uint8_t)(round >> (8 * b)), msg[45 + b] = (uint8_t)(authority_set_id >> (8 * b));
+        msg[53] = 0x80;
+        for (int j = 0; j < 7; ++j) {
+            uint64_t v = 0;
+            for (int b = 0; b < 8; ++b) v = (v << 8) | msg[8 * j + b];
+            hpub[2 * j] = v & 0xFFFFFFFFULL, hpub[2 * j + 1] = v >> 32;
+        }
+        hpub[14] = 1;
     }
-    return rc;
+    // the lookup challenges every proof must have used: a transcript of all public inputs and trace caps
+    uint64_t chal[4];
+    v_shared_challenges_n(ppub, npub, pcap, (size_t)n_tab, (size_t)4 << cfg->cap_height, chal, 4);
+    uint64_t bus[2] = {0, 0};
+    for (int t = 0; t < n_tab; ++t) {
+        const uint64_t* apub = nullptr;
+        int L = 0;
+        const int32_t rc = vx_stark_verify_ext(cfg, proof[t], pl[t], air[t], want[t], n_want[t], chal, &apub, &L, err, errlen);
+        if (rc != VX_OK) return rc;
+        for (int q = 0; q < 2; ++q) bus[q] = glh::add(bus[q], glh::mul(apub[q], ((uint64_t)1 << L) % glh::P));  // a table publishes its total / rows
+    }
+    // the bus closes: state roots and data roots of the hashed headers = the leaves of the Merkle trees; the keys of the signed
+    // authorities = the keys the signatures verify under; R || A and H between the curve table and the SHA-512 table
+    NEED(bus[0] == 0 && bus[1] == 0, "the lookup bus between the tables does not balance");
+    return VX_OK;
 }
 }

@@ -33,7 +33,7 @@ SYMBOLS = [
 VX_AIR_FIBONACCI, VX_AIR_MIX, VX_AIR_BLAKE_CHAIN, VX_AIR_LOOKUP = 1, 2, 6, 5
 VX_BLAKE_AIR_COLS, VX_BLAKE_AIR_AUX_COLS = 740, 278
 VX_AIR_SHA_TREE = {256: 7, 512: 8, 16: 9}
-VX_AIR_SHA_CHAIN, VX_SHA_AIR_COLS = 4, 731
+VX_AIR_SHA_CHAIN, VX_SHA_AIR_COLS, VX_SHA_AIR_AUX_COLS, VX_SHA_TREE_AIR_COLS = 4, 733, 4, 731
 VX_AIR_ED25519 = {17: 10, 16: 12}
 VX_ED_AIR_COLS, VX_ED_AIR_AUX_COLS = 838, 688
 VX_AIR_SHA512 = {16: 11, 10: 13}
@@ -115,13 +115,13 @@ def load_library():
         "vx_header_range_proof_bound": [C.POINTER(StarkConfig), sz, sz, C.POINTER(sz)],
         "vx_header_range_prove": [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.POINTER(JustificationStruct), C.POINTER(StarkConfig), vp, vp, sz, C.POINTER(sz)],
         "vx_stark_verify": [C.POINTER(StarkConfig), vp, sz, C.c_int, vp, sz, C.c_char_p, sz],
-        "vx_header_range_verify": [C.POINTER(StarkConfig), vp, sz, C.c_uint32, C.c_uint32, vp, vp, C.c_uint32, vp, C.c_char_p, sz],
+        "vx_header_range_verify": [C.POINTER(StarkConfig), vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, C.c_uint32, vp, C.c_char_p, sz],
         "vx_stark_prove": [vp, C.c_int, C.POINTER(StarkConfig), vp, C.c_int, vp, sz, vp, sz, C.POINTER(sz)],
         "vx_blake2b_256_batch": [vp, vp, sz, vp, sz, vp], "vx_sha256_pairs": [vp, vp, sz, vp],
         "vx_verify_subchain": [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp],
         "vx_blake_chain_trace": [vp, vp, sz, vp, sz, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp],
         "vx_ed25519_verify_batch": [vp, vp, vp, vp, C.c_uint32, vp, sz, vp],
-        "vx_sha_chain_trace": [vp, vp, sz, C.c_int, vp, vp, vp],
+        "vx_sha_chain_trace": [vp, vp, sz, vp, C.c_uint32, C.c_int, vp, vp, vp],
         "vx_ed_trace": [vp, vp, vp, vp, C.c_uint32, vp, sz, C.c_int, C.c_uint32, vp, vp],
         "vx_sha512_trace": [vp, vp, vp, vp, C.c_uint32, vp, sz, C.c_int, C.c_uint32, vp, vp],
         "vx_verify_simple_justification": [vp, C.c_uint32, vp, u64, vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32],
@@ -170,16 +170,22 @@ def stark_verify(proof, cfg=None, expect_air=0, expect_public=None):
         raise VxError(rc, err.value.decode())
 
 
-HR_HDR = 19  # words before the first proof in a header_range blob
+HR_HDR = 22  # words before the first proof in a header_range blob
+HR_MAGIC = 0x3545474E41525248  # "HRRANGE5"
 
 
 def split_blob(blob):
-    """(hash-chain proof, authority-commitment proof, Merkle proof) words of a header_range blob."""
-    l1, l2, l3 = int(blob[16]), int(blob[17]), int(blob[18])
-    return blob[HR_HDR: HR_HDR + l1], blob[HR_HDR + l1: HR_HDR + l1 + l2], blob[HR_HDR + l1 + l2: HR_HDR + l1 + l2 + l3]
+    """(hash-chain, authority-commitment, Merkle, Ed25519, SHA-512) proofs of a header_range blob (the last two and the second
+    are empty when it was proven without a justification)."""
+    out, off = [], HR_HDR
+    for t in range(5):
+        ln = int(blob[16 + t])
+        out.append(blob[off: off + ln])
+        off += ln
+    return tuple(out)
 
 
-def header_range_verify(blob, max_headers, trusted_block, trusted_hash, target_block, out96, cfg=None, authority_set_hash=None):
+def header_range_verify(blob, max_headers, trusted_block, trusted_hash, target_block, out96, cfg=None, authority_set_hash=None, authority_set_id=0):
     L = load_library()
     cfg = cfg or default_stark_config()
     b = np.ascontiguousarray(blob, dtype=np.uint64)
@@ -187,7 +193,7 @@ def header_range_verify(blob, max_headers, trusted_block, trusted_hash, target_b
     o = np.frombuffer(bytes(out96), dtype=np.uint8).copy()
     ah = None if authority_set_hash is None else np.frombuffer(bytes(authority_set_hash), dtype=np.uint8).copy()
     err = C.create_string_buffer(256)
-    rc = L.vx_header_range_verify(C.byref(cfg), _ptr(b), b.size, max_headers, trusted_block, _ptr(th), None if ah is None else _ptr(ah), target_block,
+    rc = L.vx_header_range_verify(C.byref(cfg), _ptr(b), b.size, max_headers, trusted_block, _ptr(th), authority_set_id, None if ah is None else _ptr(ah), target_block,
                                   _ptr(o), err, 256)
     if rc != 0:
         raise VxError(rc, err.value.decode())
@@ -473,12 +479,15 @@ class Context:
         self._ck(self.L.vx_blake_chain_trace(self.h, headers_buf.h, stride, _ptr(sizes), sizes.size, _ptr(th), first_block_number, tree_size, log_n, trace_buf.h, _ptr(pub), _ptr(dig)))
         return trace_buf, pub, dig
 
-    def sha_chain_trace(self, pubkeys, log_n, trace_buf=None):
+    def sha_chain_trace(self, pubkeys, log_n, trace_buf=None, signed=None, bus_on=0):
+        """ShaChainAir trace -> (Buffer [733][2^log_n], the 10 public inputs, the commitment).  signed: the flags of the
+        authorities whose keys go to the EdDSA table over the bus (bus_on)."""
         pk = np.ascontiguousarray(np.frombuffer(b"".join(pubkeys), dtype=np.uint8))
         trace_buf = trace_buf or self.alloc(VX_SHA_AIR_COLS << log_n)
-        pub = np.zeros(8, dtype=np.uint64)
+        pub = np.zeros(10, dtype=np.uint64)
         com = np.zeros(32, dtype=np.uint8)
-        self._ck(self.L.vx_sha_chain_trace(self.h, _ptr(pk), pk.size // 32, log_n, trace_buf.h, _ptr(pub), _ptr(com)))
+        sg = None if signed is None else np.ascontiguousarray(signed, dtype=np.uint8)
+        self._ck(self.L.vx_sha_chain_trace(self.h, _ptr(pk), pk.size // 32, None if sg is None else _ptr(sg), bus_on, log_n, trace_buf.h, _ptr(pub), _ptr(com)))
         return trace_buf, pub, com.tobytes()
 
     def ed_trace(self, pubkeys, sigs, msg, signed, log_n, bus_on=0, trace_buf=None):

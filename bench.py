@@ -65,11 +65,12 @@ class Workload:
 
     def check(self, res):
         assert res[0] == self.chain.expected_outputs(N_HEADERS), "public outputs differ from the native mirror"
-        assert int(res[1][0]) == 0x3445474E41525248 and res[1][4:16].tobytes() == res[0]
+        assert int(res[1][0]) == self.vx.lib.HR_MAGIC and res[1][4:16].tobytes() == res[0]
         # (outside the timed region) the product's host verifier accepts the blob: both tables, the bus balance, the commitment
         ch = self.chain
         self.vx.lib.header_range_verify(res[1], N_HEADERS, ch.trusted_block, ch.trusted_hash, ch.target_block, res[0], self.cfg,
-                                        authority_set_hash=self.just.sh.tobytes() if self.just is not None else None)
+                                        authority_set_hash=self.just.sh.tobytes() if self.just is not None else None,
+                                        authority_set_id=self.just.struct.authority_set_id if self.just is not None else 0)
 
 
 class RotateWorkload:

@@ -219,12 +219,14 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
 
 /* ---- K8: ShaChainAir trace generation (compute_authority_set_commitment, justification.rs:127-162):
  * the chained SHA-256 commitment h_0 = SHA256(pk_0), h_i = SHA256(h_{i-1} || pk_i) over n_keys 32-byte
- * keys (host buffer).  Writes the 731-column trace (64 rows per compression, 2*n_keys - 1
- * compressions, padded with idle blocks), the 8 public inputs (the commitment as big-endian words)
- * and optionally the 32 commitment bytes.  Prove with vx_stark_prove(ctx, VX_AIR_SHA_CHAIN, ...). */
-enum { VX_AIR_SHA_CHAIN = 4, VX_SHA_AIR_COLS = 731 };
-int32_t vx_sha_chain_trace(vx_ctx* ctx, const uint8_t* pubkeys, size_t n_keys, int log_n, vx_buf* trace_out,
-                           uint64_t public_inputs_out[8], uint8_t commitment_out[32]);
+ * keys (host buffer).  Writes the 733-column trace (64 rows per compression, 2*n_keys - 1
+ * compressions, padded with idle blocks), the 10 public inputs (the commitment as big-endian words, the
+ * number of keys, bus_on) and optionally the 32 commitment bytes.  signed_flags (may be NULL = none) marks
+ * the keys whose signatures the EdDSA table verifies; with bus_on they are sent to it over the lookup bus
+ * (bus_on = 0: a stand-alone proof).  Prove with vx_stark_prove(ctx, VX_AIR_SHA_CHAIN, ...). */
+enum { VX_AIR_SHA_CHAIN = 4, VX_SHA_AIR_COLS = 733, VX_SHA_AIR_AUX_COLS = 4, VX_SHA_TREE_AIR_COLS = 731 /* the Merkle AIRs 7 / 8 / 9 */ };
+int32_t vx_sha_chain_trace(vx_ctx* ctx, const uint8_t* pubkeys, size_t n_keys, const uint8_t* signed_flags, uint32_t bus_on, int log_n, vx_buf* trace_out,
+                           uint64_t public_inputs_out[10], uint8_t commitment_out[32]);
 
 /* ---- K8: EdAir trace generation (the curve half of the 300 conditional EdDSA verifications, justification.rs:229-243):
  * n_signatures slots (pubkey 32 B, signature R || S 64 B, flag), all over the same message (the 53-byte precommit); a slot
@@ -307,11 +309,15 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
                               uint32_t max_headers, uint32_t trusted_block, const uint8_t trusted_hash[32],
                               uint32_t target_block, const vx_justification* just, const vx_stark_config* cfg,
                               uint8_t out96[96], uint64_t* proof_out, size_t proof_cap, size_t* proof_len);
-/* HeaderRangeCircuit verify: checks the blob of vx_header_range_prove against the request
- * (blocks, trusted hash) and the claimed 96 output bytes, then verifies the STARK. */
+/* HeaderRangeCircuit verify: checks the blob of vx_header_range_prove against the request (the five fields of the
+ * circuit's 80-byte EVM input, header_range.rs:30-37) and the claimed 96 output bytes: every table's STARK under the
+ * shared lookup challenges, the bus balance, and -- when the blob carries a justification -- that the committed
+ * authority set is authority_set_hash, that more than 2/3 of it signed, and that what it signed is the precommit for
+ * (target header hash, target_block, authority_set_id).  authority_set_hash = NULL for a blob proven without one. */
 int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob, size_t blob_len, uint32_t max_headers,
-                               uint32_t trusted_block, const uint8_t trusted_hash[32], const uint8_t* authority_set_hash /* 32 B or NULL */,
-                               uint32_t target_block, const uint8_t out96[96], char* err, size_t errlen);
+                               uint32_t trusted_block, const uint8_t trusted_hash[32], uint64_t authority_set_id,
+                               const uint8_t* authority_set_hash /* 32 B or NULL */, uint32_t target_block, const uint8_t out96[96], char* err,
+                               size_t errlen);
 
 /* ---- RotateCircuit: circuits/rotate.rs:80-109, circuits/builder/rotate.rs:74-323 ----
  * EVM input = u64 authority_set_id || bytes32 authority_set_hash (40 B, dummy_rotate.rs:11-14);

@@ -14,6 +14,12 @@ Block types (one-hot flags, constant inside a block):
 Row r holds the working state BEFORE round r, the 16-word schedule window w_r..w_{r+15}, the round
 outputs NA/NE (new a, new e), and at r = 63 the feed-forward FF = H_in + state_64 (values: a digest word is range
 checked where it is consumed -- as message bits of a later block, or as a public input).
+
+Bus to EdAir (oracle/ed_air.py): a key's block carries a witness flag SGC ("this authority signed"); the key is sent as four
+tuples (4 (index) + j, l0 + 2^16 l1, l2 + 2^16 l3, 0, TAG_KEY) of little-endian 16-bit limbs, from the rows where its words
+2j / 2j+1 sit in window positions 0 / 1 as bits (rows 0, 2, 4, 6 of FIRST, rows 8, 10, 12, 14 of DATA).  The index is the key
+counter KC - 1; KC ends as the number of committed keys (public input 8, the denominator of the 2/3 threshold,
+justification.rs:164-186).  Public input 9 = bus_on (0: a stand-alone proof, nothing is sent).
 """
 import numpy as np
 
@@ -52,11 +58,15 @@ FFC0 = 703         # 8 feed-forward carry bits
 HIN0 = 711         # 8 initial-state words (values)
 DG0 = 719          # digest register, 8 words (values)
 T_FIRST, T_DATA, T_PAD, T_IDLE = 727, 728, 729, 730
-COLS = 731
+COLS = 731         # the compression layout every SHA-256 table shares
+SGC, KC, CHAIN_COLS = 731, 732, 733   # ShaChainAir only: the "signed" flag of a key's block, the key counter
 BIT_RANGES = [(0, DV), (NA0, WV0), (S0R, FFV0), (FFC0, HIN0)]  # every boolean column
-PUB = 8
-PERIODIC = 4       # sel_0, sel_63, sched_on (r <= 47), K_r
+PUB = 10           # digest words, number of keys, bus_on
+PERIODIC = 4       # sel_0, sel_63, sched_on (r <= 47), K_r  (+ 3 for ShaChainAir: key-send rows of FIRST / DATA blocks, j)
+CHAIN_PERIODIC = 7
 PERIOD_LOG = 6
+AUX, CHAL, AUXPUB = 4, 4, 1
+TAG_KEY = 5
 ST_BITS = {0: A_, 1: B_, 2: C_, 4: E_, 5: F_, 6: G_}
 
 
@@ -67,6 +77,13 @@ def WV(p):
 
 def periodic_values():
     return [[1 if r == 0 else 0 for r in range(64)], [1 if r == 63 else 0 for r in range(64)], [1 if r <= 47 else 0 for r in range(64)], list(K)]
+
+
+def chain_periodic_values():
+    ksf = [1 if r in (0, 2, 4, 6) else 0 for r in range(64)]
+    ksd = [1 if r in (8, 10, 12, 14) else 0 for r in range(64)]
+    kj = [(r % 8) // 2 if r < 16 and r % 2 == 0 else 0 for r in range(64)]
+    return periodic_values() + [ksf, ksd, kj]
 
 
 def rotr(x, n):
@@ -168,10 +185,11 @@ def fill_block(tr, base, h_in, block):
     return out
 
 
-def gen_trace(pubkeys, log_n):
+def gen_trace(pubkeys, log_n, signed=None, bus_on=0):
     n = 1 << log_n
     blocks, final = gen_blocks(pubkeys, n // 64)
-    tr = np.zeros((COLS, n), dtype=np.uint64)
+    tr = np.zeros((CHAIN_COLS, n), dtype=np.uint64)
+    kc = 0
     final_words = [int.from_bytes(final[4 * j: 4 * j + 4], "big") for j in range(8)]
     dg = list(final_words)  # block 0 carries the final digest (the register wraps around cyclically)
     for bi, blk in enumerate(blocks):
@@ -180,10 +198,14 @@ def gen_trace(pubkeys, log_n):
         for wd in range(8):
             tr[DG0 + wd, rows] = dg[wd]
         tr[{"FIRST": T_FIRST, "DATA": T_DATA, "PAD": T_PAD, "IDLE": T_IDLE}[blk["type"]], rows] = 1
+        if blk["type"] in ("FIRST", "DATA"):
+            kc += 1
+            tr[SGC, rows] = 1 if signed is not None and signed[kc - 1] else 0
+        tr[KC, rows] = kc
         if blk["type"] in ("FIRST", "PAD"):
             dg = list(out)
-    assert dg == final_words
-    return tr, final_words, final
+    assert dg == final_words and kc == len(pubkeys)
+    return tr, final_words + [kc, bus_on], final
 
 
 # ----------------------------------------------------------------------------- constraints
@@ -276,12 +298,60 @@ def compression_constraints(loc, nxt, per, c, data_flag):
         c.constraint(in_block * (nxt[HIN0 + wd] - loc[HIN0 + wd]))
 
 
+def key_lookup(loc, per, pub):
+    """(multiplicity, tag, tuple) of the local row's key send: the words at window positions 0 / 1 as four 16-bit limbs."""
+    def limbs(col0):  # bytes b0 b1 b2 b3 of the big-endian word: (b0 + 256 b1, b2 + 256 b3)
+        return val(loc, col0 + 24, 8) + val(loc, col0 + 16, 8) * 256, val(loc, col0 + 8, 8) + val(loc, col0, 8) * 256
+
+    a0, b0 = limbs(W0B)
+    a1, b1 = limbs(W1B)
+    m = loc[SGC] * pub[9] * (per[4] * loc[T_FIRST] + per[5] * loc[T_DATA])
+    return m, TAG_KEY, ((loc[KC] - 1) * 4 + per[6], a0 + b0 * 65536, a1 + b1 * 65536, 0)
+
+
 class ShaChainAir:
-    ID, COLS, PUB, PERIODIC, PERIOD_LOG = ID, COLS, PUB, PERIODIC, PERIOD_LOG
-    periodic_values = staticmethod(periodic_values)
+    ID, COLS, PUB, PERIODIC, PERIOD_LOG = ID, CHAIN_COLS, PUB, CHAIN_PERIODIC, PERIOD_LOG
+    AUX, CHAL, AUXPUB = AUX, CHAL, AUXPUB
+    periodic_values = staticmethod(chain_periodic_values)
 
     @staticmethod
-    def eval(loc, nxt, per, pub, c):
+    def gen_aux(trace, chal, pub):
+        from . import oracle as O
+        from . import stark_ref as S
+
+        tr = np.ascontiguousarray(trace, dtype=np.uint64)
+        n = tr.shape[1]
+        VecF, X2 = S.VecF, S.X2
+        loc = [VecF(tr[j]) for j in range(CHAIN_COLS)]
+        per = [VecF(np.tile(np.array(v, dtype=np.uint64), n // len(v))) for v in chain_periodic_values()]
+        cv = [VecF.const(x, loc[0]) for x in chal]
+        beta, gamma = X2(cv[0], cv[1]), X2(cv[2], cv[3])
+        g2 = gamma * gamma
+        g4 = g2 * g2
+        m, tag, tup = key_lookup(loc, per, [VecF.const(x, loc[0]) for x in pub])
+        d = beta + tup[0] + gamma * tup[1] + g2 * tup[2] + g4 * tag
+        buf = np.empty(2 * n, dtype=np.uint64)
+        buf[0::2], buf[1::2] = d.a.v, d.b.v
+        out = O.ext_inv(buf)
+        h = X2(VecF(out[0::2].copy()), VecF(out[1::2].copy())) * m
+        aux = np.zeros((AUX, n), dtype=np.uint64)
+        aux[0], aux[1] = h.a.v, h.b.v
+        ninv = pow(n, P - 2, P)
+        apub = []
+        for comp, dd in ((0, h.a.v), (1, h.b.v)):
+            dl = dd.tolist()
+            sp = sum(dl) % P * ninv % P
+            z = np.zeros(n, dtype=np.uint64)
+            acc = 0
+            for i in range(n - 1):
+                acc = (acc + dl[i] - sp) % P
+                z[i + 1] = acc
+            aux[2 + comp] = z
+            apub.append(sp)
+        return aux, apub
+
+    @staticmethod
+    def eval(loc, nxt, per, pub, c, chal, aux_pub):
         sel0, sel63 = per[0], per[1]
         in_block = 1 - sel63
         # ---- 0. the four type flags
@@ -308,3 +378,24 @@ class ShaChainAir:
             c.constraint(in_block * (nxt[DG0 + wd] - loc[DG0 + wd]))
             c.constraint(sel63 * (nxt[DG0 + wd] - (upd * loc[FFV0 + wd] + (1 - upd) * loc[DG0 + wd])))
             c.last_row(upd * loc[FFV0 + wd] + (1 - upd) * loc[DG0 + wd] - pub[wd])
+        # ---- 11. the "signed" flag of a key's block and the key counter
+        c.constraint(loc[SGC] * (loc[SGC] - 1))
+        c.constraint(in_block * (nxt[SGC] - loc[SGC]))
+        c.constraint(loc[SGC] * (loc[T_PAD] + loc[T_IDLE]))
+        c.constraint(in_block * (nxt[KC] - loc[KC]))
+        c.transition(sel63 * (nxt[KC] - loc[KC] - nxt[T_DATA]))
+        c.first_row(loc[KC] - 1)
+        c.last_row(loc[KC] - pub[8])
+        # ---- 12. the bus: signed keys go to EdAir
+        from . import stark_ref as S
+
+        X2 = S.X2
+        beta, gamma = X2(chal[0], chal[1]), X2(chal[2], chal[3])
+        g2 = gamma * gamma
+        g4 = g2 * g2
+        m, tag, tup = key_lookup(loc, per, pub)
+        d = beta + tup[0] + gamma * tup[1] + g2 * tup[2] + g4 * tag
+        h = X2(loc[CHAIN_COLS], loc[CHAIN_COLS + 1])
+        c.constraint_x2(h * d - m)
+        z, zn = X2(loc[CHAIN_COLS + 2], loc[CHAIN_COLS + 3]), X2(nxt[CHAIN_COLS + 2], nxt[CHAIN_COLS + 3])
+        c.constraint_x2(zn - z - h + X2(aux_pub[0], aux_pub[1]))

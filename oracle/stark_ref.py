@@ -457,14 +457,18 @@ def quotient_values(air, lde_nat, pub, alphas, L, r, chal=None, aux_pub=None):
     return qvals
 
 
-def shared_challenges(pub_a, cap_a, pub_b, cap_b, n):
-    """Lookup challenges shared by two tables (a bus between AIRs): a transcript of both public inputs and trace caps."""
+def shared_challenges_n(tables, n):
+    """Lookup challenges shared by the tables on one bus: a transcript of every table's (public inputs, trace cap), in order."""
     sc = O.Challenger()
-    for pub, cap in ((pub_a, cap_a), (pub_b, cap_b)):
+    for pub, cap in tables:
         if len(pub):
             sc.observe(np.array([int(x) for x in pub], dtype=np.uint64))
         sc.observe(np.asarray(cap, dtype=np.uint64).reshape(-1))
     return [sc.challenge() for _ in range(n)]
+
+
+def shared_challenges(pub_a, cap_a, pub_b, cap_b, n):
+    return shared_challenges_n(((pub_a, cap_a), (pub_b, cap_b)), n)
 
 
 def proof_peek(proof, cap_h):

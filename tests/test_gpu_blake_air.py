@@ -85,7 +85,7 @@ def test_hash_chain_proof_bytes_with_the_bus_on(ctx, vx, oracle):
     ch = vx.synth.Chain(3, profile="Ptiny", stride=512)
     cfg, ocfg = ctx.stark_config(num_queries=9), dict(S.DEFAULT_CFG, num_queries=9)
     _, blob = ctx.header_range_prove(ctx.from_host(ch.headers), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
-    p_blake, _, p_tree = vx.lib.split_blob(blob)
+    p_blake, _, p_tree, _, _ = vx.lib.split_blob(blob)
     pub_b, cap_b = S.proof_peek(p_tree, ocfg["cap_height"])
     trace, wpub, _ = B.gen_trace(chain_msgs(ch), L0, ch.trusted_hash, tree_size=16)
     want = S.prove(B.BlakeChainAir, trace, wpub, ocfg, chal_hook=lambda pub_a, cap_a: S.shared_challenges(pub_a, cap_a, pub_b, cap_b, 4))
@@ -135,16 +135,25 @@ def test_forged_act_flag_cannot_be_proven(ctx, vx, oracle):
 
 
 def oracle_verify_blob(vx, blob, cfg, max_headers):
-    """The reference verifier on a header_range blob: both tables under the shared challenges, and the bus balance."""
-    p_blake, p_sha, p_tree = vx.lib.split_blob(blob)
-    pub_a, cap_a = S.proof_peek(p_blake, cfg["cap_height"])
-    pub_b, cap_b = S.proof_peek(p_tree, cfg["cap_height"])
-    chal = S.shared_challenges(pub_a, cap_a, pub_b, cap_b, 4)
-    ia = S.verify(p_blake, cfg, expect_air=B.ID, ext_chal=chal)
-    ib = S.verify(p_tree, cfg, expect_air=T.IDS[max_headers], ext_chal=chal)
+    """The reference verifier on a header_range blob: every table under the shared challenges (a transcript of all trace caps in
+    bus order: hash chain, Merkle, commitment, Ed25519, SHA-512), and the bus balance."""
+    p_blake, p_sha, p_tree, p_ed, p_h = vx.lib.split_blob(blob)
+    tables = [(p_blake, B.ID), (p_tree, T.IDS[max_headers])]
+    if p_sha.size:
+        from oracle import ed_air as E
+        from oracle import sha512_air as H5
+        from oracle import sha_air as A
+
+        n_auth = S.proof_peek(p_sha, cfg["cap_height"])[0][8]
+        ed_l, h_l = (16 if n_auth <= 256 else 17), (10 if n_auth <= 6 else 16)
+        for air in (A.ShaChainAir, E.make_air(ed_l), H5.make_air(h_l)):
+            S.register_air(air)
+        tables += [(p_sha, A.ID), (p_ed, E.IDS[ed_l]), (p_h, H5.IDS[h_l])]
+    chal = S.shared_challenges_n([S.proof_peek(p, cfg["cap_height"]) for p, _ in tables], 4)
+    infos = [S.verify(p, cfg, expect_air=air, ext_chal=chal) for p, air in tables]
     for q in range(2):
-        assert (ia["aux_public"][q] * (1 << ia["degree_bits"]) + ib["aux_public"][q] * (1 << ib["degree_bits"])) % B.P == 0, "bus does not balance"
-    return ia, ib
+        assert sum(i["aux_public"][q] * (1 << i["degree_bits"]) for i in infos) % B.P == 0, "bus does not balance"
+    return infos
 
 
 def test_header_range_prove_end_to_end(ctx, vx, oracle):
@@ -153,24 +162,34 @@ def test_header_range_prove_end_to_end(ctx, vx, oracle):
     cfg, ocfg = ctx.stark_config(num_queries=12), dict(S.DEFAULT_CFG, num_queries=12)
     out96, blob = ctx.header_range_prove(ctx.from_host(ch.headers), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
     assert out96 == ch.expected_outputs(16)
-    assert int(blob[0]) == 0x3445474E41525248 and [int(x) for x in blob[1:4]] == [16, ch.trusted_block, ch.target_block]
+    assert int(blob[0]) == vx.lib.HR_MAGIC and [int(x) for x in blob[1:4]] == [16, ch.trusted_block, ch.target_block]
     assert blob[4:16].tobytes() == out96
     ia, ib = oracle_verify_blob(vx, blob, ocfg, 16)
-    assert vx.lib.split_blob(blob)[1].size == 0
+    assert all(vx.lib.split_blob(blob)[k].size == 0 for k in (1, 3, 4))
     assert ia["public_inputs"] == limbs(ch.trusted_hash) + limbs(out96[:32]) + [ch.trusted_block + 1, ch.target_block, 16, 1]
     assert ib["public_inputs"] == [int.from_bytes(out96[32 + 4 * j: 36 + 4 * j], "big") for j in range(16)]  # ALL 96 output bytes are public inputs of a proof
     # with a justification: accepted when > 2/3 signed the target, refused otherwise
     good = vx.lib.PackedJustification(vx.synth.Justification(ch.target_block, ch.target_hash, n_auth=9, n_signed=7), 12)
     o2, b2 = ctx.header_range_prove(ctx.from_host(ch.headers), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg, just=good)
-    assert o2 == out96 and (vx.lib.split_blob(b2)[0] == vx.lib.split_blob(blob)[0]).all() and (vx.lib.split_blob(b2)[2] == vx.lib.split_blob(blob)[2]).all()
-    from oracle import sha_air as A
-    S.register_air(A.ShaChainAir)
-    S.verify(vx.lib.split_blob(b2)[1], ocfg, expect_air=A.ID)
-    vx.lib.header_range_verify(b2, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, o2, cfg, authority_set_hash=good.sh.tobytes())
+    assert o2 == out96 and all(p.size for p in vx.lib.split_blob(b2))
+    # the reference verifier: five tables on one bus (hash chain, Merkle, commitment, Ed25519, SHA-512)
+    infos = oracle_verify_blob(vx, b2, ocfg, 16)
+    assert infos[2]["public_inputs"][8:] == [9, 1] and infos[3]["public_inputs"] == [7, 1]
+    sid = good.struct.authority_set_id
+    vx.lib.header_range_verify(b2, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, o2, cfg, authority_set_hash=good.sh.tobytes(), authority_set_id=sid)
+    with pytest.raises(vx.VxError):  # another authority set
+        vx.lib.header_range_verify(b2, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, o2, cfg, authority_set_hash=bytes(32), authority_set_id=sid)
+    with pytest.raises(vx.VxError):  # the signatures are over the precommit of THIS set id
+        vx.lib.header_range_verify(b2, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, o2, cfg, authority_set_hash=good.sh.tobytes(), authority_set_id=sid + 1)
+    with pytest.raises(vx.VxError):  # a request that names an authority set cannot be answered without a justification
+        vx.lib.header_range_verify(blob, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg, authority_set_hash=good.sh.tobytes(), authority_set_id=sid)
+    with pytest.raises(vx.VxError):  # ... and a justification cannot be dropped from the blob
+        cut = np.concatenate([b2[:17], np.array([0, b2[18], 0, 0, 0], dtype=np.uint64), vx.lib.split_blob(b2)[0], vx.lib.split_blob(b2)[2]])
+        vx.lib.header_range_verify(cut, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, o2, cfg)
+    bad_round = b2.copy()
+    bad_round[21] += np.uint64(1)  # the precommit's round is part of the signed message
     with pytest.raises(vx.VxError):
-        vx.lib.header_range_verify(b2, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, o2, cfg, authority_set_hash=bytes(32))
-    with pytest.raises(vx.VxError):  # a blob without the commitment proof cannot satisfy a request that names a set hash
-        vx.lib.header_range_verify(blob, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg, authority_set_hash=good.sh.tobytes())
+        vx.lib.header_range_verify(bad_round, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, o2, cfg, authority_set_hash=good.sh.tobytes(), authority_set_id=sid)
     for bad_j in (vx.synth.Justification(ch.target_block, ch.target_hash, n_auth=9, n_signed=6),
                   vx.synth.Justification(ch.target_block, ch.hashes[3], n_auth=9)):
         with pytest.raises(vx.VxError) as e:
@@ -205,9 +224,8 @@ def test_merkle_roots_are_bound_by_the_proof(ctx, vx, oracle):
     # a Merkle proof from a different chain (other roots, internally consistent) next to this chain's hash-chain proof
     other = vx.synth.Chain(11, profile="Ptiny", stride=512, seed=777)
     o2, b2 = ctx.header_range_prove(ctx.from_host(other.headers), 512, other.sizes, 16, other.trusted_block, other.trusted_hash, other.target_block, cfg)
-    pa, _, _ = vx.lib.split_blob(blob)
-    _, _, pb = vx.lib.split_blob(b2)
-    franken = np.concatenate([blob[:16], np.array([pa.size, 0, pb.size], dtype=np.uint64), pa, pb])
+    pa, pb = vx.lib.split_blob(blob)[0], vx.lib.split_blob(b2)[2]
+    franken = np.concatenate([blob[:16], np.array([pa.size, 0, pb.size, 0, 0, 0], dtype=np.uint64), pa, pb])
     fr_out = out96[:32] + o2[32:]
     franken[4:16] = np.frombuffer(fr_out, dtype=np.uint64)
     with pytest.raises(vx.VxError):
@@ -220,7 +238,7 @@ def test_merkle_table_proof_bytes_match_reference_prover(ctx, vx, oracle):
     ch = vx.synth.Chain(5, profile="Ptiny", stride=512)
     cfg, ocfg = ctx.stark_config(num_queries=9), dict(S.DEFAULT_CFG, num_queries=9)
     out96, blob = ctx.header_range_prove(ctx.from_host(ch.headers), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
-    p_blake, _, p_tree = vx.lib.split_blob(blob)
+    p_blake, _, p_tree, _, _ = vx.lib.split_blob(blob)
     pub_a, cap_a = S.proof_peek(p_blake, ocfg["cap_height"])
     ttr, tpub = T.gen_trace(ch.state_roots, ch.data_roots, 16)
     want = S.prove(TREE16, ttr, tpub, ocfg, chal_hook=lambda pub_b, cap_b: S.shared_challenges(pub_a, cap_a, pub_b, cap_b, 4))

@@ -81,8 +81,8 @@ def test_rotate_prove_small(ctx, vx):
     info = S.verify(p0, pcfg, expect_air=B.ID)
     assert info["public_inputs"] == limbs(e.bytes[:32]) + limbs(e.hash) + [140000, 140000, 0, 0]  # stand-alone: nothing on the bus
     be = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "big") for j in range(8)]  # noqa: E731
-    assert S.verify(p1, pcfg, expect_air=A.ID)["public_inputs"] == be(sj.authority_set_hash)
-    assert S.verify(p2, pcfg, expect_air=A.ID)["public_inputs"] == be(out32)
+    assert S.verify(p1, pcfg, expect_air=A.ID)["public_inputs"][:8] == be(sj.authority_set_hash)
+    assert S.verify(p2, pcfg, expect_air=A.ID)["public_inputs"][:8] == be(out32)
     # product verifier: accepts, and is bound to the request and the claimed output
     vx.lib.rotate_verify(blob, 3, sj.authority_set_hash, out32, cfg)
     for args in ((4, sj.authority_set_hash, out32), (3, bytes(32), out32), (3, sj.authority_set_hash, bytes(32))):

@@ -20,7 +20,7 @@ def test_trace_and_proof_match_oracle(ctx, vx, oracle, n_keys, log_n):
     pks = keys(n_keys)
     buf, pub, com = ctx.sha_chain_trace(pks, log_n)
     want, wpub, final = A.gen_trace(pks, log_n)
-    got = buf.download().reshape(A.COLS, 1 << log_n)
+    got = buf.download().reshape(A.CHAIN_COLS, 1 << log_n)
     bad = np.argwhere(got != want)
     assert bad.size == 0, f"first differing cells (col,row): {bad[:5].tolist()}"
     assert [int(x) for x in pub] == wpub and com == final
@@ -29,6 +29,15 @@ def test_trace_and_proof_match_oracle(ctx, vx, oracle, n_keys, log_n):
     assert (proof == S.prove(A.ShaChainAir, want, wpub, cfg)).all()
     S.verify(proof, cfg, expect_air=A.ID, expect_public=wpub)
     vx.lib.stark_verify(proof, ctx.stark_config(num_queries=10), expect_air=A.ID, expect_public=wpub)
+    # with the bus on: the keys of the signed authorities are sent; trace and auxiliary columns == oracle
+    signed = [(i % 3) != 1 for i in range(n_keys)]
+    buf, pub, _ = ctx.sha_chain_trace(pks, log_n, signed=signed, bus_on=1)
+    want, wpub, _ = A.gen_trace(pks, log_n, signed=signed, bus_on=1)
+    assert (buf.download().reshape(A.CHAIN_COLS, 1 << log_n) == want).all() and [int(x) for x in pub] == wpub
+    chal = [3, 5, 7, 11]
+    aux, apub = ctx.stark_aux_trace(A.ID, buf, log_n, chal, A.AUX, public_inputs=pub)
+    waux, wapub = A.ShaChainAir.gen_aux(want, chal, wpub)
+    assert (aux.download().reshape(A.AUX, 1 << log_n) == waux).all() and [int(x) for x in apub[:2]] == wapub and wapub != [0, 0]
 
 
 def test_300_authorities(ctx, vx):
