@@ -10,7 +10,8 @@
 // A ZERO-CHECK is the gadget without c on twice the expression.  14 gadgets (672 cells, 672 lookups) per row.
 // A slot is 256 rows: row 0 SETUP-A (A on the curve, canonical, sign; -A and B - A in cached form), row 1 SETUP-B
 // (H = qq l + hr, hr < l; accumulator := identity), rows 2..254 STEP (Q' = 2Q + addend selected by the bits of S and
-// hr; dbl-2008-hwcd + madd-2008-hwcd-3), row 255 FINAL ((xR Z, yR Z) = (X, Y), canonical, sign).  Layout, bus tuples
+// hr; dbl-2008-hwcd + madd-2008-hwcd-3), row 255 FINAL ((xR Z, yR Z) = (X, Y), canonical, sign).  Slots are compact: slot s
+// verifies the s-th chosen signature, whose authority index is the slot register AIDX (2/3 of 300 fit 2^16 rows).  Layout, bus tuples
 // and the constraint ORDER (protocol) are restated independently in oracle/ed_air.py -- read its header for the map.
 #pragma once
 #include <vector>
@@ -21,7 +22,7 @@
 namespace edc {
 constexpr int NG = 14, CELLS = NG * 48;
 constexpr int XA0 = 672, YA0 = 688, NT0 = 704, X30 = 720, Y30 = 736, BT0 = 752, HR0 = 768, SEL0 = 784;
-constexpr int BS = 832, BH = 833, LAH = 834, SG = 835, CNT = 836, MULT = 837, COLS = 838;
+constexpr int BS = 832, BH = 833, LAH = 834, SG = 835, CNT = 836, MULT = 837, AIDX = 838, COLS = 839;
 constexpr int N_RANGE = CELLS / 2, N_BUS = 6, HB0 = N_RANGE, HT = N_RANGE + N_BUS, ZZ = HT + 1, N_HELP = ZZ + 1, AUX = 2 * N_HELP;
 constexpr int TAG_R16 = 4, TAG_KEY = 5, TAG_EDMSG = 6, TAG_EDH = 7;
 enum { P_S0N, P_S1N, P_STN, P_FINN, P_KEEP, P_STEP, P_LST, P_R0, P_R1, P_R255, P_LE0, P_SLOT = 26, P_T = 27, N_PERIODIC = 28 };
@@ -311,6 +312,7 @@ struct EdAirT {
 #pragma unroll 1
         for (int col = XA0; col < SEL0; ++col) c.constraint(keep * (nxt[col] - loc[col]));
         c.constraint(keep * (nxt[SG] - loc[SG]));
+        c.constraint(keep * (nxt[AIDX] - loc[AIDX]));
         {
             const F bs = loc[BS], bh = loc[BH], w11 = bs * bh, w10 = bs - w11, w01 = bh - w11, w00 = one - bs - bh + w11;
 #pragma unroll 1
@@ -358,7 +360,7 @@ struct EdAirT {
             for (int b = 0; b < 4; ++b) {
                 const F m = on * (zero - r0 - r1);
                 const F tag = r0 * F::from(TAG_KEY) + r1 * F::from(TAG_EDH);
-                const F t0 = (r0 + r1) * (slot4 + F::from((uint64_t)b));
+                const F t0 = r0 * (loc[AIDX] * F::from(4) + F::from((uint64_t)b)) + r1 * (slot4 + F::from((uint64_t)b));
                 const F u1 = r0 * p2(enc_a, 4 * b) + r1 * p3(hl, 8 * b), u2 = r0 * p2(enc_a, 4 * b + 2) + r1 * p3(hl, 8 * b + 3), u3 = r1 * p2(hl, 8 * b + 6);
                 const X2<F> d = beta + t0 + gamma * u1 + g2 * u2 + g3 * u3 + g4 * tag;
                 const X2<F> h{loc[AX(HB0 + b, 0)], loc[AX(HB0 + b, 1)]};

@@ -656,11 +656,13 @@ static int tree_log_n(uint32_t max_headers) {
     while ((1u << (l - 8)) < max_headers) ++l;
     return l;
 }
-// the EdDSA tables by the size of the authority set: 256 rows per signature / 164 rows per hash
-static int ed_log_n(size_t n_auth) { return n_auth <= 256 ? 16 : 17; }
-static int ed_air_id(size_t n_auth) { return n_auth <= 256 ? VX_AIR_ED25519_16 : VX_AIR_ED25519; }
-static int s512_log_n(size_t n_auth) { return n_auth <= 6 ? 10 : 16; }
-static int s512_air_id(size_t n_auth) { return n_auth <= 6 ? VX_AIR_SHA512_10 : VX_AIR_SHA512; }
+// the EdDSA tables by the number of signatures they verify: 256 rows per signature (one slot stays idle) / 164 rows per hash.
+// The prover needs floor(2n/3) + 1 of the n authorities (justification.rs:164-186), so it verifies exactly that many.
+static size_t sig_quorum(size_t n_auth) { return 2 * n_auth / 3 + 1; }
+static int ed_log_n(size_t n_sig) { return n_sig <= 255 ? 16 : 17; }
+static int ed_air_id(size_t n_sig) { return n_sig <= 255 ? VX_AIR_ED25519_16 : VX_AIR_ED25519; }
+static int s512_log_n(size_t n_sig) { return n_sig <= 6 ? 10 : 16; }
+static int s512_air_id(size_t n_sig) { return n_sig <= 6 ? VX_AIR_SHA512_10 : VX_AIR_SHA512; }
 
 int32_t vx_header_range_proof_bound(const vx_stark_config* cfg, size_t n_chunks, size_t n_authorities, size_t* n_words) {
     if (!cfg || !n_words || n_chunks == 0) return VX_ERR_ARG;
@@ -670,8 +672,8 @@ int32_t vx_header_range_proof_bound(const vx_stark_config* cfg, size_t n_chunks,
     int32_t rc = vx_stark_proof_bound(VX_AIR_BLAKE_CHAIN, cfg, log_n, &w1);
     if (rc == VX_OK && n_authorities) rc = vx_stark_proof_bound(VX_AIR_SHA_CHAIN, cfg, sha_log_n(n_authorities), &w2);
     if (rc == VX_OK) rc = vx_stark_proof_bound(8, cfg, tree_log_n(512), &w3);  // the largest Merkle AIR (the request's max_headers is not known here)
-    if (rc == VX_OK && n_authorities) rc = vx_stark_proof_bound(ed_air_id(n_authorities), cfg, ed_log_n(n_authorities), &w4);
-    if (rc == VX_OK && n_authorities) rc = vx_stark_proof_bound(s512_air_id(n_authorities), cfg, s512_log_n(n_authorities), &w5);
+    if (rc == VX_OK && n_authorities) rc = vx_stark_proof_bound(ed_air_id(sig_quorum(n_authorities)), cfg, ed_log_n(sig_quorum(n_authorities)), &w4);
+    if (rc == VX_OK && n_authorities) rc = vx_stark_proof_bound(s512_air_id(sig_quorum(n_authorities)), cfg, s512_log_n(sig_quorum(n_authorities)), &w5);
     *n_words = w1 + w2 + w3 + w4 + w5 + VX_HR_HDR;
     return rc;
 }
@@ -768,6 +770,15 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
         }
         VX_CHECK(c, "header_range: no side context for every table (the provers meet at their challenge hooks, each on its own context)");
     }
+    // the signatures the proof verifies: the first floor(2n/3) + 1 signed authorities (more would only cost rows); when fewer
+    // signed, all of them -- the native threshold check refuses the justification before anything is proven
+    std::vector<uint8_t> chosen;
+    size_t n_sig = 0;
+    if (just) {
+        chosen.assign(just->num_authorities, 0);
+        for (size_t i = 0; i < just->num_authorities && n_sig < sig_quorum(just->num_authorities); ++i)
+            if (just->validator_signed[i]) chosen[i] = 1, ++n_sig;
+    }
     uint64_t tpub[16];
     auto prove_tree = [&](vx_ctx* c, TableJob& j) -> int32_t {
         vx_buf* tt = nullptr;
@@ -801,34 +812,34 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
         VX_TRY(vx_alloc(c, ((size_t)VX_SHA_AIR_COLS) << sl, &st));
         uint64_t spub[10];
         uint8_t com[32];
-        int32_t r = vx_sha_chain_trace_dev(c, just->pubkeys, just->num_authorities, just->validator_signed, 1, sl, st->d, spub, com);
+        int32_t r = vx_sha_chain_trace_dev(c, just->pubkeys, just->num_authorities, chosen.data(), 1, sl, st->d, spub, com);
         if (r == VX_OK && memcmp(com, just->authority_set_hash, 32) != 0) r = vx_fail(c, VX_ERR_STATEMENT, "header_range: authority-set commitment mismatch");
         if (r == VX_OK) r = vx_stark_prove_impl(c, VX_AIR_SHA_CHAIN, cfg, st->d, st->n, /*consume_trace=*/0, sl, spub, 10, j.proof.data(), j.proof.size(), &j.len, &hooks[2]);
         (void)vx_free(c, st);
         return r;
     };
     auto prove_ed = [&](vx_ctx* c, TableJob& j) -> int32_t {
-        const int el = ed_log_n(just->num_authorities), id = ed_air_id(just->num_authorities);
+        const int el = ed_log_n(n_sig), id = ed_air_id(n_sig);
         size_t bound = 0;
         VX_TRY(vx_stark_proof_bound(id, cfg, el, &bound));
         j.proof.resize(bound);
         vx_buf* et = nullptr;
         VX_TRY(vx_alloc(c, ((size_t)VX_ED_AIR_COLS) << el, &et));
         uint64_t epub[2];
-        int32_t r = vx_ed_trace_dev(c, just->pubkeys, just->signatures, just->precommit, 53, just->validator_signed, just->num_authorities, el, 1, et->d, epub);
+        int32_t r = vx_ed_trace_dev(c, just->pubkeys, just->signatures, just->precommit, 53, chosen.data(), just->num_authorities, el, 1, et->d, epub);
         if (r == VX_OK) r = vx_stark_prove_impl(c, id, cfg, et->d, et->n, /*consume_trace=*/0, el, epub, 2, j.proof.data(), j.proof.size(), &j.len, &hooks[3]);
         (void)vx_free(c, et);
         return r;
     };
     auto prove_s512 = [&](vx_ctx* c, TableJob& j) -> int32_t {
-        const int hl = s512_log_n(just->num_authorities), id = s512_air_id(just->num_authorities);
+        const int hl = s512_log_n(n_sig), id = s512_air_id(n_sig);
         size_t bound = 0;
         VX_TRY(vx_stark_proof_bound(id, cfg, hl, &bound));
         j.proof.resize(bound);
         vx_buf* ht = nullptr;
         VX_TRY(vx_alloc(c, ((size_t)VX_SHA512_AIR_COLS) << hl, &ht));
         uint64_t hpub[15];
-        int32_t r = vx_sha512_trace_dev(c, just->pubkeys, just->signatures, just->precommit, just->validator_signed, just->num_authorities, hl, 1, ht->d, hpub);
+        int32_t r = vx_sha512_trace_dev(c, just->pubkeys, just->signatures, just->precommit, chosen.data(), just->num_authorities, hl, 1, ht->d, hpub);
         if (r == VX_OK) r = vx_stark_prove_impl(c, id, cfg, ht->d, ht->n, /*consume_trace=*/0, hl, hpub, 15, j.proof.data(), j.proof.size(), &j.len, &hooks[4]);
         (void)vx_free(c, ht);
         return r;

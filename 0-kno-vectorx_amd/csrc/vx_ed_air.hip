@@ -26,7 +26,7 @@ struct EdSlot {
     int32_t hl[32], qq[17], hr[16], hw[16], crlo[32], crhi[32];
     uint8_t cxa[16], cya[16], cxr[16], cyr[16], chr[16];  // carries of x + w = top (15 used)
     uint32_t s[8], h[8];                                   // the scalars whose bits the STEP rows consume
-    uint32_t sign_a, sign_r, sg, cnt;
+    uint32_t sign_a, sign_r, sg, cnt, aidx, pad;
 };
 
 __device__ void limbs16(const ed::U256& x, int32_t* out) {
@@ -42,13 +42,15 @@ __device__ void canon_witness(const int32_t* x, int t, int32_t* w, uint8_t* cy) 
         cy[k] = (uint8_t)borrow;  // x_k + w_k + cy_(k-1) = top_k + 2^16 cy_k
     }
 }
-__global__ __launch_bounds__(64) void k_ed_slots(const uint8_t* pubkeys, const uint8_t* sigs, const uint8_t* msg, uint32_t msg_len, const uint8_t* sg_flags,
-                                                 const uint32_t* cnt, size_t n_sigs, size_t m, EdSlot* out, uint32_t* bad) {
+// slot s < k verifies the signature of authority idx[s]; slots k.. are idle (all identical: only slot k is made)
+__global__ __launch_bounds__(64) void k_ed_slots(const uint8_t* pubkeys, const uint8_t* sigs, const uint8_t* msg, uint32_t msg_len, const uint32_t* idx, size_t k_active,
+                                                 EdSlot* out, uint32_t* bad) {
     using namespace ed;
     const size_t s = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (s >= m) return;
+    if (s > k_active) return;
     EdSlot& o = out[s];
-    const bool on = s < n_sigs && sg_flags[s];
+    const bool on = s < k_active;
+    const size_t au = on ? idx[s] : 0;
     U256 one, zero;
     for (int j = 0; j < 8; ++j) one.w[j] = j == 0, zero.w[j] = 0;
     const U256 bx = fe_from(ED_BX), by = fe_from(ED_BY);
@@ -57,8 +59,8 @@ __global__ __launch_bounds__(64) void k_ed_slots(const uint8_t* pubkeys, const u
     for (int j = 0; j < 64; ++j) dig[j] = 0;
     for (int j = 0; j < 8; ++j) o.s[j] = 0;
     if (on) {
-        const uint8_t* pk = pubkeys + 32 * s;
-        const uint8_t* sg = sigs + 64 * s;
+        const uint8_t* pk = pubkeys + 32 * au;
+        const uint8_t* sg = sigs + 64 * au;
         if (!pt_decode(pk, &A) || !pt_decode(sg, &R)) {
             atomicAdd(bad, 1u);
             return;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(64) void k_ed_slots(const uint8_t* pubkeys, const u
     limbs16(A.X, o.xa), limbs16(A.Y, o.ya), limbs16(x3, o.x3), limbs16(y3, o.y3), limbs16(R.X, o.xr), limbs16(R.Y, o.yr);
     canon_witness(o.xa, K_QM1, o.wxa, o.cxa), canon_witness(o.ya, K_QM1, o.wya, o.cya);
     canon_witness(o.xr, K_QM1, o.wxr, o.cxr), canon_witness(o.yr, K_QM1, o.wyr, o.cyr);
-    o.sign_a = A.X.w[0] & 1, o.sign_r = R.X.w[0] & 1, o.sg = on, o.cnt = cnt[s];
+    o.sign_a = A.X.w[0] & 1, o.sign_r = R.X.w[0] & 1, o.sg = on, o.cnt = (uint32_t)(on ? s + 1 : k_active), o.aidx = (uint32_t)au, o.pad = 0;
     // H = qq l + hr, bit-serial: r = 2r + bit; if r >= l: r -= l, quotient bit 1
     uint32_t r[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[16];
     for (int j = 0; j < 16; ++j) q[j] = 0;
@@ -156,12 +158,12 @@ __device__ __forceinline__ void ed_normalise(const int64_t* F, int k, int32_t& c
 }
 
 constexpr int ED_SLOTS_PER_BLOCK = 4;
-__global__ __launch_bounds__(64) void k_ed_rows(const EdSlot* slots, int32_t* stage, size_t m, uint32_t* bad) {
+__global__ __launch_bounds__(64) void k_ed_rows(const EdSlot* slots, int32_t* stage, size_t k_active, uint32_t* bad) {
     __shared__ int32_t As[ED_SLOTS_PER_BLOCK][16], Bs[ED_SLOTS_PER_BLOCK][16];
     __shared__ int64_t Fs[ED_SLOTS_PER_BLOCK][16];
     const int sl = threadIdx.x >> 4, k = threadIdx.x & 15;
-    const size_t slot = blockIdx.x * (size_t)ED_SLOTS_PER_BLOCK + sl;  // m is a multiple of 4
-    const EdSlot& in = slots[slot];
+    const size_t slot = blockIdx.x * (size_t)ED_SLOTS_PER_BLOCK + sl;       // the grid covers slots 0 .. k_active rounded up to 4:
+    const EdSlot& in = slots[slot < k_active ? slot : k_active];             // the extra ones repeat the idle slot
     int32_t* row = stage + slot * 256 * (size_t)COLS;
     // F_k of a * b (both operands: this lane's limb)
     auto fold = [&](int32_t a, int32_t b) -> int64_t {
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(64) void k_ed_rows(const EdSlot* slots, int32_t* st
         row[SEL0 + k] = w00 * one_k + w10 * kk(K_BC0) + w01 * (ya + xa) + w11 * (y3 - x3);
         row[SEL0 + 16 + k] = w00 * one_k + w10 * kk(K_BC1) + w01 * (ya - xa) + w11 * (y3 + x3);
         row[SEL0 + 32 + k] = w10 * kk(K_BC2) + w01 * nt + w11 * bt;
-        if (k < 6) row[BS + k] = k == 0 ? bs : k == 1 ? bh : k == 2 ? lah : k == 3 ? (int32_t)in.sg : k == 4 ? (int32_t)in.cnt : 0;  // BS BH LAH SG CNT MULT
+        if (k < 7) row[BS + k] = k == 0 ? bs : k == 1 ? bh : k == 2 ? lah : k == 3 ? (int32_t)in.sg : k == 4 ? (int32_t)in.cnt : k == 5 ? 0 : (int32_t)in.aidx;  // BS BH LAH SG CNT MULT AIDX
     };
     // ---- row 0: SETUP-A
     clear();
@@ -263,12 +265,13 @@ __global__ __launch_bounds__(64) void k_ed_rows(const EdSlot* slots, int32_t* st
     }
 }
 
-// staging [n][COLS] int32 -> trace [COLS][n] field elements; one 64 x 64 tile per block
-__global__ __launch_bounds__(256) void k_ed_expand(const int32_t* stage, uint64_t* trace, size_t n) {
+// staging [(k_active + 1) * 256][COLS] int32 -> trace [COLS][n] field elements; one 64 x 64 tile per block; every idle slot
+// is a copy of staging slot k_active
+__global__ __launch_bounds__(256) void k_ed_expand(const int32_t* stage, uint64_t* trace, size_t n, size_t k_active) {
     __shared__ int32_t tile[64][65];
-    const size_t row0 = blockIdx.x * (size_t)64;
+    const size_t row0 = blockIdx.x * (size_t)64, slot = row0 >> 8, src0 = (slot < k_active ? slot : k_active) * 256 + (row0 & 255);
     const int col0 = blockIdx.y * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int r = ty; r < 64; r += 4) tile[r][tx] = col0 + tx < COLS ? stage[(row0 + r) * COLS + col0 + tx] : 0;
+    for (int r = ty; r < 64; r += 4) tile[r][tx] = col0 + tx < COLS ? stage[(src0 + r) * COLS + col0 + tx] : 0;
     __syncthreads();
     for (int c = ty; c < 64; c += 4) {
         if (col0 + c >= COLS) break;
@@ -276,11 +279,13 @@ __global__ __launch_bounds__(256) void k_ed_expand(const int32_t* stage, uint64_
         trace[(size_t)(col0 + c) * n + row0 + tx] = v < 0 ? GL_P - (uint64_t)(-(int64_t)v) : (uint64_t)v;
     }
 }
-constexpr int ED_HIST_COPIES = 8;
-__global__ __launch_bounds__(256) void k_ed_hist(const int32_t* stage, size_t n, uint32_t* hist) {
+// one block per staged row; the rows of the idle slot count once for every idle slot of the trace
+constexpr int ED_HIST_COPIES = 32;
+__global__ __launch_bounds__(256) void k_ed_hist(const int32_t* stage, size_t k_active, uint32_t idle_weight, uint32_t* hist) {
     const size_t row = blockIdx.x;
+    const uint32_t w = (row >> 8) < k_active ? 1u : idle_weight;
     uint32_t* h = hist + (size_t)(blockIdx.x % ED_HIST_COPIES) * 65536;
-    for (int col = threadIdx.x; col < CELLS; col += 256) atomicAdd(&h[(uint32_t)stage[row * COLS + col] & 65535u], 1u);
+    for (int col = threadIdx.x; col < CELLS; col += 256) atomicAdd(&h[(uint32_t)stage[row * COLS + col] & 65535u], w);
 }
 __global__ __launch_bounds__(256) void k_ed_mult(const uint32_t* hist, uint64_t* mult_col) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(256) void k_ed_aux(EdAuxArgs a) {
     for (int b = 0; b < N_BUS; ++b) hb[b] = gl2{0, 0};
     if ((r == 0 || r == 1 || r == 255) && a.bus_on && T(SG)) {
         const gl2 g2 = gl2_mul(a.gamma, a.gamma), g3 = gl2_mul(g2, a.gamma), g4 = gl2_mul(g2, g2);
-        const uint64_t slot4 = 4 * (uint64_t)(i >> 8), sign = T(BS);
+        const uint64_t slot4 = 4 * (uint64_t)(i >> 8), sign = T(BS), aidx4 = 4 * T(AIDX);
         auto enc = [&](int g, int k) -> uint64_t { return k < 15 ? T(C(g, k)) : T(C(g, 15)) + 32768 * sign; };
         auto hl = [&](int k) -> uint64_t { return k < 16 ? T(C(0, k)) : T(RL(0, k - 16)); };
         auto fp = [&](uint64_t t0, uint64_t t1, uint64_t t2, uint64_t t3, int tag) -> gl2 {
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(256) void k_ed_aux(EdAuxArgs a) {
         auto neg = [](gl2 x) -> gl2 { return gl2{gl_neg(x.a), gl_neg(x.b)}; };
         if (r == 0) {
             for (int b = 0; b < 4; ++b)
-                hb[b] = neg(gl2_inv(fp(slot4 + b, enc(7, 4 * b) | (enc(7, 4 * b + 1) << 16), enc(7, 4 * b + 2) | (enc(7, 4 * b + 3) << 16), 0, TAG_KEY)));
+                hb[b] = neg(gl2_inv(fp(aidx4 + b, enc(7, 4 * b) | (enc(7, 4 * b + 1) << 16), enc(7, 4 * b + 2) | (enc(7, 4 * b + 3) << 16), 0, TAG_KEY)));
             for (int b = 0; b < 2; ++b)
                 hb[4 + b] = gl2_inv(fp(slot4 + b + 2, enc(7, 8 * b) | (enc(7, 8 * b + 1) << 16) | (enc(7, 8 * b + 2) << 32),
                                        enc(7, 8 * b + 3) | (enc(7, 8 * b + 4) << 16) | (enc(7, 8 * b + 5) << 32), enc(7, 8 * b + 6) | (enc(7, 8 * b + 7) << 16), TAG_EDMSG));
@@ -378,48 +383,47 @@ int32_t vx_ed_trace_dev(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* sigs
                         int log_n, uint64_t bus_on, uint64_t* trace_d, uint64_t pub_out[2]) {
     const size_t n = (size_t)1 << log_n, m = n >> 8;
     VX_CHECK(log_n >= 16 && log_n <= 20, "ed trace: log_n %d out of range [16, 20] (the trace holds one copy of the 2^16-row range table)", log_n);
-    VX_CHECK(n_sigs <= m, "ed trace: %zu signatures do not fit the %zu slots of 2^%d rows", n_sigs, m, log_n);
     VX_CHECK(msg_len <= 64, "ed trace: message of %u bytes (the precommit has 53)", msg_len);
-    std::vector<uint32_t> cnt(m);
-    uint32_t acc = 0;
-    for (size_t s = 0; s < m; ++s) acc += s < n_sigs && signed_flags[s] ? 1 : 0, cnt[s] = acc;
-    // device scratch: keys | sigs | msg | flags | cnt | bad | slots | hist, then the staging buffer from the pool
-    const size_t w_keys = 4 * n_sigs + 1, w_sigs = 8 * n_sigs + 1, w_msg = 8, w_flags = (n_sigs + 7) / 8 + 1, w_cnt = (m + 1) / 2, w_slots = (m * sizeof(EdSlot) + 7) / 8;
+    std::vector<uint32_t> idx;  // compact slots: slot s verifies the s-th flagged authority
+    for (size_t s = 0; s < n_sigs; ++s)
+        if (signed_flags[s]) idx.push_back((uint32_t)s);
+    const size_t k = idx.size(), k4 = (k + 1 + ED_SLOTS_PER_BLOCK - 1) / ED_SLOTS_PER_BLOCK * ED_SLOTS_PER_BLOCK;  // staged slots: the active ones + the idle one, rounded up
+    VX_CHECK(k < m, "ed trace: %zu signatures do not fit the %zu slots of 2^%d rows (one slot stays idle)", k, m - 1, log_n);
+    // device scratch: keys | sigs | msg | idx | bad | slots | hist, then the staging buffer from the pool
+    const size_t w_keys = 4 * n_sigs + 1, w_sigs = 8 * n_sigs + 1, w_msg = 8, w_idx = (k + 1) / 2 + 1, w_slots = ((k + 1) * sizeof(EdSlot) + 7) / 8;
     const size_t w_hist = (size_t)ED_HIST_COPIES * 65536 / 2;
     uint64_t* sc;
-    VX_TRY(vx_scratch(ctx, w_keys + w_sigs + w_msg + w_flags + w_cnt + 1 + w_slots + w_hist, &sc));
+    VX_TRY(vx_scratch(ctx, w_keys + w_sigs + w_msg + w_idx + 1 + w_slots + w_hist, &sc));
     uint8_t* d_keys = (uint8_t*)sc;
     uint8_t* d_sigs = (uint8_t*)(sc + w_keys);
     uint8_t* d_msg = (uint8_t*)(sc + w_keys + w_sigs);
-    uint8_t* d_flags = (uint8_t*)(sc + w_keys + w_sigs + w_msg);
-    uint32_t* d_cnt = (uint32_t*)(sc + w_keys + w_sigs + w_msg + w_flags);
-    uint32_t* d_bad = (uint32_t*)(sc + w_keys + w_sigs + w_msg + w_flags + w_cnt);
-    EdSlot* d_slots = (EdSlot*)(sc + w_keys + w_sigs + w_msg + w_flags + w_cnt + 1);
-    uint32_t* d_hist = (uint32_t*)(sc + w_keys + w_sigs + w_msg + w_flags + w_cnt + 1 + w_slots);
+    uint32_t* d_idx = (uint32_t*)(sc + w_keys + w_sigs + w_msg);
+    uint32_t* d_bad = (uint32_t*)(sc + w_keys + w_sigs + w_msg + w_idx);
+    EdSlot* d_slots = (EdSlot*)(sc + w_keys + w_sigs + w_msg + w_idx + 1);
+    uint32_t* d_hist = (uint32_t*)(sc + w_keys + w_sigs + w_msg + w_idx + 1 + w_slots);
     if (n_sigs) {
         VX_HIP(hipMemcpyAsync(d_keys, pubkeys, 32 * n_sigs, hipMemcpyHostToDevice, ctx->stream));
         VX_HIP(hipMemcpyAsync(d_sigs, sigs, 64 * n_sigs, hipMemcpyHostToDevice, ctx->stream));
-        VX_HIP(hipMemcpyAsync(d_flags, signed_flags, n_sigs, hipMemcpyHostToDevice, ctx->stream));
     }
+    if (k) VX_HIP(hipMemcpyAsync(d_idx, idx.data(), k * 4, hipMemcpyHostToDevice, ctx->stream));
     VX_HIP(hipMemcpyAsync(d_msg, msg, msg_len, hipMemcpyHostToDevice, ctx->stream));
-    VX_HIP(hipMemcpyAsync(d_cnt, cnt.data(), m * 4, hipMemcpyHostToDevice, ctx->stream));
     VX_HIP(hipMemsetAsync(d_bad, 0, 8, ctx->stream));
     VX_HIP(hipMemsetAsync(d_hist, 0, w_hist * 8, ctx->stream));
-    int32_t* stage = (int32_t*)vx_pool_alloc(ctx, n * (size_t)COLS * 4);
+    int32_t* stage = (int32_t*)vx_pool_alloc(ctx, k4 * 256 * (size_t)COLS * 4);
     if (!stage) return vx_fail(ctx, VX_ERR_OOM, "ed trace: out of device memory");
-    hipLaunchKernelGGL(k_ed_slots, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, ctx->stream, d_keys, d_sigs, d_msg, msg_len, d_flags, d_cnt, n_sigs, m, d_slots, d_bad);
-    hipLaunchKernelGGL(k_ed_rows, dim3((unsigned)(m / ED_SLOTS_PER_BLOCK)), dim3(64), 0, ctx->stream, (const EdSlot*)d_slots, stage, m, d_bad);
-    hipLaunchKernelGGL(k_ed_expand, dim3((unsigned)(n / 64), (COLS + 63) / 64), dim3(256), 0, ctx->stream, (const int32_t*)stage, trace_d, n);
-    hipLaunchKernelGGL(k_ed_hist, dim3((unsigned)n), dim3(256), 0, ctx->stream, (const int32_t*)stage, n, d_hist);
+    hipLaunchKernelGGL(k_ed_slots, dim3((unsigned)((k + 1 + 63) / 64)), dim3(64), 0, ctx->stream, d_keys, d_sigs, d_msg, msg_len, (const uint32_t*)d_idx, k, d_slots, d_bad);
+    hipLaunchKernelGGL(k_ed_rows, dim3((unsigned)(k4 / ED_SLOTS_PER_BLOCK)), dim3(64), 0, ctx->stream, (const EdSlot*)d_slots, stage, k, d_bad);
+    hipLaunchKernelGGL(k_ed_expand, dim3((unsigned)(n / 64), (COLS + 63) / 64), dim3(256), 0, ctx->stream, (const int32_t*)stage, trace_d, n, k);
+    hipLaunchKernelGGL(k_ed_hist, dim3((unsigned)((k + 1) * 256)), dim3(256), 0, ctx->stream, (const int32_t*)stage, k, (uint32_t)(m - k), d_hist);
     hipLaunchKernelGGL(k_ed_mult, dim3(256), dim3(256), 0, ctx->stream, (const uint32_t*)d_hist, trace_d + (size_t)MULT * n);
     const hipError_t e = hipGetLastError();
     vx_pool_free(ctx, stage);
     if (e != hipSuccess) return vx_fail(ctx, VX_ERR_DEVICE, "ed trace: %s", hipGetErrorString(e));
     uint32_t bad = 0;
     VX_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
-    VX_HIP(hipStreamSynchronize(ctx->stream));  // cnt (host vector) must outlive the copy; bad is read below
+    VX_HIP(hipStreamSynchronize(ctx->stream));  // idx (host vector) must outlive the copy; bad is read below
     if (bad) return vx_fail(ctx, VX_ERR_STATEMENT, "ed trace: a signed slot does not verify (undecodable key / R, or [S]B != R + [h]A)");
-    pub_out[0] = acc, pub_out[1] = bus_on;
+    pub_out[0] = k, pub_out[1] = bus_on;
     return VX_OK;
 }
 

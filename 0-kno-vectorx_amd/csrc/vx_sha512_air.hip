@@ -31,15 +31,16 @@ __device__ void compress(const uint64_t* h_in, const uint64_t* block, uint64_t* 
     }
     for (int i = 0; i < 8; ++i) out[i] = h_in[i] + s[i];
 }
-__global__ __launch_bounds__(64) void k_s512_slots(const uint8_t* pubkeys, const uint8_t* sigs, const uint8_t* msg, const uint8_t* flags, size_t n_sigs, size_t m, S5Slot* out) {
+// slot s < k hashes for authority idx[s] (the slots are compact, in the order of EdAir's); the others hash an all-zero R || A
+__global__ __launch_bounds__(64) void k_s512_slots(const uint8_t* pubkeys, const uint8_t* sigs, const uint8_t* msg, const uint32_t* idx, size_t k_active, size_t m, S5Slot* out) {
     const size_t s = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (s >= m) return;
     S5Slot& o = out[s];
-    const bool on = s < n_sigs && flags[s];
+    const bool on = s < k_active;
     uint8_t buf[128];
     for (int j = 0; j < 128; ++j) buf[j] = 0;
     if (on)
-        for (int j = 0; j < 32; ++j) buf[j] = sigs[64 * s + j], buf[32 + j] = pubkeys[32 * s + j];
+        for (int j = 0; j < 32; ++j) buf[j] = sigs[64 * (size_t)idx[s] + j], buf[32 + j] = pubkeys[32 * (size_t)idx[s] + j];
     for (int j = 0; j < MSG_LEN; ++j) buf[64 + j] = msg[j];
     buf[64 + MSG_LEN] = 0x80;
     for (int i = 0; i < 16; ++i) {
@@ -185,24 +186,29 @@ int32_t vx_sha512_trace_dev(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* 
                             uint64_t* trace_d, uint64_t pub_out[15]) {
     const size_t n = (size_t)1 << log_n, m = n / SLOT_ROWS;
     VX_CHECK(log_n >= 8 && log_n <= 20, "sha512 trace: log_n %d out of range [8, 20]", log_n);
-    VX_CHECK(n_sigs <= m, "sha512 trace: %zu signatures do not fit the %zu slots of 2^%d rows", n_sigs, m, log_n);
-    const size_t w_keys = 4 * n_sigs + 1, w_sigs = 8 * n_sigs + 1, w_msg = 8, w_flags = (n_sigs + 7) / 8 + 1, w_slots = (m * sizeof(S5Slot) + 7) / 8;
+    std::vector<uint32_t> idx;  // compact slots, in EdAir's order: slot s = the s-th flagged authority
+    for (size_t s = 0; s < n_sigs; ++s)
+        if (flags[s]) idx.push_back((uint32_t)s);
+    const size_t k = idx.size();
+    VX_CHECK(k <= m, "sha512 trace: %zu signatures do not fit the %zu slots of 2^%d rows", k, m, log_n);
+    const size_t w_keys = 4 * n_sigs + 1, w_sigs = 8 * n_sigs + 1, w_msg = 8, w_idx = k / 2 + 1, w_slots = (m * sizeof(S5Slot) + 7) / 8;
     uint64_t* sc;
-    VX_TRY(vx_scratch(ctx, w_keys + w_sigs + w_msg + w_flags + w_slots, &sc));
+    VX_TRY(vx_scratch(ctx, w_keys + w_sigs + w_msg + w_idx + w_slots, &sc));
     uint8_t* d_keys = (uint8_t*)sc;
     uint8_t* d_sigs = (uint8_t*)(sc + w_keys);
     uint8_t* d_msg = (uint8_t*)(sc + w_keys + w_sigs);
-    uint8_t* d_flags = (uint8_t*)(sc + w_keys + w_sigs + w_msg);
-    S5Slot* d_slots = (S5Slot*)(sc + w_keys + w_sigs + w_msg + w_flags);
+    uint32_t* d_idx = (uint32_t*)(sc + w_keys + w_sigs + w_msg);
+    S5Slot* d_slots = (S5Slot*)(sc + w_keys + w_sigs + w_msg + w_idx);
     if (n_sigs) {
         VX_HIP(hipMemcpyAsync(d_keys, pubkeys, 32 * n_sigs, hipMemcpyHostToDevice, ctx->stream));
         VX_HIP(hipMemcpyAsync(d_sigs, sigs, 64 * n_sigs, hipMemcpyHostToDevice, ctx->stream));
-        VX_HIP(hipMemcpyAsync(d_flags, flags, n_sigs, hipMemcpyHostToDevice, ctx->stream));
     }
+    if (k) VX_HIP(hipMemcpyAsync(d_idx, idx.data(), k * 4, hipMemcpyHostToDevice, ctx->stream));
     VX_HIP(hipMemcpyAsync(d_msg, msg, MSG_LEN, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_s512_slots, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, ctx->stream, d_keys, d_sigs, d_msg, d_flags, n_sigs, m, d_slots);
+    hipLaunchKernelGGL(k_s512_slots, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, ctx->stream, d_keys, d_sigs, d_msg, (const uint32_t*)d_idx, k, m, d_slots);
     hipLaunchKernelGGL(k_s512_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const S5Slot*)d_slots, m, trace_d, n);
     VX_HIP(hipGetLastError());
+    VX_HIP(hipStreamSynchronize(ctx->stream));  // idx (host vector) must outlive the copy
     uint8_t tail[64];
     memset(tail, 0, sizeof tail);
     memcpy(tail, msg, MSG_LEN);

@@ -536,8 +536,8 @@ int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob,
         NEED(n_signed * 3 > n_auth * 2, "fewer than 2/3 of the authority set signed (%llu of %llu)", (unsigned long long)n_signed, (unsigned long long)n_auth);
         spub[8] = n_auth, spub[9] = 1;
         epub[0] = n_signed, epub[1] = 1;
-        air[3] = n_auth <= 256 ? VX_AIR_ED25519_16 : VX_AIR_ED25519;
-        air[4] = n_auth <= 6 ? VX_AIR_SHA512_10 : VX_AIR_SHA512;
+        air[3] = n_signed <= 255 ? VX_AIR_ED25519_16 : VX_AIR_ED25519;  // the tables are sized by the number of signatures they verify
+        air[4] = n_signed <= 6 ? VX_AIR_SHA512_10 : VX_AIR_SHA512;
         // the signed message: the precommit for (target header hash, target block, round, set id) -- decoder.rs:159-200
         uint8_t msg[64];
         memset(msg, 0, sizeof msg);

@@ -229,12 +229,12 @@ int32_t vx_sha_chain_trace(vx_ctx* ctx, const uint8_t* pubkeys, size_t n_keys, c
                            uint64_t public_inputs_out[10], uint8_t commitment_out[32]);
 
 /* ---- K8: EdAir trace generation (the curve half of the 300 conditional EdDSA verifications, justification.rs:229-243):
- * n_signatures slots (pubkey 32 B, signature R || S 64 B, flag), all over the same message (the 53-byte precommit); a slot
- * whose flag is 0 stays idle.  2^log_n rows hold 2^log_n / 256 slots (300 signatures need log_n = 17).  Writes the
- * 838-column trace and the 2 public inputs (number of signed slots, bus_on); VX_ERR_STATEMENT when a signed slot does
- * not verify.  bus_on = 0 makes a stand-alone table (nothing sent to the SHA-512 / authority-set tables).
+ * n_signatures authorities (pubkey 32 B, signature R || S 64 B, flag), all over the same message (the 53-byte precommit);
+ * the flagged ones take the slots of the table in order (slot s = the s-th flagged authority; its index rides along for
+ * the bus), 256 rows per slot, at least one slot stays idle: 2^16 rows serve up to 255 signatures -- 2/3 of 300.  Writes
+ * the 839-column trace and the 2 public inputs (number of signatures, bus_on); VX_ERR_STATEMENT when one does not verify.  bus_on = 0 makes a stand-alone table (nothing sent to the SHA-512 / authority-set tables).
  * Prove with vx_stark_prove(ctx, VX_AIR_ED25519 (2^17 rows) or VX_AIR_ED25519_16 (2^16 rows), ...). */
-enum { VX_AIR_ED25519 = 10, VX_AIR_ED25519_16 = 12, VX_ED_AIR_COLS = 838, VX_ED_AIR_AUX_COLS = 688 };
+enum { VX_AIR_ED25519 = 10, VX_AIR_ED25519_16 = 12, VX_ED_AIR_COLS = 839, VX_ED_AIR_AUX_COLS = 688 };
 int32_t vx_ed_trace(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* signatures, const uint8_t* message, uint32_t message_len, const uint8_t* signed_flags,
                     size_t n_signatures, int log_n, uint32_t bus_on, vx_buf* trace_out, uint64_t public_inputs_out[2]);
 

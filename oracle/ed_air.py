@@ -23,9 +23,11 @@ A slot is 256 rows:  row 0 SETUP-A, row 1 SETUP-B, rows 2..254 STEP (scalar bit 
   SETUP-A  A = (xA, yA) on the curve, both canonical, sign bit; -A and B - A in cached form (the slot's carried columns)
   SETUP-B  H = qq l + hr, hr < l (the scalar whose bits the STEP rows consume); the accumulator starts at (0, 1, 1)
   FINAL    (xR Z, yR Z) = (X, Y): the result is the point whose compressed form is R; xR, yR canonical, sign bit.
-Unsigned slots run on all-zero bits (identity throughout) and touch no bus.
+Idle slots run on all-zero bits (identity throughout) and touch no bus.  Slots are COMPACT: slot s verifies the s-th chosen
+signature, whose authority index sits in the slot register AIDX (the prover needs only floor(2n/3) + 1 of the n authorities,
+so 2^16 rows = 256 slots serve an authority set of 300).
 Bus tuples (t0, t1, t2, t3, tag) carry 8 limbs as (index, l0 + 2^16 l1 + 2^32 l2, l3 + .., l6 + 2^16 l7):
-  TAG_KEY   (4 slot + j)      compressed A, quarters j = 0..3 (4 limbs: (index, l0 + 2^16 l1, l2 + 2^16 l3, 0))   received (sent by ShaChainAir for signed keys)
+  TAG_KEY   (4 AIDX + j)      compressed A, quarters j = 0..3 (4 limbs: (index, l0 + 2^16 l1, l2 + 2^16 l3, 0))   received (sent by ShaChainAir for signed keys)
   TAG_EDMSG (4 slot + part)   R halves (part 0, 1), A halves (2, 3)    sent     (the SHA-512 table's message words 0..7)
   TAG_EDH   (4 slot + j)      the digest as 32 little-endian limbs     received
 Public inputs: (number of signed slots, bus_on).  Constraint ORDER is protocol (0-kno-vectorx_amd/csrc/air_ed.cuh).
@@ -46,7 +48,7 @@ BX, BY = pyref._Bx, pyref._By
 NG = 14
 CELLS = NG * 48
 XA0, YA0, NT0, X30, Y30, BT0, HR0, SEL0 = 672, 688, 704, 720, 736, 752, 768, 784
-BS, BH, LAH, SG, CNT, MULT, COLS = 832, 833, 834, 835, 836, 837, 838
+BS, BH, LAH, SG, CNT, MULT, AIDX, COLS = 832, 833, 834, 835, 836, 837, 838, 839
 N_RANGE, N_BUS = CELLS // 2, 6
 HB0, HT, ZZ = N_RANGE, N_RANGE + N_BUS, N_RANGE + N_BUS + 1
 N_HELP = N_RANGE + N_BUS + 2
@@ -197,7 +199,7 @@ def bus_lookups(loc, per, pub):
         tk = (enc_a[4 * b] + enc_a[4 * b + 1] * 65536, enc_a[4 * b + 2] + enc_a[4 * b + 3] * 65536)
         m = on * (0 - r0 - r1)
         tag = r0 * TAG_KEY + r1 * TAG_EDH
-        out.append((m, tag, ((r0 + r1) * (slot * 4 + b), r0 * tk[0] + r1 * th[0], r0 * tk[1] + r1 * th[1], r1 * th[2])))
+        out.append((m, tag, (r0 * (loc[AIDX] * 4 + b) + r1 * (slot * 4 + b), r0 * tk[0] + r1 * th[0], r0 * tk[1] + r1 * th[1], r1 * th[2])))
     for b in range(2):
         ta, tr = pack8(enc_a, 8 * b), pack8(enc_r, 8 * b)
         m = on * (r0 + r255)
@@ -281,7 +283,7 @@ def eval(loc, nxt, per, pub, c, chal, aux_pub):  # noqa: A001
             c.constraint(finn * cy[k] * (cy[k] - 1))
     c.constraint(finn * (xr[0] - nxt[RH(2, 0)] * 2 - nxt[BS]))
     # ---- 6. slot registers, the addend selection, the scalar bits
-    for col in list(range(XA0, SEL0)) + [SG]:
+    for col in list(range(XA0, SEL0)) + [SG, AIDX]:
         c.constraint(keep * (nxt[col] - loc[col]))
     bs, bh = loc[BS], loc[BH]
     w11 = bs * bh
@@ -431,15 +433,15 @@ def _canon_cells(row, g, xs, top, col_of=None):
 
 
 def gen_trace(sigs, log_n, bus_on=1):
-    """sigs: per slot dict(A=32 B, R=32 B, S=int, H=64-byte digest, signed=bool) (missing slots are unsigned).
-    -> trace [COLS][n], public inputs [number signed, bus_on]."""
+    """sigs: the chosen signatures, one per slot: dict(A=32 B, R=32 B, S=int, H=64-byte digest, idx=authority index); the
+    remaining slots are idle.  -> trace [COLS][n], public inputs [number of signatures, bus_on]."""
     n = 1 << log_n
     m = n // 256
     assert log_n >= 16 and len(sigs) <= m
     tr = np.zeros((COLS, n), dtype=np.uint64)
     xa_v, ya_v, sa_v, xr_v, yr_v, sr_v, hh_v, s_v, sg_v = [], [], [], [], [], [], [], [], []
     for s in range(m):
-        sig = sigs[s] if s < len(sigs) and sigs[s]["signed"] else None
+        sig = sigs[s] if s < len(sigs) else None
         if sig is None:
             xa_v.append(BX), ya_v.append(BY), sa_v.append(BX & 1), xr_v.append(0), yr_v.append(1), sr_v.append(0), hh_v.append(0), s_v.append(0), sg_v.append(0)
             continue
@@ -575,6 +577,7 @@ def gen_trace(sigs, log_n, bus_on=1):
     for r, row in rows.items():
         row.v[XA0:SEL0] = carried
         row.v[SG], row.v[CNT] = sgn, cnt
+        row.v[AIDX] = np.array([sigs[q]["idx"] if q < len(sigs) else 0 for q in range(m)], dtype=np.int64)
         if r < 2 or r == 255:
             bs, bh = row.v[BS], row.v[BH]
             w11 = bs * bh

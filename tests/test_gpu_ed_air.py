@@ -23,7 +23,8 @@ def signatures(n, unsigned=(2,)):
         A, sg = pyref.ed25519_public(sec), pyref.ed25519_sign(sec, MSG)
         on = i not in unsigned
         keys.append(A), sigs.append(sg), flags.append(1 if on else 0)
-        recs.append(dict(A=A, R=sg[:32], S=int.from_bytes(sg[32:], "little"), H=hashlib.sha512(sg[:32] + A + MSG).digest(), signed=on))
+        if on:  # the tables' slots are compact: the s-th flagged authority, its index alongside
+            recs.append(dict(A=A, R=sg[:32], S=int.from_bytes(sg[32:], "little"), H=hashlib.sha512(sg[:32] + A + MSG).digest(), idx=i))
     return keys, sigs, flags, recs
 
 
@@ -55,28 +56,36 @@ def test_trace_aux_and_proof_match_oracle(ctx, vx):
 
 
 def test_300_signatures_full_size(ctx, vx):
-    just = vx.synth.Justification(100256, hashlib.blake2b(b"t", digest_size=32).digest())
+    th = hashlib.blake2b(b"t", digest_size=32).digest()
+    just = vx.synth.Justification(100256, th, n_signed=201)  # 2/3 of 300 (+1): what a header_range proof verifies -- 2^16 rows
     t0 = time.time()
-    buf, pub = ctx.ed_trace(just.pubkeys, just.signatures, just.precommit, just.signed, 17)
+    buf, pub = ctx.ed_trace(just.pubkeys, just.signatures, just.precommit, just.signed, 16)
     ctx.sync()
     t1 = time.time()
-    assert int(pub[0]) == sum(just.signed)
-    proof = ctx.stark_prove(E.IDS[17], buf, 17, pub)
+    assert int(pub[0]) == 201
+    proof = ctx.stark_prove(E.IDS[16], buf, 16, pub)
     t2 = time.time()
     print(f"ed trace {1e3 * (t1 - t0):.1f} ms, prove {1e3 * (t2 - t1):.1f} ms, proof {proof.size * 8 / 1e6:.2f} MB")
-    vx.lib.stark_verify(proof, expect_air=E.IDS[17], expect_public=pub)
+    vx.lib.stark_verify(proof, expect_air=E.IDS[16], expect_public=pub)
+    # every one of 300 authorities signed: 2^17 rows
+    full = vx.synth.Justification(100256, th)
+    b17, p17 = ctx.ed_trace(full.pubkeys, full.signatures, full.precommit, full.signed, 17)
+    assert int(p17[0]) == 300
+    vx.lib.stark_verify(ctx.stark_prove(E.IDS[17], b17, 17, p17), expect_air=E.IDS[17], expect_public=p17)
+    with pytest.raises(vx.VxError):  # ... and does not fit 2^16 rows
+        ctx.ed_trace(full.pubkeys, full.signatures, full.precommit, full.signed, 16)
     # a forged signature cannot be given a trace
     sigs = list(just.signatures)
     k = just.signed.index(1)
     sigs[k] = sigs[k][:40] + bytes([sigs[k][40] ^ 1]) + sigs[k][41:]
     with pytest.raises(vx.VxError) as e:
-        ctx.ed_trace(just.pubkeys, sigs, just.precommit, just.signed, 17)
+        ctx.ed_trace(just.pubkeys, sigs, just.precommit, just.signed, 16)
     assert e.value.code == -5  # VX_ERR_STATEMENT
     # ... but is ignored when its slot is not signed
     flags = list(just.signed)
     flags[k] = 0
-    _, pub2 = ctx.ed_trace(just.pubkeys, sigs, just.precommit, flags, 17)
-    assert int(pub2[0]) == sum(just.signed) - 1
+    _, pub2 = ctx.ed_trace(just.pubkeys, sigs, just.precommit, flags, 16)
+    assert int(pub2[0]) == 200
 
 
 def test_sha512_table_matches_oracle(ctx, vx):
@@ -85,7 +94,7 @@ def test_sha512_table_matches_oracle(ctx, vx):
     air = H.make_air(10)
     S.register_air(air)
     keys, sigs, flags, _ = signatures(5)
-    slots = [(sg[:32], k) if f else None for k, sg, f in zip(keys, sigs, flags)]
+    slots = [(sg[:32], k) for k, sg, f in zip(keys, sigs, flags) if f]
     for bus_on in (1, 0):
         buf, pub = ctx.sha512_trace(keys, sigs, MSG, flags, 10, bus_on=bus_on)
         want, wpub, dig = H.gen_trace(slots, MSG, 10, bus_on=bus_on)
@@ -108,7 +117,7 @@ def test_sha512_300_slots_and_bus_against_the_curve_table(ctx, vx):
     EdAir are the authority-set table's side and stay open here)."""
     from oracle import sha512_air as H
 
-    just = vx.synth.Justification(100256, hashlib.blake2b(b"t", digest_size=32).digest())
+    just = vx.synth.Justification(100256, hashlib.blake2b(b"t", digest_size=32).digest(), n_signed=201)
     t0 = time.time()
     hb, hpub = ctx.sha512_trace(just.pubkeys, just.signatures, just.precommit, just.signed, 16, bus_on=1)
     ctx.sync()
@@ -121,8 +130,8 @@ def test_sha512_300_slots_and_bus_against_the_curve_table(ctx, vx):
         vx.lib.stark_verify(proof, expect_air=H.IDS[16], expect_public=hpub)
     chal = [11, 13, 17, 19]
     _, apub_h = ctx.stark_aux_trace(H.IDS[16], hb, 16, chal, H.AUX, public_inputs=hpub)
-    eb, epub = ctx.ed_trace(just.pubkeys, just.signatures, just.precommit, just.signed, 17, bus_on=1)
-    aux_e, apub_e = ctx.stark_aux_trace(E.IDS[17], eb, 17, chal, E.AUX, public_inputs=epub)
+    eb, epub = ctx.ed_trace(just.pubkeys, just.signatures, just.precommit, just.signed, 16, bus_on=1)
+    aux_e, apub_e = ctx.stark_aux_trace(E.IDS[16], eb, 16, chal, E.AUX, public_inputs=epub)
     # the key receives alone, recomputed on the host from the keys
     P = E.P
     ExtS = S.ExtS
@@ -136,7 +145,7 @@ def test_sha512_300_slots_and_bus_against_the_curve_table(ctx, vx):
             for b in range(4):
                 d = beta + (4 * s + b) + gamma * (l[4 * b] + (l[4 * b + 1] << 16)) + g2 * (l[4 * b + 2] + (l[4 * b + 3] << 16)) + g4 * E.TAG_KEY
                 keys_total = keys_total + d.inv()
-    tot_e = ExtS(int(apub_e[0]), int(apub_e[1])) * (1 << 17)
+    tot_e = ExtS(int(apub_e[0]), int(apub_e[1])) * (1 << 16)
     tot_h = ExtS(int(apub_h[0]), int(apub_h[1])) * (1 << 16)
     rest = tot_e + tot_h + keys_total  # EdAir's total holds the key receives with a minus sign
     assert (rest.a, rest.b) == (0, 0)

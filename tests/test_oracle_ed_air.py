@@ -18,15 +18,17 @@ CHAL = [3, 5, 7, 11]
 
 
 def signatures(n, unsigned=(2,)):
+    """The chosen signatures of n authorities (authority `unsigned` did not sign): compact slots, authority index alongside."""
     sigs, slots = [], []
     for i in range(n):
+        if i in unsigned:
+            continue
         sec = bytes([i + 1]) * 32
         A = pyref.ed25519_public(sec)
         sg = pyref.ed25519_sign(sec, MSG)
         assert pyref.ed25519_verify(A, MSG, sg)
-        on = i not in unsigned
-        sigs.append(dict(A=A, R=sg[:32], S=int.from_bytes(sg[32:], "little"), H=hashlib.sha512(sg[:32] + A + MSG).digest(), signed=on))
-        slots.append((sg[:32], A) if on else None)
+        sigs.append(dict(A=A, R=sg[:32], S=int.from_bytes(sg[32:], "little"), H=hashlib.sha512(sg[:32] + A + MSG).digest(), idx=i))
+        slots.append((sg[:32], A))
     return sigs, slots
 
 
@@ -40,7 +42,7 @@ def ed():
 
 def test_ed_trace_satisfies_every_constraint(ed):
     assert ed["pub"] == [4, 1]
-    # the first 8 slots (5 real, one of them unsigned, 3 idle) and the wrap-around pair
+    # the first 8 slots (4 signatures, 4 idle) and the wrap-around pair
     assert S.check_trace(ed["air"], ed["tr"], ed["pub"], chal=CHAL, aux=ed["aux"], aux_pub=ed["apub"], rows=(0, 2048)) is None
     assert S.check_trace(ed["air"], ed["tr"], ed["pub"], chal=CHAL, aux=ed["aux"], aux_pub=ed["apub"], rows=(65536 - 300, 65536)) is None
 
@@ -49,8 +51,6 @@ def test_ed_result_is_the_signature_equation(ed):
     """Row 254's accumulator is [S]B - [h]A = R projectively (independent big-int arithmetic)."""
     tr = ed["tr"]
     for s, sig in enumerate(ed["sigs"]):
-        if not sig["signed"]:
-            continue
         val = lambda g: sum(int(tr[E.C(g, k), 256 * s + 254]) << (16 * k) for k in range(16)) % E.Q  # noqa: E731
         X, Y, Z = val(11), val(12), val(13)
         zi = pow(Z, E.Q - 2, E.Q)
@@ -70,8 +70,8 @@ def test_ed_forgeries_violate_a_constraint(ed, what):
     elif what == "h_limb":
         t2[E.C(0, 3), 257] ^= 1
     elif what == "claim_signed":
-        t2[E.SG, 512:768] = 1
-        rows = (500, 800)
+        t2[E.SG, 1024:1280] = 1  # an idle slot
+        rows = (1000, 1300)
     elif what == "carry":
         t2[E.RL(4, 5), 40] ^= 1
     else:
@@ -93,7 +93,7 @@ def test_sha512_table_and_its_forgeries():
     air = H.make_air(10)
     aux, apub = H.gen_aux(tr, CHAL, pub)
     assert S.check_trace(air, tr, pub, chal=CHAL, aux=aux, aux_pub=apub) is None
-    assert dig[0] == hashlib.sha512(slots[0][0] + slots[0][1] + MSG).digest() and dig[2] is None
+    assert dig[0] == hashlib.sha512(slots[0][0] + slots[0][1] + MSG).digest() and dig[4] is None
     for col, row in ((H.W0B + 5, 3), (H.W0B + 5, 161), (H.NA0 + 9, 40), (H.SGF, 170)):
         t2 = tr.copy()
         t2[col, row] ^= 1
@@ -132,5 +132,5 @@ def test_bus_between_the_two_tables_balances(ed):
         if per_s[H.P_RCV][i] or per_s[H.P_SND][i]:
             rows_s.append(H.bus_lookup([int(ts[j, i]) for j in range(H.COLS)], [v[i] for v in per_s], pubs))
     te, tsum = total(rows_e), total(rows_s)
-    assert keys == 16 and (te.a, te.b) != (0, 0)
+    assert keys == 16 and (te.a, te.b) != (0, 0)  # 4 signatures x 4 key quarters
     assert ((te + tsum).a, (te + tsum).b) == (0, 0)
