@@ -30,6 +30,9 @@ VX_HD constexpr int C(int g, int k) { return g * 48 + k; }
 VX_HD constexpr int RL(int g, int k) { return g * 48 + 16 + k; }
 VX_HD constexpr int RH(int g, int k) { return g * 48 + 32 + k; }
 VX_HD constexpr int AX(int e, int comp) { return COLS + 2 * e + comp; }
+// SETUP-B: cell of digest byte j (gadget 5, then gadget 6's c cells) and of 256 * byte j (gadget 6's rl / rh, gadget 7's c / rl)
+VX_HD constexpr int BYA(int j) { return j < 48 ? 5 * 48 + j : C(6, j - 48); }
+VX_HD constexpr int BYB(int j) { return j < 32 ? 6 * 48 + 16 + j : 7 * 48 + (j - 32); }
 // constant limb vectors: 2d, -2d, d, -d xB yB, xB, yB, the base point in cached form (y - x, y + x, 2d x y), q - 1, l - 1, l
 enum { K_2D, K_2DN, K_D, K_BD, K_XB, K_YB, K_BC0, K_BC1, K_BC2, K_QM1, K_LM1, K_LL, N_CONST };
 #define EDA_TABLE_INIT {EDA_K2D_INIT, EDA_K2DN_INIT, EDA_KD_INIT, EDA_KBD_INIT, EDA_XB_INIT, EDA_YB_INIT, EDA_BC0_INIT, EDA_BC1_INIT, EDA_BC2_INIT, \
@@ -303,6 +306,11 @@ struct EdAirT {
             for (int g = 11; g < 14; ++g)
 #pragma unroll 1
                 for (int k = 0; k < 16; ++k) c.constraint(s1n * (nxt[C(g, k)] - ((g > 11 && k == 0) ? one : zero)));
+            const F k8 = F::from(256);
+#pragma unroll 1
+            for (int j = 0; j < 64; ++j) c.constraint(s1n * (nxt[BYB(j)] - nxt[BYA(j)] * k8));  // b and 256 b are 16-bit cells: b is a byte
+#pragma unroll 1
+            for (int k = 0; k < 32; ++k) c.constraint(s1n * (hl(k) - nxt[BYA(2 * k)] - nxt[BYA(2 * k + 1)] * k8));  // H's limbs are byte pairs
         }
         // ---- 5. FINAL extras: canonical xR, yR, the sign bit
         canonical(finn, [&](int k) { return nxt[C(0, k)]; }, [&](int k) { return nxt[C(2, k)]; }, [&](int k) { return nxt[RL(2, k)]; }, K_QM1);
@@ -353,29 +361,36 @@ struct EdAirT {
             const F k32 = F::from(1ULL << 32);
             auto enc_a = [&](int k) -> F { return k < 15 ? loc[C(7, k)] : loc[C(7, 15)] + loc[BS] * F::from(32768); };
             auto enc_r = [&](int k) -> F { return k < 15 ? loc[C(1, k)] : loc[C(1, 15)] + loc[BS] * F::from(32768); };
-            auto hl = [&](int k) -> F { return k < 16 ? loc[C(0, k)] : loc[RL(0, k - 16)]; };
+            // half q of the digest (q = 2 word + (0 lo | 1 hi)): the big-endian sum of its four byte cells
+            auto dh = [&](int q) -> F {
+                if (q >= 16) return zero;
+                const int b0 = 8 * (q >> 1) + ((q & 1) ? 0 : 4);
+                return loc[BYA(b0)] * F::from(1ULL << 24) + loc[BYA(b0 + 1)] * k16 + loc[BYA(b0 + 2)] * F::from(256) + loc[BYA(b0 + 3)];
+            };
             auto p3 = [&](auto&& f, int i) -> F { return f(i) + f(i + 1) * k16 + f(i + 2) * k32; };
             auto p2 = [&](auto&& f, int i) -> F { return f(i) + f(i + 1) * k16; };
+            const F slot8 = per[P_SLOT] * F::from(8);
 #pragma unroll 1
             for (int b = 0; b < 4; ++b) {
                 const F m = on * (zero - r0 - r1);
                 const F tag = r0 * F::from(TAG_KEY) + r1 * F::from(TAG_EDH);
-                const F t0 = r0 * (loc[AIDX] * F::from(4) + F::from((uint64_t)b)) + r1 * (slot4 + F::from((uint64_t)b));
-                const F u1 = r0 * p2(enc_a, 4 * b) + r1 * p3(hl, 8 * b), u2 = r0 * p2(enc_a, 4 * b + 2) + r1 * p3(hl, 8 * b + 3), u3 = r1 * p2(hl, 8 * b + 6);
+                const F t0 = r0 * (loc[AIDX] * F::from(4) + F::from((uint64_t)b)) + r1 * (slot8 + F::from((uint64_t)b));
+                const F u1 = r0 * p2(enc_a, 4 * b) + r1 * dh(3 * b), u2 = r0 * p2(enc_a, 4 * b + 2) + r1 * dh(3 * b + 1), u3 = r1 * dh(3 * b + 2);
                 const X2<F> d = beta + t0 + gamma * u1 + g2 * u2 + g3 * u3 + g4 * tag;
                 const X2<F> h{loc[AX(HB0 + b, 0)], loc[AX(HB0 + b, 1)]};
                 c.constraint_x2(h * d - m);
                 hsum = hsum + h;
             }
 #pragma unroll 1
-            for (int b = 0; b < 2; ++b) {
-                const F m = on * (r0 + r255);
-                const F tag = (r0 + r255) * F::from(TAG_EDMSG);
-                const F t0 = r0 * (slot4 + F::from((uint64_t)(b + 2))) + r255 * (slot4 + F::from((uint64_t)b));
-                const F u1 = r0 * p3(enc_a, 8 * b) + r255 * p3(enc_r, 8 * b), u2 = r0 * p3(enc_a, 8 * b + 3) + r255 * p3(enc_r, 8 * b + 3);
-                const F u3 = r0 * p2(enc_a, 8 * b + 6) + r255 * p2(enc_r, 8 * b + 6);
+            for (int b = 4; b < 6; ++b) {
+                const F m = on * (r0 + r255 - r1);
+                const F tag = (r0 + r255) * F::from(TAG_EDMSG) + r1 * F::from(TAG_EDH);
+                const F t0 = r0 * (slot4 + F::from((uint64_t)(b - 2))) + r255 * (slot4 + F::from((uint64_t)(b - 4))) + r1 * (slot8 + F::from((uint64_t)b));
+                const int o = 8 * (b - 4);
+                const F u1 = r0 * p3(enc_a, o) + r255 * p3(enc_r, o) + r1 * dh(3 * b), u2 = r0 * p3(enc_a, o + 3) + r255 * p3(enc_r, o + 3) + r1 * dh(3 * b + 1);
+                const F u3 = r0 * p2(enc_a, o + 6) + r255 * p2(enc_r, o + 6) + r1 * dh(3 * b + 2);
                 const X2<F> d = beta + t0 + gamma * u1 + g2 * u2 + g3 * u3 + g4 * tag;
-                const X2<F> h{loc[AX(HB0 + 4 + b, 0)], loc[AX(HB0 + 4 + b, 1)]};
+                const X2<F> h{loc[AX(HB0 + b, 0)], loc[AX(HB0 + b, 1)]};
                 c.constraint_x2(h * d - m);
                 hsum = hsum + h;
             }

@@ -1,13 +1,14 @@
-// Sha512Air (AIR ids 11 / 13 for 2^16 / 2^10 rows): H_i = SHA-512(R_i || A_i || M) for every enabled slot -- the hash half
+// Sha512Air (AIR ids 11 / 14 / 13 for 2^16 / 2^15 / 2^10 rows): H_i = SHA-512(R_i || A_i || M) for every enabled slot -- the hash half
 // of the conditional EdDSA verifications of verify_simple_justification (/root/reference
 // circuits/builder/justification.rs:229-243 -> curta's EdDSA gadget, starkyx v1.0.0, not vendored; native mirror
 // circuits/input/mod.rs:241-247).  FIPS 180-4, one round per row; 64-bit words are split in 32-bit halves wherever
-// arithmetic happens.  A slot takes 164 rows: block 1 = R || A || M || 80 00.. (80 rows), block 2 = the constant length
-// block (80 rows, continues from block 1), 4 DIGEST rows whose window positions 0 / 1 hold digest words 2j / 2j+1 as bits.
-// Everything positional is a periodic column of full period.  Only words an XOR reads are bit columns (a, b, c, e, f, g,
-// new a, new e, window positions 0, 1, 14); Sigma0 / Sigma1 / Ch / Maj are degree-3 polynomials of those bits, sigma0 /
-// sigma1 have result + carry bits.  R || A arrives over the bus from EdAir (air_ed.cuh) at rows 0, 2, 4, 6 of block 1, the
-// digest goes back from the digest rows, 8 little-endian 16-bit limbs per tuple, under the slot's flag SGF.
+// arithmetic happens.  A slot takes 160 rows: block 1 = R || A || M || 80 00.. (80 rows), block 2 = the constant length
+// block (80 rows, continues from block 1).  Everything positional is a periodic column of full period.  Only words an
+// XOR reads are bit columns (a, b, c, e, f, g, new a, new e, window positions 0, 1, 14); Sigma0 / Sigma1 / Ch / Maj are degree-3 polynomials of those bits, sigma0 /
+// sigma1 have result + carry bits.  R || A arrives over the bus from EdAir (air_ed.cuh) at rows 0, 2, 4, 6 of block 1 (8
+// little-endian 16-bit limbs per tuple, cut from the bits of window positions 0 / 1); the digest goes back from rows 74..79
+// of block 2 as three 32-bit feed-forward halves per tuple (held in FFV from row 74 on; EdAir's byte cells bound them), all
+// under the slot's flag SGF.
 // Public inputs: message words 8..14 of block 1 as (lo, hi) halves, bus_on.  Constraint ORDER is protocol:
 // oracle/sha512_air.py restates it independently.
 #pragma once
@@ -22,8 +23,8 @@ constexpr int A_ = 0, B_ = 64, C_ = 128, E_ = 192, F_ = 256, G_ = 320, DV = 384,
 constexpr int W0B = 516, W1B = 580, W14B = 644, WV0 = 708, WV15 = 732;
 constexpr int S0R = 734, S0C = 798, S1R = 862, S1C = 926, CE0 = 990, CA0 = 996, CW0 = 1002;
 constexpr int FFV0 = 1006, FFC0 = 1022, HIN0 = 1038, SGF = 1054, COLS = 1055;
-constexpr int SLOT_ROWS = 164, MSG_LEN = 53;
-enum { P_B1, P_INB, P_SCHED, P_KLO, P_KHI, P_LAST, P_CONT, P_HSET, P_RCV, P_SND, P_T0, P_DG0, P_FFK = 15, P_SGK = 16, N_PERIODIC = 17 };
+constexpr int SLOT_ROWS = 160, SEND0 = 80 + 74, MSG_LEN = 53;
+enum { P_B1, P_INB, P_SCHED, P_KLO, P_KHI, P_LAST, P_CONT, P_HSET, P_RCV, P_T0, P_FFK, P_SGK, P_SD0, N_PERIODIC = 18 };
 VX_HD constexpr int WV(int p) { return p == 15 ? WV15 : WV0 + 2 * (p - 2); }
 VX_HD constexpr int st_bits(int wd) { return wd == 0 ? A_ : wd == 1 ? B_ : wd == 2 ? C_ : wd == 4 ? E_ : wd == 5 ? F_ : wd == 6 ? G_ : -1; }
 #define S5_IV_INIT {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL, \
@@ -63,12 +64,10 @@ struct Sha512AirT {
                 P(P_LAST, o + 79) = 1, P(P_HSET, o) = 1;
             }
             P(P_CONT, b + 79) = 1;
-            for (int j = 0; j < 4; ++j) {
-                P(P_RCV, b + 2 * j) = 1, P(P_T0, b + 2 * j) = 4 * s + j;
-                P(P_SND, b + 160 + j) = 1, P(P_T0, b + 160 + j) = 4 * s + j, P(P_DG0 + j, b + 160 + j) = 1;
-            }
-            for (size_t r = b + 159; r < b + 163; ++r) P(P_FFK, r) = 1;
-            for (size_t r = b; r < b + 163; ++r) P(P_SGK, r) = 1;
+            for (int j = 0; j < 4; ++j) P(P_RCV, b + 2 * j) = 1, P(P_T0, b + 2 * j) = 4 * s + j;
+            for (int j = 0; j < 6; ++j) P(P_SD0 + j, b + SEND0 + j) = 1, P(P_T0, b + SEND0 + j) = 8 * s + j;
+            for (size_t r = b + SEND0; r < b + SEND0 + 5; ++r) P(P_FFK, r) = 1;
+            for (size_t r = b; r < b + 159; ++r) P(P_SGK, r) = 1;
         }
     }
 
@@ -220,35 +219,31 @@ struct Sha512AirT {
         for (int p = 0; p < 16; ++p)
 #pragma unroll 1
             for (int h = 0; h < 2; ++h) c.constraint(cont * (window(nxt, p, h) - F::from((pad2(p) >> (32 * h)) & 0xFFFFFFFFULL)));
-        // ---- 9. digest rows: window positions 0 / 1 hold the digest words 2j / 2j+1; FF and the slot flag are kept
-#pragma unroll 1
-        for (int h = 0; h < 2; ++h) {
-            const F w0 = val(loc, W0B + 32 * h, 32), w1 = val(loc, W1B + 32 * h, 32);
-            F acc0 = zero, acc1 = zero;
-#pragma unroll 1
-            for (int j = 0; j < 4; ++j) {
-                acc0 = acc0 + per[P_DG0 + j] * (w0 - loc[FFV0 + 4 * j + h]);
-                acc1 = acc1 + per[P_DG0 + j] * (w1 - loc[FFV0 + 4 * j + 2 + h]);
-            }
-            c.constraint(acc0);
-            c.constraint(acc1);
-        }
+        // ---- 9. the digest is held from row 74 of block 2 on (it is sent from there); the slot flag is kept
 #pragma unroll 1
         for (int k = 0; k < 16; ++k) c.constraint(per[P_FFK] * (nxt[FFV0 + k] - loc[FFV0 + k]));
         c.constraint(per[P_SGK] * (nxt[SGF] - loc[SGF]));
-        // ---- 10. the bus: 8 limbs of the words at window positions 0 and 1 (limb j of a word = bytes 2j, 2j+1 of its
-        // big-endian byte string, little-endian)
+        // ---- 10. the bus: receive rows take 8 limbs of the words at window positions 0 and 1 (limb j of a word = bytes 2j, 2j+1
+        // of its big-endian byte string, little-endian); send row j gives the feed-forward halves 3j, 3j+1, 3j+2
         {
             const X2<F> beta{chal[0], chal[1]}, gamma{chal[2], chal[3]}, g2 = gamma * gamma, g3 = g2 * gamma, g4 = g2 * g2;
-            const F k8 = F::from(256), k16 = F::from(65536), k32 = F::from(1ULL << 32);
+            const F k8 = F::from(256), k16 = F::from(65536), k32 = F::from(1ULL << 32), rcv = per[P_RCV];
             auto limb = [&](int q) -> F {  // q = 0..7: limbs of W0 then W1
                 const int col0 = (q < 4 ? W0B : W1B), j = q & 3;
                 return val(loc, col0 + 56 - 16 * j, 8) + val(loc, col0 + 48 - 16 * j, 8) * k8;
             };
-            const F t1 = limb(0) + limb(1) * k16 + limb(2) * k32, t2 = limb(3) + limb(4) * k16 + limb(5) * k32, t3 = limb(6) + limb(7) * k16;
-            const F m = loc[SGF] * pub[14] * (per[P_SND] - per[P_RCV]);
-            const F tag = per[P_SND] * F::from(edc::TAG_EDH) + per[P_RCV] * F::from(edc::TAG_EDMSG);
-            const X2<F> d = beta + per[P_T0] + gamma * t1 + g2 * t2 + g3 * t3 + g4 * tag;
+            F t[3] = {rcv * (limb(0) + limb(1) * k16 + limb(2) * k32), rcv * (limb(3) + limb(4) * k16 + limb(5) * k32), rcv * (limb(6) + limb(7) * k16)};
+            F snd = zero;
+#pragma unroll 1
+            for (int i = 0; i < 3; ++i)
+#pragma unroll 1
+                for (int j = 0; j < 6; ++j)
+                    if (3 * j + i < 16) t[i] = t[i] + per[P_SD0 + j] * loc[FFV0 + 3 * j + i];
+#pragma unroll 1
+            for (int j = 0; j < 6; ++j) snd = snd + per[P_SD0 + j];
+            const F m = loc[SGF] * pub[14] * (snd - rcv);
+            const F tag = snd * F::from(edc::TAG_EDH) + rcv * F::from(edc::TAG_EDMSG);
+            const X2<F> d = beta + per[P_T0] + gamma * t[0] + g2 * t[1] + g3 * t[2] + g4 * tag;
             const X2<F> h{loc[COLS], loc[COLS + 1]}, z{loc[COLS + 2], loc[COLS + 3]}, zn{nxt[COLS + 2], nxt[COLS + 3]};
             c.constraint_x2(h * d - m);
             c.constraint_x2(zn - z - h + X2<F>{apub[0], apub[1]});
@@ -256,4 +251,5 @@ struct Sha512AirT {
     }
 };
 using Sha512Air16 = Sha512AirT<16, 11>;
+using Sha512Air15 = Sha512AirT<15, 14>;
 using Sha512Air10 = Sha512AirT<10, 13>;

@@ -661,8 +661,8 @@ static int tree_log_n(uint32_t max_headers) {
 static size_t sig_quorum(size_t n_auth) { return 2 * n_auth / 3 + 1; }
 static int ed_log_n(size_t n_sig) { return n_sig <= 255 ? 16 : 17; }
 static int ed_air_id(size_t n_sig) { return n_sig <= 255 ? VX_AIR_ED25519_16 : VX_AIR_ED25519; }
-static int s512_log_n(size_t n_sig) { return n_sig <= 6 ? 10 : 16; }
-static int s512_air_id(size_t n_sig) { return n_sig <= 6 ? VX_AIR_SHA512_10 : VX_AIR_SHA512; }
+static int s512_log_n(size_t n_sig) { return n_sig <= 6 ? 10 : n_sig <= 204 ? 15 : 16; }
+static int s512_air_id(size_t n_sig) { return n_sig <= 6 ? VX_AIR_SHA512_10 : n_sig <= 204 ? VX_AIR_SHA512_15 : VX_AIR_SHA512; }
 
 int32_t vx_header_range_proof_bound(const vx_stark_config* cfg, size_t n_chunks, size_t n_authorities, size_t* n_words) {
     if (!cfg || !n_words || n_chunks == 0) return VX_ERR_ARG;

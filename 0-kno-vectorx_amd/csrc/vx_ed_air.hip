@@ -25,6 +25,7 @@ struct EdSlot {
     int32_t wxa[16], wya[16], wxr[16], wyr[16];  // q - 1 - x
     int32_t hl[32], qq[17], hr[16], hw[16], crlo[32], crhi[32];
     uint8_t cxa[16], cya[16], cxr[16], cyr[16], chr[16];  // carries of x + w = top (15 used)
+    uint8_t dig[64];                                       // the SHA-512 digest H
     uint32_t s[8], h[8];                                   // the scalars whose bits the STEP rows consume
     uint32_t sign_a, sign_r, sg, cnt, aidx, pad;
 };
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(64) void k_ed_slots(const uint8_t* pubkeys, const u
         }
     }
     for (int j = 0; j < 8; ++j) o.h[j] = r[j];
+    for (int j = 0; j < 64; ++j) o.dig[j] = dig[j];
     for (int j = 0; j < 32; ++j) o.hl[j] = (int32_t)dig[2 * j] | ((int32_t)dig[2 * j + 1] << 8);
     for (int j = 0; j < 17; ++j) o.qq[j] = (q[j >> 1] >> (16 * (j & 1))) & 0xFFFF;
     for (int j = 0; j < 16; ++j) o.hr[j] = (r[j >> 1] >> (16 * (j & 1))) & 0xFFFF;
@@ -234,6 +236,7 @@ __global__ __launch_bounds__(64) void k_ed_rows(const EdSlot* slots, int32_t* st
     row[C(2, k)] = in.crlo[k], row[RL(2, k)] = in.crlo[16 + k], row[C(3, k)] = in.crhi[k], row[RL(3, k)] = in.crhi[16 + k];
     if (k < 15) row[C(4, k)] = in.chr[k];
     if (k == 0) row[C(1, 0)] = in.qq[16], row[C(12, 0)] = 1, row[C(13, 0)] = 1;
+    for (int j = k; j < 64; j += 16) row[BYA(j)] = in.dig[j], row[BYB(j)] = 256 * (int32_t)in.dig[j];  // (cell columns are congruent to j mod 16)
     registers(0, 0, 0);
     // ---- rows 2..254: STEP
     int32_t X = 0, Y = one_k, Z = one_k, lah = 0;
@@ -324,7 +327,6 @@ __global__ __launch_bounds__(256) void k_ed_aux(EdAuxArgs a) {
         const gl2 g2 = gl2_mul(a.gamma, a.gamma), g3 = gl2_mul(g2, a.gamma), g4 = gl2_mul(g2, g2);
         const uint64_t slot4 = 4 * (uint64_t)(i >> 8), sign = T(BS), aidx4 = 4 * T(AIDX);
         auto enc = [&](int g, int k) -> uint64_t { return k < 15 ? T(C(g, k)) : T(C(g, 15)) + 32768 * sign; };
-        auto hl = [&](int k) -> uint64_t { return k < 16 ? T(C(0, k)) : T(RL(0, k - 16)); };
         auto fp = [&](uint64_t t0, uint64_t t1, uint64_t t2, uint64_t t3, int tag) -> gl2 {
             gl2 d = gl2_add(a.beta, gl2_add(gl2_scale(a.gamma, t1), gl2_add(gl2_scale(g2, t2), gl2_add(gl2_scale(g3, t3), gl2_scale(g4, (uint64_t)tag)))));
             d.a = gl_add(d.a, t0);
@@ -338,9 +340,12 @@ __global__ __launch_bounds__(256) void k_ed_aux(EdAuxArgs a) {
                 hb[4 + b] = gl2_inv(fp(slot4 + b + 2, enc(7, 8 * b) | (enc(7, 8 * b + 1) << 16) | (enc(7, 8 * b + 2) << 32),
                                        enc(7, 8 * b + 3) | (enc(7, 8 * b + 4) << 16) | (enc(7, 8 * b + 5) << 32), enc(7, 8 * b + 6) | (enc(7, 8 * b + 7) << 16), TAG_EDMSG));
         } else if (r == 1) {
-            for (int b = 0; b < 4; ++b)
-                hb[b] = neg(gl2_inv(fp(slot4 + b, hl(8 * b) | (hl(8 * b + 1) << 16) | (hl(8 * b + 2) << 32), hl(8 * b + 3) | (hl(8 * b + 4) << 16) | (hl(8 * b + 5) << 32),
-                                       hl(8 * b + 6) | (hl(8 * b + 7) << 16), TAG_EDH)));
+            auto dh = [&](int q) -> uint64_t {  // half q of the digest: big-endian sum of four byte cells
+                if (q >= 16) return 0;
+                const int b0 = 8 * (q >> 1) + ((q & 1) ? 0 : 4);
+                return (T(BYA(b0)) << 24) | (T(BYA(b0 + 1)) << 16) | (T(BYA(b0 + 2)) << 8) | T(BYA(b0 + 3));
+            };
+            for (int b = 0; b < 6; ++b) hb[b] = neg(gl2_inv(fp(2 * slot4 + b, dh(3 * b), dh(3 * b + 1), dh(3 * b + 2), TAG_EDH)));
         } else {
             for (int b = 0; b < 2; ++b)
                 hb[4 + b] = gl2_inv(fp(slot4 + b, enc(1, 8 * b) | (enc(1, 8 * b + 1) << 16) | (enc(1, 8 * b + 2) << 32),

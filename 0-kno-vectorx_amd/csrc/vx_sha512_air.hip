@@ -84,16 +84,6 @@ __global__ __launch_bounds__(256) void k_s512_rows(const S5Slot* slots, size_t m
     }
     const S5Slot& sl = slots[slot];
     tr[(size_t)SGF * n + row] = sl.sg;
-    if (q >= 160) {  // digest row j: an all-zero state, the digest words 2j / 2j+1 in window positions 0 / 1
-        const int j = q - 160;
-        const uint64_t w0 = sl.out[2 * j], w1 = sl.out[2 * j + 1];
-        for (int col = 0; col < SGF; ++col) tr[(size_t)col * n + row] = 0;
-        put_bits(tr, n, row, W0B, w0), put_bits(tr, n, row, W1B, w1);
-        put_bits(tr, n, row, NE0, w0), put_bits(tr, n, row, NA0, w0);  // the local round equation: NE = NA = 0 + .. + w_0
-        put_xor3(tr, n, row, rr(w1, 1), rr(w1, 8), w1 >> 7, S0R, S0C);
-        for (int wd = 0; wd < 8; ++wd) put_halves(tr, n, row, FFV0 + 2 * wd, sl.out[wd]);
-        return;
-    }
     const int blk = q / 80, r = q % 80;
     uint64_t w[96], s[8], h_in[8];
     for (int i = 0; i < 16; ++i) w[i] = blk ? pad2(i) : sl.blk1[i];
@@ -136,7 +126,7 @@ __global__ __launch_bounds__(256) void k_s512_rows(const S5Slot* slots, size_t m
         if (r == 79) {
             const uint64_t t2[2] = {h_in[wd], s80[wd]};
             add_halves(t2, 2, c_lo, c_hi, ff);
-        }
+        } else if (blk && r >= 74) ff = sl.out[wd];  // the digest is held (and sent) from row 74 of block 2 on
         put_halves(tr, n, row, FFV0 + 2 * wd, ff);
         tr[(size_t)(FFC0 + 2 * wd) * n + row] = c_lo, tr[(size_t)(FFC0 + 2 * wd + 1) * n + row] = c_hi;
         put_halves(tr, n, row, HIN0 + 2 * wd, h_in[wd]);
@@ -148,23 +138,30 @@ __global__ __launch_bounds__(256) void k_s512_aux(const uint64_t* tr, uint64_t* 
     if (row >= n) return;
     const size_t slot = row / SLOT_ROWS;
     const int q = (int)(row % SLOT_ROWS);
-    const bool rcv = slot < m && q < 8 && !(q & 1), snd = slot < m && q >= 160;
+    const bool rcv = slot < m && q < 8 && !(q & 1), snd = slot < m && q >= SEND0;
     gl2 h{0, 0};
     if ((rcv || snd) && bus_on && tr[(size_t)SGF * n + row]) {
-        auto word = [&](int col0) -> uint64_t {
-            uint64_t v = 0;
-            for (int i = 0; i < 64; ++i) v |= tr[(size_t)(col0 + i) * n + row] << i;
-            return v;
-        };
-        const uint64_t w[2] = {word(W0B), word(W1B)};
-        uint64_t l[8];
-        for (int j = 0; j < 8; ++j) {  // limb j of a word: bytes 2j, 2j+1 of its big-endian byte string, little-endian
-            const uint64_t x = w[j >> 2];
-            const int k = j & 3;
-            l[j] = ((x >> (56 - 16 * k)) & 0xFF) | (((x >> (48 - 16 * k)) & 0xFF) << 8);
+        uint64_t t0, t1, t2, t3;
+        if (rcv) {
+            auto word = [&](int col0) -> uint64_t {
+                uint64_t v = 0;
+                for (int i = 0; i < 64; ++i) v |= tr[(size_t)(col0 + i) * n + row] << i;
+                return v;
+            };
+            const uint64_t w[2] = {word(W0B), word(W1B)};
+            uint64_t l[8];
+            for (int j = 0; j < 8; ++j) {  // limb j of a word: bytes 2j, 2j+1 of its big-endian byte string, little-endian
+                const uint64_t x = w[j >> 2];
+                const int k = j & 3;
+                l[j] = ((x >> (56 - 16 * k)) & 0xFF) | (((x >> (48 - 16 * k)) & 0xFF) << 8);
+            }
+            t0 = 4 * slot + q / 2, t1 = l[0] | (l[1] << 16) | (l[2] << 32), t2 = l[3] | (l[4] << 16) | (l[5] << 32), t3 = l[6] | (l[7] << 16);
+        } else {
+            const int j = q - SEND0;
+            auto ff = [&](int k) -> uint64_t { return k < 16 ? tr[(size_t)(FFV0 + k) * n + row] : 0; };
+            t0 = 8 * slot + j, t1 = ff(3 * j), t2 = ff(3 * j + 1), t3 = ff(3 * j + 2);
         }
         const gl2 g2 = gl2_mul(gamma, gamma), g3 = gl2_mul(g2, gamma), g4 = gl2_mul(g2, g2);
-        const uint64_t t0 = 4 * slot + (rcv ? q / 2 : q - 160), t1 = l[0] | (l[1] << 16) | (l[2] << 32), t2 = l[3] | (l[4] << 16) | (l[5] << 32), t3 = l[6] | (l[7] << 16);
         gl2 d = gl2_add(beta, gl2_add(gl2_scale(gamma, t1), gl2_add(gl2_scale(g2, t2), gl2_add(gl2_scale(g3, t3), gl2_scale(g4, snd ? edc::TAG_EDH : edc::TAG_EDMSG)))));
         d.a = gl_add(d.a, t0);
         h = gl2_inv(d);

@@ -372,7 +372,7 @@ static const AirDesc AIRS[] = {
     desc<ShaTreeAir256>(ShaTreeAir256::periodic_values, vx_sha_tree_gen_aux_256), desc<ShaTreeAir512>(ShaTreeAir512::periodic_values, vx_sha_tree_gen_aux_512),
     desc<ShaTreeAir16>(ShaTreeAir16::periodic_values, vx_sha_tree_gen_aux_16),
     desc<EdAir17>(EdAir17::periodic_values, vx_ed_air_gen_aux), desc<EdAir16>(EdAir16::periodic_values, vx_ed_air_gen_aux),
-    desc<Sha512Air16>(Sha512Air16::periodic_values, vx_sha512_air_gen_aux), desc<Sha512Air10>(Sha512Air10::periodic_values, vx_sha512_air_gen_aux),
+    desc<Sha512Air16>(Sha512Air16::periodic_values, vx_sha512_air_gen_aux), desc<Sha512Air10>(Sha512Air10::periodic_values, vx_sha512_air_gen_aux), desc<Sha512Air15>(Sha512Air15::periodic_values, vx_sha512_air_gen_aux),
 };
 static const AirDesc* find_air(int id) {
     for (const AirDesc& d : AIRS)

@@ -171,7 +171,7 @@ void v_lookup_periodic(std::vector<uint64_t>& v) {
 const AirV V_AIRS[] = {
     vdesc<ShaAir>(ShaAir::periodic_values), vdesc<FibAir>(v_no_periodic), vdesc<MixAir>(v_mix_periodic), vdesc<BlakeAir>(v_blake_periodic),
     vdesc<LookupAir>(v_lookup_periodic), vdesc<ShaTreeAir256>(ShaTreeAir256::periodic_values), vdesc<ShaTreeAir512>(ShaTreeAir512::periodic_values),
-    vdesc<ShaTreeAir16>(ShaTreeAir16::periodic_values), vdesc<EdAir17>(EdAir17::periodic_values), vdesc<EdAir16>(EdAir16::periodic_values), vdesc<Sha512Air16>(Sha512Air16::periodic_values), vdesc<Sha512Air10>(Sha512Air10::periodic_values),
+    vdesc<ShaTreeAir16>(ShaTreeAir16::periodic_values), vdesc<EdAir17>(EdAir17::periodic_values), vdesc<EdAir16>(EdAir16::periodic_values), vdesc<Sha512Air16>(Sha512Air16::periodic_values), vdesc<Sha512Air10>(Sha512Air10::periodic_values), vdesc<Sha512Air15>(Sha512Air15::periodic_values),
 };
 size_t brev(size_t x, int bits) {
     size_t r = 0;
@@ -537,7 +537,7 @@ int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob,
         spub[8] = n_auth, spub[9] = 1;
         epub[0] = n_signed, epub[1] = 1;
         air[3] = n_signed <= 255 ? VX_AIR_ED25519_16 : VX_AIR_ED25519;  // the tables are sized by the number of signatures they verify
-        air[4] = n_signed <= 6 ? VX_AIR_SHA512_10 : VX_AIR_SHA512;
+        air[4] = n_signed <= 6 ? VX_AIR_SHA512_10 : n_signed <= 204 ? VX_AIR_SHA512_15 : VX_AIR_SHA512;
         // the signed message: the precommit for (target header hash, target block, round, set id) -- decoder.rs:159-200
         uint8_t msg[64];
         memset(msg, 0, sizeof msg);

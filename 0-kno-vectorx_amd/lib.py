@@ -36,7 +36,7 @@ VX_AIR_SHA_TREE = {256: 7, 512: 8, 16: 9}
 VX_AIR_SHA_CHAIN, VX_SHA_AIR_COLS, VX_SHA_AIR_AUX_COLS, VX_SHA_TREE_AIR_COLS = 4, 733, 4, 731
 VX_AIR_ED25519 = {17: 10, 16: 12}
 VX_ED_AIR_COLS, VX_ED_AIR_AUX_COLS = 839, 688
-VX_AIR_SHA512 = {16: 11, 10: 13}
+VX_AIR_SHA512 = {16: 11, 15: 14, 10: 13}
 VX_SHA512_AIR_COLS, VX_SHA512_AIR_AUX_COLS = 1055, 4
 
 

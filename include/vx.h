@@ -239,10 +239,11 @@ int32_t vx_ed_trace(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* signatur
                     size_t n_signatures, int log_n, uint32_t bus_on, vx_buf* trace_out, uint64_t public_inputs_out[2]);
 
 /* ---- K8: Sha512Air trace generation (the hash half of the same verifications): H_i = SHA-512(R_i || A_i || message) for
- * every signed slot, 164 rows per slot (2^16 rows hold 399 slots).  Writes the 1055-column trace and the 15 public
- * inputs (message words 8..14 of the first block as (lo, hi) halves, bus_on).  message_len must be 53 (the precommit).
- * Prove with vx_stark_prove(ctx, VX_AIR_SHA512 (2^16 rows) or VX_AIR_SHA512_10 (2^10 rows), ...). */
-enum { VX_AIR_SHA512 = 11, VX_AIR_SHA512_10 = 13, VX_SHA512_AIR_COLS = 1055, VX_SHA512_AIR_AUX_COLS = 4 };
+ * every flagged authority, in compact slots of 160 rows in EdAir's order (2^15 rows hold 204 slots).  Writes the
+ * 1055-column trace and the 15 public inputs (message words 8..14 of the first block as (lo, hi) halves, bus_on).
+ * message_len must be 53 (the precommit).  Prove with vx_stark_prove(ctx, VX_AIR_SHA512 (2^16 rows), VX_AIR_SHA512_15
+ * (2^15) or VX_AIR_SHA512_10 (2^10), ...). */
+enum { VX_AIR_SHA512 = 11, VX_AIR_SHA512_10 = 13, VX_AIR_SHA512_15 = 14, VX_SHA512_AIR_COLS = 1055, VX_SHA512_AIR_AUX_COLS = 4 };
 int32_t vx_sha512_trace(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* signatures, const uint8_t* message, uint32_t message_len, const uint8_t* signed_flags,
                         size_t n_signatures, int log_n, uint32_t bus_on, vx_buf* trace_out, uint64_t public_inputs_out[15]);
 

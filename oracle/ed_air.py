@@ -21,7 +21,8 @@ A slot is 256 rows:  row 0 SETUP-A, row 1 SETUP-B, rows 2..254 STEP (scalar bit 
          g0 X^2  g1 Y^2  g2 Z^2  g3 (X+Y)^2 | E = g3-g0-g1, G = g1-g0, F = G-2 g2, H = -g0-g1 | g4 E F  g5 G H  g6 E H  g7 F G
          g8 (g5-g4) ym  g9 (g5+g4) yp  g10 g6 t2d | D = 2 g7, E' = g9-g8, F' = D-g10, G' = D+g10, H' = g9+g8 | g11 E'F'  g12 G'H'  g13 F'G'
   SETUP-A  A = (xA, yA) on the curve, both canonical, sign bit; -A and B - A in cached form (the slot's carried columns)
-  SETUP-B  H = qq l + hr, hr < l (the scalar whose bits the STEP rows consume); the accumulator starts at (0, 1, 1)
+  SETUP-B  H = qq l + hr, hr < l (the scalar whose bits the STEP rows consume), H's limbs re-cut from the digest bytes;
+           the accumulator starts at (0, 1, 1)
   FINAL    (xR Z, yR Z) = (X, Y): the result is the point whose compressed form is R; xR, yR canonical, sign bit.
 Idle slots run on all-zero bits (identity throughout) and touch no bus.  Slots are COMPACT: slot s verifies the s-th chosen
 signature, whose authority index sits in the slot register AIDX (the prover needs only floor(2n/3) + 1 of the n authorities,
@@ -29,7 +30,8 @@ so 2^16 rows = 256 slots serve an authority set of 300).
 Bus tuples (t0, t1, t2, t3, tag) carry 8 limbs as (index, l0 + 2^16 l1 + 2^32 l2, l3 + .., l6 + 2^16 l7):
   TAG_KEY   (4 AIDX + j)      compressed A, quarters j = 0..3 (4 limbs: (index, l0 + 2^16 l1, l2 + 2^16 l3, 0))   received (sent by ShaChainAir for signed keys)
   TAG_EDMSG (4 slot + part)   R halves (part 0, 1), A halves (2, 3)    sent     (the SHA-512 table's message words 0..7)
-  TAG_EDH   (4 slot + j)      the digest as 32 little-endian limbs     received
+  TAG_EDH   (8 slot + j)      the digest, three 32-bit halves per tuple (word 0 lo, word 0 hi, word 1 lo, ..), j = 0..5   received --
+                              as big-endian sums of the 64 digest BYTES, which SETUP-B holds in range-checked cells (b and 256 b)
 Public inputs: (number of signed slots, bus_on).  Constraint ORDER is protocol (0-kno-vectorx_amd/csrc/air_ed.cuh).
 """
 import numpy as np
@@ -84,6 +86,16 @@ def RL(g, k):
 
 def RH(g, k):
     return g * 48 + 32 + k
+
+
+def BYA(j):
+    """Cell of digest byte j (SETUP-B): gadget 5 holds bytes 0..47, gadget 6's c cells bytes 48..63."""
+    return 5 * 48 + j if j < 48 else C(6, j - 48)
+
+
+def BYB(j):
+    """Cell of 256 * (digest byte j): gadget 6's rl / rh cells, then gadget 7's c / rl cells."""
+    return 6 * 48 + 16 + j if j < 32 else 7 * 48 + (j - 32)
 
 
 def period_logs(L):
@@ -184,28 +196,35 @@ def pack8(l, i):
     return l[i] + l[i + 1] * (1 << 16) + l[i + 2] * (1 << 32), l[i + 3] + l[i + 4] * (1 << 16) + l[i + 5] * (1 << 32), l[i + 6] + l[i + 7] * (1 << 16)
 
 
+def digest_half(loc, q):
+    """Half q of the digest (q = 2 word + (0 lo | 1 hi)) as the big-endian sum of its four byte cells."""
+    b0 = 8 * (q // 2) + (0 if q % 2 else 4)
+    return loc[BYA(b0)] * (1 << 24) + loc[BYA(b0 + 1)] * (1 << 16) + loc[BYA(b0 + 2)] * 256 + loc[BYA(b0 + 3)]
+
+
 def bus_lookups(loc, per, pub):
     """The six bus lookups of the local row: (multiplicity, tag, (t0, t1, t2, t3)), every entry of degree <= 2.
-    Helpers 0..3: row 0 receives key quarter b (4 limbs), row 1 receives digest part b (8 limbs);
-    helpers 4, 5: row 0 sends A half b - 4 (message parts 2, 3), row 255 sends R half b - 4 (parts 0, 1)."""
+    Row 1 receives the digest on all six (three 32-bit halves each); row 0 receives the four key quarters on helpers 0..3
+    and sends the A halves (message parts 2, 3) on helpers 4, 5; row 255 sends the R halves (parts 0, 1) on helpers 4, 5."""
     r0, r1, r255, slot = per[P_R0], per[P_R1], per[P_R255], per[P_SLOT]
     on = loc[SG] * pub[1]
     enc_a = [loc[C(7, k)] for k in range(15)] + [loc[C(7, 15)] + loc[BS] * 32768]
     enc_r = [loc[C(1, k)] for k in range(15)] + [loc[C(1, 15)] + loc[BS] * 32768]
-    hl = [loc[C(0, k)] for k in range(16)] + [loc[RL(0, k)] for k in range(16)]
     out = []
-    for b in range(4):
-        th = pack8(hl, 8 * b)
-        tk = (enc_a[4 * b] + enc_a[4 * b + 1] * 65536, enc_a[4 * b + 2] + enc_a[4 * b + 3] * 65536)
-        m = on * (0 - r0 - r1)
-        tag = r0 * TAG_KEY + r1 * TAG_EDH
-        out.append((m, tag, (r0 * (loc[AIDX] * 4 + b) + r1 * (slot * 4 + b), r0 * tk[0] + r1 * th[0], r0 * tk[1] + r1 * th[1], r1 * th[2])))
-    for b in range(2):
-        ta, tr = pack8(enc_a, 8 * b), pack8(enc_r, 8 * b)
-        m = on * (r0 + r255)
-        tag = (r0 + r255) * TAG_EDMSG
-        t0 = r0 * (slot * 4 + b + 2) + r255 * (slot * 4 + b)
-        out.append((m, tag, (t0, r0 * ta[0] + r255 * tr[0], r0 * ta[1] + r255 * tr[1], r0 * ta[2] + r255 * tr[2])))
+    for b in range(6):
+        th = [digest_half(loc, 3 * b + i) if 3 * b + i < 16 else 0 for i in range(3)]
+        if b < 4:
+            tk = (enc_a[4 * b] + enc_a[4 * b + 1] * 65536, enc_a[4 * b + 2] + enc_a[4 * b + 3] * 65536)
+            m = on * (0 - r0 - r1)
+            tag = r0 * TAG_KEY + r1 * TAG_EDH
+            tup = (r0 * (loc[AIDX] * 4 + b) + r1 * (slot * 8 + b), r0 * tk[0] + r1 * th[0], r0 * tk[1] + r1 * th[1], r1 * th[2])
+        else:
+            ta, tr = pack8(enc_a, 8 * (b - 4)), pack8(enc_r, 8 * (b - 4))
+            m = on * (r0 + r255 - r1)
+            tag = (r0 + r255) * TAG_EDMSG + r1 * TAG_EDH
+            t0 = r0 * (slot * 4 + b - 2) + r255 * (slot * 4 + b - 4) + r1 * (slot * 8 + b)
+            tup = (t0, r0 * ta[0] + r255 * tr[0] + r1 * th[0], r0 * ta[1] + r255 * tr[1] + r1 * th[1], r0 * ta[2] + r255 * tr[2] + r1 * th[2])
+        out.append((m, tag, tup))
     return out
 
 
@@ -273,6 +292,10 @@ def eval(loc, nxt, per, pub, c, chal, aux_pub):  # noqa: A001
     for g, want in ((11, [0] * 16), (12, ONE), (13, ONE)):
         for k in range(16):
             c.constraint(s1n * (nxt[C(g, k)] - want[k]))
+    for j in range(64):  # the digest bytes: b and 256 b are both 16-bit cells, so b is a byte
+        c.constraint(s1n * (nxt[BYB(j)] - nxt[BYA(j)] * 256))
+    for k in range(32):  # H's little-endian 16-bit limbs are pairs of digest bytes
+        c.constraint(s1n * (hl[k] - nxt[BYA(2 * k)] - nxt[BYA(2 * k + 1)] * 256))
     # ---- 5. FINAL extras: canonical xR, yR, the sign bit
     xr, yr = cells(nxt, 0), cells(nxt, 1)
     for x, g in ((xr, 2), (yr, 3)):
@@ -495,6 +518,9 @@ def gen_trace(sigs, log_n, bus_on=1):
             r1.v[C(0, k), s], r1.v[RL(0, k), s], r1.v[RH(0, k), s] = hl[k], hl[16 + k], ql[k]
             r1.v[RL(1, k), s] = rl_[k]
         r1.v[C(1, 0), s] = ql[16]
+        for j in range(64):
+            byte = (hh >> (8 * j)) & 0xFF
+            r1.v[BYA(j), s], r1.v[BYB(j), s] = byte, 256 * byte
         cr = 0
         for k in range(33):
             e = sum(ql[i] * LL[k - i] for i in range(17) if 0 <= k - i < 16) + (rl_[k] if k < 16 else 0) - (hl[k] if k < 32 else 0) + cr

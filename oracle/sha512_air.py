@@ -6,15 +6,18 @@ starkyx v1.0.0, not vendored; native mirror circuits/input/mod.rs:241-247).  R_i
 (oracle/ed_air.py), the digest goes back the same way.  FIPS 180-4, one round per row, 64-bit words split in 32-bit
 halves wherever arithmetic happens (a sum of six 64-bit words does not fit the 64-bit field).
 
-A slot takes 164 rows: block 1 = R || A || M || 80 00 00 | 0^8 (80 rows), block 2 = 0^120 || len 936 (80 rows, starts
-from block 1's output), then 4 DIGEST rows whose window positions 0 / 1 hold the digest words 2j / 2j+1 as bits (so the
-bus can re-cut them into the little-endian 16-bit limbs EdAir computes with).  Everything positional is a periodic
-column of full period: selectors, round constants, the bus tuple index.  Rows after the last slot are idle (all zero).
+A slot takes 160 rows: block 1 = R || A || M || 80 00 00 | 0^8 (80 rows), block 2 = 0^120 || len 936 (80 rows, starts
+from block 1's output).  Everything positional is a periodic column of full period: selectors, round constants, the bus
+tuple index.  Rows after the last slot are idle (all zero).  204 slots fit 2^15 rows (2/3 of 300 authorities + 1 = 201).
 Only words an XOR reads are bit columns (a, b, c, e, f, g, new a, new e, window positions 0, 1, 14); Sigma0 / Sigma1 /
 Ch / Maj are degree-3 polynomials of those bits, sigma0 / sigma1 have result + carry bits (x + y + z = r + 2c).
-Bus tuples (oracle/ed_air.py): 8 limbs = two 64-bit words w, w': limb j of a word = bytes (2j, 2j+1) of its big-endian
-byte string, little-endian -- (t0, l0 + 2^16 l1 + 2^32 l2, l3 + 2^16 l4 + 2^32 l5, l6 + 2^16 l7), tag TAG_EDMSG at rows
-0, 2, 4, 6 of block 1 (received), TAG_EDH at the digest rows (sent), both under the slot's flag SGF.
+Bus (oracle/ed_air.py), under the slot's flag SGF:
+  received at rows 0, 2, 4, 6 of block 1 (TAG_EDMSG, index 4 slot + j): message words 2j, 2j+1 (window positions 0 / 1, bits)
+    as 8 limbs -- limb j of a word = bytes (2j, 2j+1) of its big-endian byte string, little-endian --
+    (l0 + 2^16 l1 + 2^32 l2, l3 + 2^16 l4 + 2^32 l5, l6 + 2^16 l7);
+  sent at rows 74..79 of block 2 (TAG_EDH, index 8 slot + j): the digest, three 32-bit halves per tuple in the order
+    (word 0 lo, word 0 hi, word 1 lo, ...) -- the feed-forward VALUES, which the prover holds in FFV from row 74 on.  EdAir
+    receives them as big-endian sums of range-checked byte cells, which is what bounds them to 32 bits.
 Public inputs: message words 8..14 of block 1 as (lo, hi) halves (14 values), bus_on.
 """
 import hashlib
@@ -27,7 +30,7 @@ from .ed_air import TAG_EDH, TAG_EDMSG
 
 P = 2**64 - 2**32 + 1
 ID = 11
-IDS = {16: 11, 10: 13}  # AIR id by log2(rows)
+IDS = {16: 11, 15: 14, 10: 13}  # AIR id by log2(rows)
 M64, M32 = (1 << 64) - 1, 0xFFFFFFFF
 K = [
     0x428a2f98d728ae22, 0x7137449123ef65cd, 0xb5c0fbcfec4d3b2f, 0xe9b5dba58189dbbc, 0x3956c25bf348b538, 0x59f111f1b605d019, 0x923f82a4af194f9b, 0xab1c5ed5da6d8118,
@@ -43,7 +46,8 @@ K = [
 IV = [0x6a09e667f3bcc908, 0xbb67ae8584caa73b, 0x3c6ef372fe94f82b, 0xa54ff53a5f1d36f1, 0x510e527fade682d1, 0x9b05688c2b3e6c1f, 0x1f83d9abfb41bd6b, 0x5be0cd19137e2179]
 MSG_LEN = 53
 PAD2 = [0] * 15 + [8 * (64 + MSG_LEN)]  # block 2 of a 117-byte message
-SLOT_ROWS, ROUNDS = 164, 80
+SLOT_ROWS, ROUNDS = 160, 80
+SEND0 = 80 + 74  # the six send rows of a slot
 
 A_, B_, C_, E_, F_, G_ = 0, 64, 128, 192, 256, 320  # state words held as bits
 DV, HV = 384, 386                                   # d, h as (lo, hi) values
@@ -58,7 +62,7 @@ COLS = 1055
 BIT_RANGES = [(0, DV), (NA0, WV0), (S0R, FFV0), (FFC0, HIN0), (SGF, SGF + 1)]
 ST_BITS = {0: A_, 1: B_, 2: C_, 4: E_, 5: F_, 6: G_}
 AUX, CHAL, AUXPUB, PUB = 4, 4, 1, 15
-P_B1, P_INB, P_SCHED, P_KLO, P_KHI, P_LAST, P_CONT, P_HSET, P_RCV, P_SND, P_T0, P_DG0, P_FFK, P_SGK, PERIODIC = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 15, 16, 17
+P_B1, P_INB, P_SCHED, P_KLO, P_KHI, P_LAST, P_CONT, P_HSET, P_RCV, P_T0, P_FFK, P_SGK, P_SD0, PERIODIC = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 18
 
 
 def WV(p):
@@ -86,11 +90,11 @@ def periodic_values(n):
         for j in range(4):
             cols[P_RCV, b + 2 * j] = 1
             cols[P_T0, b + 2 * j] = 4 * s + j
-            cols[P_SND, b + 160 + j] = 1
-            cols[P_T0, b + 160 + j] = 4 * s + j
-            cols[P_DG0 + j, b + 160 + j] = 1
-        cols[P_FFK, b + 159:b + 163] = 1
-        cols[P_SGK, b:b + 163] = 1
+        for j in range(6):
+            cols[P_SD0 + j, b + SEND0 + j] = 1
+            cols[P_T0, b + SEND0 + j] = 8 * s + j
+        cols[P_FFK, b + SEND0:b + SEND0 + 5] = 1
+        cols[P_SGK, b:b + 159] = 1
     return [c.tolist() for c in cols]
 
 
@@ -213,20 +217,7 @@ def gen_trace(slots, msg, log_n, bus_on=1):
         dig = b"".join(x.to_bytes(8, "big") for x in out)
         assert dig == hashlib.sha512(head + msg).digest()
         digests.append(dig if ra else None)
-        for j in range(4):
-            row = b + 160 + j
-            for i in range(64):
-                tr[W0B + i, row] = (out[2 * j] >> i) & 1
-                tr[W1B + i, row] = (out[2 * j + 1] >> i) & 1
-            # the local round equation holds on every row: with an all-zero state NE = NA = the window's word 0
-            for i in range(64):
-                tr[NE0 + i, row] = tr[NA0 + i, row] = (out[2 * j] >> i) & 1
-            w1 = out[2 * j + 1]
-            x, y, z = rotr(w1, 1), rotr(w1, 8), w1 >> 7
-            for i in range(64):
-                sm = ((x >> i) & 1) + ((y >> i) & 1) + ((z >> i) & 1)
-                tr[S0R + i, row], tr[S0C + i, row] = sm & 1, sm >> 1
-        for row in range(b + 159, b + 164):
+        for row in range(b + SEND0, b + 160):
             for wd in range(8):
                 tr[FFV0 + 2 * wd, row], tr[FFV0 + 2 * wd + 1, row] = out[wd] & M32, out[wd] >> 32
         tr[SGF, b:b + SLOT_ROWS] = 1 if ra else 0
@@ -275,12 +266,20 @@ def limbs_of_word_bits(row, col0):
 
 def bus_lookup(loc, per, pub):
     l = limbs_of_word_bits(loc, W0B) + limbs_of_word_bits(loc, W1B)
-    t1 = l[0] + l[1] * (1 << 16) + l[2] * (1 << 32)
-    t2 = l[3] + l[4] * (1 << 16) + l[5] * (1 << 32)
-    t3 = l[6] + l[7] * (1 << 16)
-    m = loc[SGF] * pub[14] * (per[P_SND] - per[P_RCV])
-    tag = per[P_SND] * TAG_EDH + per[P_RCV] * TAG_EDMSG
-    return m, tag, (per[P_T0], t1, t2, t3)
+    rcv = per[P_RCV]
+    tr = [l[0] + l[1] * (1 << 16) + l[2] * (1 << 32), l[3] + l[4] * (1 << 16) + l[5] * (1 << 32), l[6] + l[7] * (1 << 16)]
+    snd, tt = None, []
+    for i in range(3):
+        acc = rcv * tr[i]
+        for j in range(6):
+            if 3 * j + i < 16:
+                acc = acc + per[P_SD0 + j] * loc[FFV0 + 3 * j + i]
+        tt.append(acc)
+    for j in range(6):
+        snd = per[P_SD0 + j] if snd is None else snd + per[P_SD0 + j]
+    m = loc[SGF] * pub[14] * (snd - rcv)
+    tag = snd * TAG_EDH + rcv * TAG_EDMSG
+    return m, tag, (per[P_T0], tt[0], tt[1], tt[2])
 
 
 def eval(loc, nxt, per, pub, c, chal, aux_pub):  # noqa: A001
@@ -396,16 +395,7 @@ def eval(loc, nxt, per, pub, c, chal, aux_pub):  # noqa: A001
         wn = window(nxt, p)
         for half in range(2):
             c.constraint(cont * (wn[half] - ((PAD2[p] >> (32 * half)) & M32)))
-    # ---- 9. digest rows: window positions 0 / 1 hold the digest words 2j / 2j+1; FF and the slot flag are kept
-    w1 = halves_of_bits(loc, W1B)
-    for half in range(2):
-        acc0 = acc1 = None
-        for j in range(4):
-            t0 = per[P_DG0 + j] * (w0[half] - loc[FFV0 + 4 * j + half])
-            t1 = per[P_DG0 + j] * (w1[half] - loc[FFV0 + 4 * j + 2 + half])
-            acc0, acc1 = (t0, t1) if acc0 is None else (acc0 + t0, acc1 + t1)
-        c.constraint(acc0)
-        c.constraint(acc1)
+    # ---- 9. the digest is held from row 74 of block 2 on (it is sent from there); the slot flag is kept
     for k in range(16):
         c.constraint(per[P_FFK] * (nxt[FFV0 + k] - loc[FFV0 + k]))
     c.constraint(per[P_SGK] * (nxt[SGF] - loc[SGF]))

@@ -144,8 +144,8 @@ def oracle_verify_blob(vx, blob, cfg, max_headers):
         from oracle import sha512_air as H5
         from oracle import sha_air as A
 
-        n_auth = S.proof_peek(p_sha, cfg["cap_height"])[0][8]
-        ed_l, h_l = (16 if n_auth <= 256 else 17), (10 if n_auth <= 6 else 16)
+        n_sig = S.proof_peek(p_ed, cfg["cap_height"])[0][0]  # the EdDSA tables are sized by the signatures they verify
+        ed_l, h_l = (16 if n_sig <= 255 else 17), (10 if n_sig <= 6 else 15 if n_sig <= 204 else 16)
         for air in (A.ShaChainAir, E.make_air(ed_l), H5.make_air(h_l)):
             S.register_air(air)
         tables += [(p_sha, A.ID), (p_ed, E.IDS[ed_l]), (p_h, H5.IDS[h_l])]

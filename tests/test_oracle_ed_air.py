@@ -94,7 +94,7 @@ def test_sha512_table_and_its_forgeries():
     aux, apub = H.gen_aux(tr, CHAL, pub)
     assert S.check_trace(air, tr, pub, chal=CHAL, aux=aux, aux_pub=apub) is None
     assert dig[0] == hashlib.sha512(slots[0][0] + slots[0][1] + MSG).digest() and dig[4] is None
-    for col, row in ((H.W0B + 5, 3), (H.W0B + 5, 161), (H.NA0 + 9, 40), (H.SGF, 170)):
+    for col, row in ((H.W0B + 5, 3), (H.FFV0 + 5, 156), (H.NA0 + 9, 40), (H.SGF, 170)):
         t2 = tr.copy()
         t2[col, row] ^= 1
         assert S.check_trace(air, t2, pub, chal=CHAL, aux=aux, aux_pub=apub) is not None
@@ -129,7 +129,7 @@ def test_bus_between_the_two_tables_balances(ed):
                 else:
                     rows_e.append(lk)
     for i in range(1 << 10):
-        if per_s[H.P_RCV][i] or per_s[H.P_SND][i]:
+        if per_s[H.P_RCV][i] or any(per_s[H.P_SD0 + j][i] for j in range(6)):
             rows_s.append(H.bus_lookup([int(ts[j, i]) for j in range(H.COLS)], [v[i] for v in per_s], pubs))
     te, tsum = total(rows_e), total(rows_s)
     assert keys == 16 and (te.a, te.b) != (0, 0)  # 4 signatures x 4 key quarters
