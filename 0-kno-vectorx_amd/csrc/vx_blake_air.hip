@@ -15,6 +15,7 @@
 #include <mutex>
 #include <thread>
 
+#include "vx_bus.h"
 #include "vx_internal.h"
 
 
@@ -678,56 +679,122 @@ int32_t vx_header_range_proof_bound(const vx_stark_config* cfg, size_t n_chunks,
     return rc;
 }
 
-namespace {
-// The tables of one statement share their lookup challenges: every prover stops after its trace cap (the challenge hook)
-// and waits for the caps of all the others; each then derives the same challenges from the transcript of all (public
-// inputs, cap) pairs in table order.  A rendezvous of host threads, one per table, each with its own context and stream.
-struct BusMeet {
-    static constexpr int MAX = 5;
-    std::mutex m;
-    std::condition_variable cv;
-    int n_parties = 0, arrived = 0;
-    bool failed = false;
-    std::vector<uint64_t> pub[MAX], cap[MAX];
-    static int32_t meet(BusMeet* r, int who, const uint64_t* pub, size_t n_pub, const uint64_t* cap, size_t cap_words, uint64_t* chal, size_t n_chal) {
-        std::unique_lock<std::mutex> lk(r->m);
-        r->pub[who].assign(pub, pub + n_pub);
-        r->cap[who].assign(cap, cap + cap_words);
-        ++r->arrived;
-        r->cv.notify_all();
-        r->cv.wait(lk, [&] { return r->arrived == r->n_parties || r->failed; });
-        if (r->arrived != r->n_parties) return VX_ERR_STATEMENT;  // another table's prover gave up
-        const uint64_t *pubs[MAX], *caps[MAX];
-        size_t ns[MAX];
-        for (int t = 0; t < r->n_parties; ++t) pubs[t] = r->pub[t].data(), ns[t] = r->pub[t].size(), caps[t] = r->cap[t].data();
-        uint64_t c[4];
-        vx_shared_challenges_n(pubs, ns, caps, (size_t)r->n_parties, cap_words, c, 4);
-        for (size_t q = 0; q < n_chal && q < 4; ++q) chal[q] = c[q];
-        return VX_OK;
-    }
-    void fail() {
-        std::lock_guard<std::mutex> lk(m);
-        failed = true;
-        cv.notify_all();
-    }
-};
-struct BusParty {
-    BusMeet* rv;
-    int who;
-};
-int32_t bus_hook(void* u, const uint64_t* pub, size_t n_pub, const uint64_t* cap, size_t cw, uint64_t* chal, size_t n_chal) {
+}  // extern "C"
+
+int32_t BusMeet::meet(BusMeet* r, int who, const uint64_t* pub, size_t n_pub, const uint64_t* cap, size_t cap_words, uint64_t* chal, size_t n_chal) {
+    std::unique_lock<std::mutex> lk(r->m);
+    r->pub[who].assign(pub, pub + n_pub);
+    r->cap[who].assign(cap, cap + cap_words);
+    ++r->arrived;
+    r->cv.notify_all();
+    r->cv.wait(lk, [&] { return r->arrived == r->n_parties || r->failed; });
+    if (r->arrived != r->n_parties) return VX_ERR_STATEMENT;  // another table's prover gave up
+    const uint64_t *pubs[MAX], *caps[MAX];
+    size_t ns[MAX];
+    for (int t = 0; t < r->n_parties; ++t) pubs[t] = r->pub[t].data(), ns[t] = r->pub[t].size(), caps[t] = r->cap[t].data();
+    uint64_t c[4];
+    vx_shared_challenges_n(pubs, ns, caps, (size_t)r->n_parties, cap_words, c, 4);
+    for (size_t q = 0; q < n_chal && q < 4; ++q) chal[q] = c[q];
+    return VX_OK;
+}
+void BusMeet::fail() {
+    std::lock_guard<std::mutex> lk(m);
+    failed = true;
+    cv.notify_all();
+}
+int32_t vx_bus_hook(void* u, const uint64_t* pub, size_t n_pub, const uint64_t* cap, size_t cw, uint64_t* chal, size_t n_chal) {
     BusParty* p = (BusParty*)u;
     return BusMeet::meet(p->rv, p->who, pub, n_pub, cap, cw, chal, n_chal);
 }
-// one table of the statement, proven from its own host thread on its own context
-struct TableJob {
-    vx_ctx* c = nullptr;
-    std::thread th;
-    int32_t rc = VX_OK;
-    std::vector<uint64_t> proof;
-    size_t len = 0;
-};
-}  // namespace
+
+size_t vx_justification_proof_bound(const vx_stark_config* cfg, size_t n_authorities, int32_t* rc_out) {
+    size_t w2 = 0, w4 = 0, w5 = 0;
+    int32_t rc = vx_stark_proof_bound(VX_AIR_SHA_CHAIN, cfg, sha_log_n(n_authorities), &w2);
+    if (rc == VX_OK) rc = vx_stark_proof_bound(ed_air_id(sig_quorum(n_authorities)), cfg, ed_log_n(sig_quorum(n_authorities)), &w4);
+    if (rc == VX_OK) rc = vx_stark_proof_bound(s512_air_id(sig_quorum(n_authorities)), cfg, s512_log_n(sig_quorum(n_authorities)), &w5);
+    *rc_out = rc;
+    return w2 + w4 + w5;
+}
+
+int32_t vx_justification_tables_start(vx_ctx* const ctxs[3], const vx_justification* just, const vx_stark_config* cfg, BusMeet* rv, int first,
+                                      int32_t (*pre)(vx_ctx*, void*), void* pre_user, JustificationTables* jt) {
+    // the signatures the proof verifies: the first floor(2n/3) + 1 signed authorities (more would only cost rows); when fewer
+    // signed, all of them -- the native threshold check refuses the justification before anything is proven
+    jt->chosen.assign(just->num_authorities, 0);
+    jt->n_sig = 0;
+    for (size_t i = 0; i < just->num_authorities && jt->n_sig < sig_quorum(just->num_authorities); ++i)
+        if (just->validator_signed[i]) jt->chosen[i] = 1, ++jt->n_sig;
+    for (int t = 0; t < 3; ++t) jt->party[t] = {rv, first + t}, jt->hooks[t] = {vx_bus_hook, &jt->party[t]}, jt->job[t].c = ctxs[t];
+    auto prove_chain = [=](vx_ctx* c, TableJob& j) -> int32_t {
+        if (pre) VX_TRY(pre(c, pre_user));
+        const int sl = sha_log_n(just->num_authorities);
+        size_t bound = 0;
+        VX_TRY(vx_stark_proof_bound(VX_AIR_SHA_CHAIN, cfg, sl, &bound));
+        j.proof.resize(bound);
+        vx_buf* st = nullptr;
+        VX_TRY(vx_alloc(c, ((size_t)VX_SHA_AIR_COLS) << sl, &st));
+        uint64_t spub[10];
+        uint8_t com[32];
+        int32_t r = vx_sha_chain_trace_dev(c, just->pubkeys, just->num_authorities, jt->chosen.data(), 1, sl, st->d, spub, com);
+        if (r == VX_OK && memcmp(com, just->authority_set_hash, 32) != 0) r = vx_fail(c, VX_ERR_STATEMENT, "authority-set commitment mismatch");
+        if (r == VX_OK) r = vx_stark_prove_impl(c, VX_AIR_SHA_CHAIN, cfg, st->d, st->n, /*consume_trace=*/0, sl, spub, 10, j.proof.data(), j.proof.size(), &j.len, &jt->hooks[0]);
+        (void)vx_free(c, st);
+        return r;
+    };
+    auto prove_ed = [=](vx_ctx* c, TableJob& j) -> int32_t {
+        const int el = ed_log_n(jt->n_sig), id = ed_air_id(jt->n_sig);
+        size_t bound = 0;
+        VX_TRY(vx_stark_proof_bound(id, cfg, el, &bound));
+        j.proof.resize(bound);
+        vx_buf* et = nullptr;
+        VX_TRY(vx_alloc(c, ((size_t)VX_ED_AIR_COLS) << el, &et));
+        uint64_t epub[2];
+        int32_t r = vx_ed_trace_dev(c, just->pubkeys, just->signatures, just->precommit, 53, jt->chosen.data(), just->num_authorities, el, 1, et->d, epub);
+        if (r == VX_OK) r = vx_stark_prove_impl(c, id, cfg, et->d, et->n, /*consume_trace=*/0, el, epub, 2, j.proof.data(), j.proof.size(), &j.len, &jt->hooks[1]);
+        (void)vx_free(c, et);
+        return r;
+    };
+    auto prove_s512 = [=](vx_ctx* c, TableJob& j) -> int32_t {
+        const int hl = s512_log_n(jt->n_sig), id = s512_air_id(jt->n_sig);
+        size_t bound = 0;
+        VX_TRY(vx_stark_proof_bound(id, cfg, hl, &bound));
+        j.proof.resize(bound);
+        vx_buf* ht = nullptr;
+        VX_TRY(vx_alloc(c, ((size_t)VX_SHA512_AIR_COLS) << hl, &ht));
+        uint64_t hpub[15];
+        int32_t r = vx_sha512_trace_dev(c, just->pubkeys, just->signatures, just->precommit, jt->chosen.data(), just->num_authorities, hl, 1, ht->d, hpub);
+        if (r == VX_OK) r = vx_stark_prove_impl(c, id, cfg, ht->d, ht->n, /*consume_trace=*/0, hl, hpub, 15, j.proof.data(), j.proof.size(), &j.len, &jt->hooks[2]);
+        (void)vx_free(c, ht);
+        return r;
+    };
+    for (int t = 0; t < 3; ++t) {
+        TableJob* j = &jt->job[t];
+        try {
+            j->th = std::thread([=] {
+                (void)hipSetDevice(j->c->device);
+                j->rc = t == 0 ? prove_chain(j->c, *j) : t == 1 ? prove_ed(j->c, *j) : prove_s512(j->c, *j);
+                if (j->rc != VX_OK) rv->fail();  // do not leave the other provers waiting at their hooks
+            });
+        } catch (...) {
+            rv->fail();
+            return VX_ERR_DEVICE;
+        }
+    }
+    return VX_OK;
+}
+
+int32_t vx_justification_tables_join(vx_ctx* ctx, JustificationTables* jt) {
+    for (int t = 0; t < 3; ++t)
+        if (jt->job[t].th.joinable()) jt->job[t].th.join();
+    // a prover released from the rendezvous by somebody else's failure reports VX_ERR_STATEMENT without a message
+    for (int t = 0; t < 3; ++t)
+        if (jt->job[t].rc != VX_OK && vx_last_error(jt->job[t].c)[0]) return vx_fail(ctx, jt->job[t].rc, "%s", vx_last_error(jt->job[t].c));
+    for (int t = 0; t < 3; ++t)
+        if (jt->job[t].rc != VX_OK) return vx_fail(ctx, jt->job[t].rc, "justification table %d failed", t);
+    return VX_OK;
+}
+
+extern "C" {
 
 int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_fetched,
                               uint32_t max_headers, uint32_t trusted_block, const uint8_t trusted_hash[32], uint32_t target_block,
@@ -758,27 +825,16 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
     //    4 Sha512Air      H = SHA-512(R || A || precommit)
     BusMeet rv;
     rv.n_parties = just ? 5 : 2;
-    BusParty party[BusMeet::MAX];
-    vx_chal_hook hooks[BusMeet::MAX];
-    for (int t = 0; t < BusMeet::MAX; ++t) party[t] = {&rv, t}, hooks[t] = {bus_hook, &party[t]};
-    TableJob job[BusMeet::MAX];
-    {   // contexts: a chain of side contexts, one per table
+    BusParty party[2] = {{&rv, 0}, {&rv, 1}};
+    const vx_chal_hook hooks[2] = {{vx_bus_hook, &party[0]}, {vx_bus_hook, &party[1]}};
+    vx_ctx* side[4] = {nullptr, nullptr, nullptr, nullptr};  // a chain of side contexts, one per table
+    {
         vx_ctx* c = ctx;
-        for (int t = 1; t < rv.n_parties; ++t) {
-            c = c ? vx_side_ctx(c) : nullptr;
-            job[t].c = c;
-        }
+        for (int t = 0; t < rv.n_parties - 1; ++t) side[t] = c = c ? vx_side_ctx(c) : nullptr;
         VX_CHECK(c, "header_range: no side context for every table (the provers meet at their challenge hooks, each on its own context)");
     }
-    // the signatures the proof verifies: the first floor(2n/3) + 1 signed authorities (more would only cost rows); when fewer
-    // signed, all of them -- the native threshold check refuses the justification before anything is proven
-    std::vector<uint8_t> chosen;
-    size_t n_sig = 0;
-    if (just) {
-        chosen.assign(just->num_authorities, 0);
-        for (size_t i = 0; i < just->num_authorities && n_sig < sig_quorum(just->num_authorities); ++i)
-            if (just->validator_signed[i]) chosen[i] = 1, ++n_sig;
-    }
+    TableJob tree;
+    tree.c = side[0];
     uint64_t tpub[16];
     auto prove_tree = [&](vx_ctx* c, TableJob& j) -> int32_t {
         vx_buf* tt = nullptr;
@@ -799,63 +855,32 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
         if (tt) (void)vx_free(c, tt);
         return r;
     };
-    auto prove_chain = [&](vx_ctx* c, TableJob& j) -> int32_t {
-        // the target header is justified by > 2/3 of the committed authority set: every rule natively first (error behaviour of
-        // the reference's hint, justification.rs:29-83), then the commitment table
-        VX_TRY(vx_verify_simple_justification(c, target_block, out96, just->authority_set_id, just->authority_set_hash, just->precommit, just->pubkeys, just->signatures,
-                                              just->validator_signed, just->num_authorities, just->max_authorities));
-        const int sl = sha_log_n(just->num_authorities);
-        size_t bound = 0;
-        VX_TRY(vx_stark_proof_bound(VX_AIR_SHA_CHAIN, cfg, sl, &bound));
-        j.proof.resize(bound);
-        vx_buf* st = nullptr;
-        VX_TRY(vx_alloc(c, ((size_t)VX_SHA_AIR_COLS) << sl, &st));
-        uint64_t spub[10];
-        uint8_t com[32];
-        int32_t r = vx_sha_chain_trace_dev(c, just->pubkeys, just->num_authorities, chosen.data(), 1, sl, st->d, spub, com);
-        if (r == VX_OK && memcmp(com, just->authority_set_hash, 32) != 0) r = vx_fail(c, VX_ERR_STATEMENT, "header_range: authority-set commitment mismatch");
-        if (r == VX_OK) r = vx_stark_prove_impl(c, VX_AIR_SHA_CHAIN, cfg, st->d, st->n, /*consume_trace=*/0, sl, spub, 10, j.proof.data(), j.proof.size(), &j.len, &hooks[2]);
-        (void)vx_free(c, st);
-        return r;
-    };
-    auto prove_ed = [&](vx_ctx* c, TableJob& j) -> int32_t {
-        const int el = ed_log_n(n_sig), id = ed_air_id(n_sig);
-        size_t bound = 0;
-        VX_TRY(vx_stark_proof_bound(id, cfg, el, &bound));
-        j.proof.resize(bound);
-        vx_buf* et = nullptr;
-        VX_TRY(vx_alloc(c, ((size_t)VX_ED_AIR_COLS) << el, &et));
-        uint64_t epub[2];
-        int32_t r = vx_ed_trace_dev(c, just->pubkeys, just->signatures, just->precommit, 53, chosen.data(), just->num_authorities, el, 1, et->d, epub);
-        if (r == VX_OK) r = vx_stark_prove_impl(c, id, cfg, et->d, et->n, /*consume_trace=*/0, el, epub, 2, j.proof.data(), j.proof.size(), &j.len, &hooks[3]);
-        (void)vx_free(c, et);
-        return r;
-    };
-    auto prove_s512 = [&](vx_ctx* c, TableJob& j) -> int32_t {
-        const int hl = s512_log_n(n_sig), id = s512_air_id(n_sig);
-        size_t bound = 0;
-        VX_TRY(vx_stark_proof_bound(id, cfg, hl, &bound));
-        j.proof.resize(bound);
-        vx_buf* ht = nullptr;
-        VX_TRY(vx_alloc(c, ((size_t)VX_SHA512_AIR_COLS) << hl, &ht));
-        uint64_t hpub[15];
-        int32_t r = vx_sha512_trace_dev(c, just->pubkeys, just->signatures, just->precommit, chosen.data(), just->num_authorities, hl, 1, ht->d, hpub);
-        if (r == VX_OK) r = vx_stark_prove_impl(c, id, cfg, ht->d, ht->n, /*consume_trace=*/0, hl, hpub, 15, j.proof.data(), j.proof.size(), &j.len, &hooks[4]);
-        (void)vx_free(c, ht);
-        return r;
+    // the target header is justified by > 2/3 of the committed authority set: every rule natively first (error behaviour of
+    // the reference's hint, justification.rs:29-83), on the commitment table's thread
+    struct PreArgs {
+        const vx_justification* just;
+        uint32_t target_block;
+        const uint8_t* target_hash;
+    } pre_args{just, target_block, out96};
+    auto pre = [](vx_ctx* c, void* u) -> int32_t {
+        const PreArgs* a = (const PreArgs*)u;
+        return vx_verify_simple_justification(c, a->target_block, a->target_hash, a->just->authority_set_id, a->just->authority_set_hash, a->just->precommit,
+                                              a->just->pubkeys, a->just->signatures, a->just->validator_signed, a->just->num_authorities, a->just->max_authorities);
     };
     int32_t rc = VX_OK;
-    for (int t = 1; t < rv.n_parties && rc == VX_OK; ++t) {
-        TableJob* j = &job[t];
-        try {
-            j->th = std::thread([&, j, t] {
-                (void)hipSetDevice(j->c->device);
-                j->rc = t == 1 ? prove_tree(j->c, *j) : t == 2 ? prove_chain(j->c, *j) : t == 3 ? prove_ed(j->c, *j) : prove_s512(j->c, *j);
-                if (j->rc != VX_OK) rv.fail();  // do not leave the other provers waiting at their hooks
-            });
-        } catch (...) {
-            rc = vx_fail(ctx, VX_ERR_DEVICE, "header_range: no host thread for table %d", t);
-        }
+    JustificationTables jt;
+    try {
+        tree.th = std::thread([&] {
+            (void)hipSetDevice(tree.c->device);
+            tree.rc = prove_tree(tree.c, tree);
+            if (tree.rc != VX_OK) rv.fail();  // do not leave the other provers waiting at their hooks
+        });
+    } catch (...) {
+        rc = vx_fail(ctx, VX_ERR_DEVICE, "header_range: no host thread for the Merkle table");
+    }
+    if (rc == VX_OK && just) {
+        rc = vx_justification_tables_start(side + 1, just, cfg, &rv, 2, pre, &pre_args, &jt);
+        if (rc != VX_OK) (void)vx_fail(ctx, rc, "header_range: no host thread for the justification tables");
     }
     vx_buf* trace = nullptr;
     size_t len1 = 0;
@@ -875,31 +900,19 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
                                  room ? proof_cap - VX_HR_HDR : 0, &len1, &hooks[0]);
     if (rc != VX_OK && rc != VX_ERR_BUFSZ) rv.fail();
     if (trace) (void)vx_free(ctx, trace);
-    for (int t = 1; t < BusMeet::MAX; ++t)
-        if (job[t].th.joinable()) job[t].th.join();
-    // the first table that failed for a reason of its own names the error (a prover released from the rendezvous by
-    // somebody else's failure reports VX_ERR_STATEMENT without a message); the justification's own rules come first
+    if (tree.th.joinable()) tree.th.join();
+    const int32_t rc_just = just ? vx_justification_tables_join(ctx, &jt) : VX_OK;  // (the justification's own rules name the error first)
     if (rc == VX_OK || rc == VX_ERR_BUFSZ) {
-        const int order[4] = {2, 3, 4, 1};
-        for (int q = 0; q < 4; ++q) {
-            const TableJob& j = job[order[q]];
-            if (order[q] < rv.n_parties && j.rc != VX_OK && vx_last_error(j.c)[0]) {
-                rc = vx_fail(ctx, j.rc, "%s", vx_last_error(j.c));
-                break;
-            }
-        }
-        if (rc == VX_OK || rc == VX_ERR_BUFSZ)
-            for (int t = 1; t < rv.n_parties; ++t)
-                if (job[t].rc != VX_OK) rc = vx_fail(ctx, job[t].rc, "header_range: table %d failed", t);
+        if (rc_just != VX_OK) rc = rc_just;
+        else if (tree.rc != VX_OK) rc = vx_fail(ctx, tree.rc, "%s", vx_last_error(tree.c));
     }
-    *proof_len = VX_HR_HDR + len1;
-    for (int t = 1; t < rv.n_parties; ++t) *proof_len += job[t].len;
+    *proof_len = VX_HR_HDR + len1 + tree.len + (just ? jt.job[0].len + jt.job[1].len + jt.job[2].len : 0);
     if (rc == VX_OK) {
         if (proof_out && proof_cap >= *proof_len) {
             size_t off = VX_HR_HDR + len1;
-            const int order[4] = {2, 1, 3, 4};  // commitment, Merkle, Ed25519, SHA-512
+            const TableJob* order[4] = {just ? &jt.job[0] : nullptr, &tree, just ? &jt.job[1] : nullptr, just ? &jt.job[2] : nullptr};  // commitment, Merkle, Ed25519, SHA-512
             for (int q = 0; q < 4; ++q)
-                if (order[q] < rv.n_parties) memcpy(proof_out + off, job[order[q]].proof.data(), job[order[q]].len * 8), off += job[order[q]].len;
+                if (order[q]) memcpy(proof_out + off, order[q]->proof.data(), order[q]->len * 8), off += order[q]->len;
         } else rc = vx_fail(ctx, VX_ERR_BUFSZ, "header_range: proof needs %zu words, buffer has %zu", *proof_len, proof_cap);
     }
     if (rc != VX_OK) return rc;
@@ -909,10 +922,10 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
     proof_out[3] = target_block;
     memcpy(proof_out + 4, out96, 96);
     proof_out[16] = len1;
-    proof_out[17] = job[2].len;
-    proof_out[18] = job[1].len;
-    proof_out[19] = job[3].len;
-    proof_out[20] = job[4].len;
+    proof_out[17] = just ? jt.job[0].len : 0;
+    proof_out[18] = tree.len;
+    proof_out[19] = just ? jt.job[1].len : 0;
+    proof_out[20] = just ? jt.job[2].len : 0;
     uint64_t round = 0;
     if (just) memcpy(&round, just->precommit + 37, 8);  // 0x01 || hash 32 || block 4 || round 8 || set id 8 (decoder.rs:159-200)
     proof_out[21] = round;

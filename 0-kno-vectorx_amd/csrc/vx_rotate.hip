@@ -8,6 +8,7 @@
 #include <thread>
 #include <vector>
 
+#include "vx_bus.h"
 #include "vx_internal.h"
 
 namespace {
@@ -66,8 +67,10 @@ __global__ __launch_bounds__(64) void k_epoch_end_check(const uint8_t* __restric
     if (t + 1 == num_authorities && (v[40] | v[41] | v[42] | v[43]) != 0) return fail(EE_DELAY, t);  // :267-274
 }
 
-const uint64_t VX_ROT_MAGIC = 0x3154415458525856ULL;  // "VXRXTAT1"
-constexpr size_t VX_ROT_HDR = 24;  // magic, set id, block, n_new, header hash (4), set hash (4), new set hash (4), 3 proof lengths, 0, parent hash (4)
+const uint64_t VX_ROT_MAGIC = 0x3254415458525856ULL;  // "VXRXTAT2"
+// magic, set id, block, n_new, header hash (4), set hash (4), new set hash (4), proof lengths: header hash, current-set commitment,
+// new-set commitment, Ed25519; parent hash (4); SHA-512 proof length, the precommit's round
+constexpr size_t VX_ROT_HDR = 26;
 
 int sha_rows_log(size_t n_keys) {
     int log_n = 6;
@@ -120,7 +123,7 @@ int32_t vx_rotate_proof_bound(const vx_stark_config* cfg, size_t n_chunks, size_
     if (!cfg || !n_words || n_chunks == 0 || n_cur_authorities == 0 || n_new_authorities == 0) return VX_ERR_ARG;
     size_t w1 = 0, w2 = 0, w3 = 0;
     int32_t rc = vx_stark_proof_bound(VX_AIR_BLAKE_CHAIN, cfg, blake_rows_log(n_chunks), &w1);
-    if (rc == VX_OK) rc = vx_stark_proof_bound(VX_AIR_SHA_CHAIN, cfg, sha_rows_log(n_cur_authorities), &w2);
+    if (rc == VX_OK) w2 = vx_justification_proof_bound(cfg, n_cur_authorities, &rc);  // commitment of the current set + Ed25519 + SHA-512
     if (rc == VX_OK) rc = vx_stark_proof_bound(VX_AIR_SHA_CHAIN, cfg, sha_rows_log(n_new_authorities), &w3);
     *n_words = VX_ROT_HDR + w1 + w2 + w3;
     return rc;
@@ -134,11 +137,10 @@ int32_t vx_rotate_prove(vx_ctx* ctx, const vx_buf* header, uint32_t header_size,
     if (header_size > MAX_HEADER_SIZE)  // input/mod.rs:851-856
         return vx_fail(ctx, VX_ERR_STATEMENT, "rotate: header size %u is greater than MAX_HEADER_SIZE %u", header_size, MAX_HEADER_SIZE);
     VX_CHECK(header_size >= 36, "rotate: header of %u bytes cannot hold a parent hash and a block number", header_size);
-    // 0. commitment of the CURRENT set (binds the EVM input hash): independent of everything below, so it is proven on
-    //    the side context from a host thread meanwhile
-    std::vector<uint64_t> cur_proof;
-    size_t cur_len = 0;
-    int32_t rc_cur = VX_OK;
+    // 0. the justification by the CURRENT set (rotate.rs:297-302) as three tables on one logUp bus -- its commitment (binds the EVM
+    //    input hash; sends the chosen signers' keys), the Ed25519 table and the SHA-512 table (vx_bus.h) -- proven on side contexts
+    //    from host threads meanwhile; they need the precommit, not the header hash
+    VX_CHECK(just->num_authorities >= 1 && just->num_authorities <= 512, "rotate: %u authorities (the EdDSA table holds 512)", just->num_authorities);
     uint8_t commit[2][32];
     auto prove_set = [&](vx_ctx* c, const uint8_t* keys, size_t nk, uint8_t com[32], uint64_t* dst, size_t cap, size_t* len) -> int32_t {
         (void)hipSetDevice(c->device);
@@ -152,26 +154,27 @@ int32_t vx_rotate_prove(vx_ctx* ctx, const vx_buf* header, uint32_t header_size,
         (void)vx_free(c, st);
         return r;
     };
+    BusMeet rv;
+    rv.n_parties = 3;
+    JustificationTables jt;
+    vx_ctx* side[3];
     {
-        size_t bound = 0;
-        VX_TRY(vx_stark_proof_bound(VX_AIR_SHA_CHAIN, cfg, sha_rows_log(just->num_authorities ? just->num_authorities : 1), &bound));
-        cur_proof.resize(bound);
+        vx_ctx* c = ctx;
+        for (int t = 0; t < 3; ++t) side[t] = c = c ? vx_side_ctx(c) : nullptr;
+        VX_CHECK(c, "rotate: no side context for every justification table");
     }
-    vx_ctx* side = just->num_authorities ? vx_side_ctx(ctx) : nullptr;
-    std::thread cur_thread;
-    if (side) {
-        try {
-            cur_thread = std::thread([&] { rc_cur = prove_set(side, just->pubkeys, just->num_authorities, commit[0], cur_proof.data(), cur_proof.size(), &cur_len); });
-        } catch (...) {  // no thread to be had: proven on this context further down
-            side = nullptr;
-        }
-    }
-    struct Joiner {  // every exit path waits for the thread
-        std::thread& t;
+    struct Joiner {  // every exit path waits for the threads
+        JustificationTables& j;
+        BusMeet& r;
         ~Joiner() {
-            if (t.joinable()) t.join();
+            for (int t = 0; t < 3; ++t)
+                if (j.job[t].th.joinable()) j.job[t].th.join();
         }
-    } joiner{cur_thread};
+    } joiner{jt, rv};
+    {
+        const int32_t rs = vx_justification_tables_start(side, just, cfg, &rv, 0, nullptr, nullptr, &jt);
+        if (rs != VX_OK) return vx_fail(ctx, rs, "rotate: no host thread for the justification tables");
+    }
     // 1. header hash = Blake2b-256 of the first header_size bytes (rotate.rs:293); the trace of its compressions
     //    is the witness of the hash STARK (one-header chain anchored at the header's own parent hash)
     uint8_t head[40], header_hash[32];
@@ -218,18 +221,19 @@ int32_t vx_rotate_prove(vx_ctx* ctx, const vx_buf* header, uint32_t header_size,
         new_proof.resize(bound);
         if (rc == VX_OK) rc = prove_set(ctx, new_pubkeys, num_authorities, commit[1], new_proof.data(), new_proof.size(), &len[2]);
     }
-    if (cur_thread.joinable()) cur_thread.join();
-    else if (rc == VX_OK && just->num_authorities)
-        rc_cur = prove_set(ctx, just->pubkeys, just->num_authorities, commit[0], cur_proof.data(), cur_proof.size(), &cur_len);
-    if (rc == VX_OK && rc_cur != VX_OK) rc = side ? vx_fail(ctx, rc_cur, "%s", vx_last_error(side)) : rc_cur;
-    if (rc == VX_OK && memcmp(commit[0], just->authority_set_hash, 32) != 0) rc = vx_fail(ctx, VX_ERR_STATEMENT, "rotate: authority-set commitment mismatch");
-    len[1] = cur_len;
-    if (rc == VX_OK && rc_room == VX_OK && proof_out && proof_cap >= VX_ROT_HDR + len[0] + len[1] + len[2]) {
-        memcpy(proof_out + VX_ROT_HDR + len[0], cur_proof.data(), len[1] * 8);
-        memcpy(proof_out + VX_ROT_HDR + len[0] + len[1], new_proof.data(), len[2] * 8);
+    const int32_t rc_just = vx_justification_tables_join(ctx, &jt);
+    if (rc == VX_OK && rc_just != VX_OK) rc = rc_just;
+    len[1] = jt.job[0].len;
+    const size_t len_ed = jt.job[1].len, len_h = jt.job[2].len, total = VX_ROT_HDR + len[0] + len[1] + len[2] + len_ed + len_h;
+    if (rc == VX_OK && rc_room == VX_OK && proof_out && proof_cap >= total) {
+        size_t off = VX_ROT_HDR + len[0];
+        memcpy(proof_out + off, jt.job[0].proof.data(), len[1] * 8), off += len[1];
+        memcpy(proof_out + off, new_proof.data(), len[2] * 8), off += len[2];
+        memcpy(proof_out + off, jt.job[1].proof.data(), len_ed * 8), off += len_ed;
+        memcpy(proof_out + off, jt.job[2].proof.data(), len_h * 8);
     }
     if (rc != VX_OK) return rc;
-    *proof_len = VX_ROT_HDR + len[0] + len[1] + len[2];
+    *proof_len = total;
     memcpy(out32, commit[1], 32);
     if (rc_room != VX_OK || !proof_out || proof_cap < *proof_len)
         return vx_fail(ctx, VX_ERR_BUFSZ, "rotate: proof needs %zu words, buffer has %zu", *proof_len, proof_cap);
@@ -243,8 +247,12 @@ int32_t vx_rotate_prove(vx_ctx* ctx, const vx_buf* header, uint32_t header_size,
     proof_out[16] = len[0];
     proof_out[17] = len[1];
     proof_out[18] = len[2];
-    proof_out[19] = 0;
+    proof_out[19] = len_ed;
     memcpy(proof_out + 20, parent, 32);
+    proof_out[24] = len_h;
+    uint64_t round = 0;
+    memcpy(&round, just->precommit + 37, 8);  // 0x01 || hash 32 || block 4 || round 8 || set id 8 (decoder.rs:159-200)
+    proof_out[25] = round;
     return VX_OK;
 }
 
@@ -260,8 +268,8 @@ int32_t vx_rotate_verify(const vx_stark_config* cfg, const uint64_t* blob, size_
     if (len <= VX_ROT_HDR || blob[0] != VX_ROT_MAGIC) return bad("bad rotate blob");
     if (blob[1] != authority_set_id || memcmp(blob + 8, authority_set_hash, 32) != 0) return bad("blob is for a different request");
     if (memcmp(blob + 12, out32, 32) != 0) return bad("public output differs from the blob");
-    const size_t l0 = blob[16], l1 = blob[17], l2 = blob[18];
-    if (l0 > len || l1 > len || l2 > len || VX_ROT_HDR + l0 + l1 + l2 != len) return bad("blob lengths are inconsistent");
+    const size_t l0 = blob[16], l1 = blob[17], l2 = blob[18], l3 = blob[19], l4 = blob[24];
+    if (l0 > len || l1 > len || l2 > len || l3 > len || l4 > len || VX_ROT_HDR + l0 + l1 + l2 + l3 + l4 != len) return bad("blob lengths are inconsistent");
     if (blob[2] >> 32) return bad("block number out of range");
     // Blake proof: a chain of exactly one header, numbered epoch_end_block, hashing to the blob's header hash.  The
     // anchor (first 8 public inputs) is the parent hash the header itself carries -- free in this statement.
@@ -278,22 +286,44 @@ int32_t vx_rotate_verify(const vx_stark_config* cfg, const uint64_t* blob, size_
     pub[18] = pub[19] = 0;
     int32_t rc = vx_stark_verify(cfg, p0, l0, VX_AIR_BLAKE_CHAIN, pub, 20, err, errlen);
     if (rc != VX_OK) return rc;
-    // public inputs of a commitment proof: the hash, the number of keys (bound by the hash; taken from the proof), bus off
-    auto verify_set = [&](const uint64_t* proof, size_t plen, const uint8_t* hash) -> int32_t {
+    // the justification by the current set: commitment, Ed25519 and SHA-512 tables under shared lookup challenges; the signed
+    // message is the precommit for (the proven header hash, the block number, the round, the request's set id)
+    {
+        const uint64_t* proof[3] = {p0 + l0, p0 + l0 + l1 + l2, p0 + l0 + l1 + l2 + l3};
+        const size_t pl[3] = {l1, l3, l4};
+        const uint64_t *ppub[3], *pcap[3];
+        size_t npub[3];
+        for (int t = 0; t < 3; ++t)
+            if (!vx_stark_proof_peek(proof[t], pl[t], cfg->cap_height, &ppub[t], &npub[t], &pcap[t])) return bad("justification proofs are too short to hold a trace cap");
+        uint64_t spub[10], epub[2], hpub[15];
+        int air[3];
+        rc = vx_justification_expect(ppub[0], npub[0], ppub[1], npub[1], npub[2], authority_set_hash, authority_set_id, (const uint8_t*)(blob + 4), (uint32_t)blob[2], blob[25],
+                                     spub, epub, hpub, air, err, errlen);
+        if (rc != VX_OK) return rc;
+        uint64_t chal[4];
+        vx_shared_challenges_host(ppub, npub, pcap, 3, (size_t)4 << cfg->cap_height, chal, 4);
+        const uint64_t* want[3] = {spub, epub, hpub};
+        const size_t n_want[3] = {10, 2, 15};
+        uint64_t bus[2] = {0, 0};
+        for (int t = 0; t < 3; ++t) {
+            const uint64_t* apub = nullptr;
+            int L = 0;
+            rc = vx_stark_verify_ext(cfg, proof[t], pl[t], air[t], want[t], n_want[t], chal, &apub, &L, err, errlen);
+            if (rc != VX_OK) return rc;
+            for (int q = 0; q < 2; ++q) bus[q] = glh::add(bus[q], glh::mul(apub[q], ((uint64_t)1 << L) % glh::P));
+        }
+        if (bus[0] || bus[1]) return bad("the lookup bus between the justification tables does not balance");
+    }
+    // the new set's commitment (stand-alone): the hash, the number of keys (bound by the hash; taken from the proof), bus off
+    {
         uint64_t spub[10];
-        be_limbs(hash, spub);
+        be_limbs(out32, spub);
         const uint64_t *ppub, *pcap;
         size_t n_ppub;
-        if (!vx_stark_proof_peek(proof, plen, cfg->cap_height, &ppub, &n_ppub, &pcap) || n_ppub != 10) {
-            if (err && errlen) snprintf(err, errlen, "authority-set commitment proof is malformed");
-            return VX_ERR_STATEMENT;
-        }
+        if (!vx_stark_proof_peek(p0 + l0 + l1, l2, cfg->cap_height, &ppub, &n_ppub, &pcap) || n_ppub != 10) return bad("authority-set commitment proof is malformed");
         spub[8] = ppub[8], spub[9] = 0;
-        return vx_stark_verify(cfg, proof, plen, VX_AIR_SHA_CHAIN, spub, 10, err, errlen);
-    };
-    rc = verify_set(p0 + l0, l1, authority_set_hash);
-    if (rc != VX_OK) return rc;
-    return verify_set(p0 + l0 + l1, l2, out32);
+        return vx_stark_verify(cfg, p0 + l0 + l1, l2, VX_AIR_SHA_CHAIN, spub, 10, err, errlen);
+    }
 }
 
 }  // extern "C"

@@ -15,6 +15,7 @@
 #include "air_sha512.cuh"
 #include "air_sha_tree.cuh"
 #include "poseidon_constants.h"
+#include "vx_bus.h"
 #include "vx_internal.h"
 
 namespace {
@@ -473,6 +474,46 @@ int32_t vx_stark_verify_ext(const vx_stark_config* cfg, const uint64_t* pr, size
     return VX_OK;
 }
 
+// host-side shared challenges for verifiers outside this file
+void vx_shared_challenges_host(const uint64_t* const* pubs, const size_t* n_pubs, const uint64_t* const* caps, size_t k, size_t cap_words, uint64_t* out, size_t n_out) {
+    v_shared_challenges_n(pubs, n_pubs, caps, k, cap_words, out, n_out);
+}
+
+// Expected public inputs and AIR ids of the three justification tables (vx_bus.h).
+int32_t vx_justification_expect(const uint64_t* ppub_chain, size_t n_chain, const uint64_t* ppub_ed, size_t n_ed, size_t n_s512, const uint8_t authority_set_hash[32],
+                                uint64_t authority_set_id, const uint8_t block_hash[32], uint32_t block_number, uint64_t round, uint64_t spub[10], uint64_t epub[2],
+                                uint64_t hpub[15], int air[3], char* err, size_t errlen) {
+    NEED(n_chain == 10 && n_ed == 2 && n_s512 == 15, "justification proofs have the wrong number of public inputs");
+    // the request's authority_set_hash must be the proven commitment; the number of authorities it binds and the number of verified
+    // signatures are read from the proofs: signed * 3 > authorities * 2 (justification.rs:164-186)
+    for (int j = 0; j < 8; ++j)
+        spub[j] = ((uint64_t)authority_set_hash[4 * j] << 24) | ((uint64_t)authority_set_hash[4 * j + 1] << 16) | ((uint64_t)authority_set_hash[4 * j + 2] << 8) |
+                  authority_set_hash[4 * j + 3];
+    const uint64_t n_auth = ppub_chain[8], n_signed = ppub_ed[0];
+    NEED(n_auth >= 1 && n_auth <= 512 && n_signed <= n_auth, "implausible authority counts");
+    NEED(n_signed * 3 > n_auth * 2, "fewer than 2/3 of the authority set signed (%llu of %llu)", (unsigned long long)n_signed, (unsigned long long)n_auth);
+    spub[8] = n_auth, spub[9] = 1;
+    epub[0] = n_signed, epub[1] = 1;
+    air[0] = VX_AIR_SHA_CHAIN;
+    air[1] = n_signed <= 255 ? VX_AIR_ED25519_16 : VX_AIR_ED25519;  // the tables are sized by the number of signatures they verify
+    air[2] = n_signed <= 6 ? VX_AIR_SHA512_10 : n_signed <= 204 ? VX_AIR_SHA512_15 : VX_AIR_SHA512;
+    // the signed message: the precommit for (block hash, block number, round, set id) -- decoder.rs:159-200
+    uint8_t msg[64];
+    memset(msg, 0, sizeof msg);
+    msg[0] = 1;
+    memcpy(msg + 1, block_hash, 32);
+    for (int b = 0; b < 4; ++b) msg[33 + b] = (uint8_t)(block_number >> (8 * b));
+    for (int b = 0; b < 8; ++b) msg[37 + b] = (uint8_t)(round >> (8 * b)), msg[45 + b] = (uint8_t)(authority_set_id >> (8 * b));
+    msg[53] = 0x80;
+    for (int j = 0; j < 7; ++j) {
+        uint64_t v = 0;
+        for (int b = 0; b < 8; ++b) v = (v << 8) | msg[8 * j + b];
+        hpub[2 * j] = v & 0xFFFFFFFFULL, hpub[2 * j + 1] = v >> 32;
+    }
+    hpub[14] = 1;
+    return VX_OK;
+}
+
 extern "C" {
 
 int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob, size_t len, uint32_t max_headers,
@@ -525,34 +566,9 @@ int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob,
     const uint64_t* want[5] = {pub, tpub, spub, epub, hpub};
     const size_t n_want[5] = {20, 16, 10, 2, 15};
     if (justified) {
-        NEED(npub[2] == 10 && npub[3] == 2 && npub[4] == 15, "justification proofs have the wrong number of public inputs");
-        // the EVM input `authority_set_hash` (header_range.rs:35) must be the proven commitment; the number of authorities it binds
-        // and the number of verified signatures are read from the proofs: signed * 3 > authorities * 2 (justification.rs:164-186)
-        for (int j = 0; j < 8; ++j)
-            spub[j] = ((uint64_t)authority_set_hash[4 * j] << 24) | ((uint64_t)authority_set_hash[4 * j + 1] << 16) | ((uint64_t)authority_set_hash[4 * j + 2] << 8) |
-                      authority_set_hash[4 * j + 3];
-        const uint64_t n_auth = ppub[2][8], n_signed = ppub[3][0];
-        NEED(n_auth >= 1 && n_auth <= 512 && n_signed <= n_auth, "implausible authority counts");
-        NEED(n_signed * 3 > n_auth * 2, "fewer than 2/3 of the authority set signed (%llu of %llu)", (unsigned long long)n_signed, (unsigned long long)n_auth);
-        spub[8] = n_auth, spub[9] = 1;
-        epub[0] = n_signed, epub[1] = 1;
-        air[3] = n_signed <= 255 ? VX_AIR_ED25519_16 : VX_AIR_ED25519;  // the tables are sized by the number of signatures they verify
-        air[4] = n_signed <= 6 ? VX_AIR_SHA512_10 : n_signed <= 204 ? VX_AIR_SHA512_15 : VX_AIR_SHA512;
-        // the signed message: the precommit for (target header hash, target block, round, set id) -- decoder.rs:159-200
-        uint8_t msg[64];
-        memset(msg, 0, sizeof msg);
-        msg[0] = 1;
-        memcpy(msg + 1, out96, 32);
-        const uint64_t round = blob[21];
-        for (int b = 0; b < 4; ++b) msg[33 + b] = (uint8_t)(target_block >> (8 * b));
-        for (int b = 0; b < 8; ++b) msg[37 + b] = (uint8_t)(round >> (8 * b)), msg[45 + b] = (uint8_t)(authority_set_id >> (8 * b));
-        msg[53] = 0x80;
-        for (int j = 0; j < 7; ++j) {
-            uint64_t v = 0;
-            for (int b = 0; b < 8; ++b) v = (v << 8) | msg[8 * j + b];
-            hpub[2 * j] = v & 0xFFFFFFFFULL, hpub[2 * j + 1] = v >> 32;
-        }
-        hpub[14] = 1;
+        const int32_t rc = vx_justification_expect(ppub[2], npub[2], ppub[3], npub[3], npub[4], authority_set_hash, authority_set_id, out96, target_block, blob[21], spub, epub,
+                                                   hpub, air + 2, err, errlen);
+        if (rc != VX_OK) return rc;
     }
     // the lookup challenges every proof must have used: a transcript of all public inputs and trace caps
     uint64_t chal[4];

@@ -211,10 +211,17 @@ def rotate_verify(blob, authority_set_id, authority_set_hash, out32, cfg=None):
         raise VxError(rc, err.value.decode())
 
 
+ROT_HDR = 26  # words before the first proof in a rotate blob
+
+
 def split_rotate_blob(blob):
-    """-> (header-hash proof, current-set commitment proof, new-set commitment proof) of a vx_rotate_prove blob."""
-    l0, l1, l2 = int(blob[16]), int(blob[17]), int(blob[18])
-    return blob[24:24 + l0], blob[24 + l0:24 + l0 + l1], blob[24 + l0 + l1:24 + l0 + l1 + l2]
+    """-> (header-hash proof, current-set commitment proof, new-set commitment proof, Ed25519 proof, SHA-512 proof) of a
+    vx_rotate_prove blob."""
+    out, off = [], ROT_HDR
+    for ln in (int(blob[16]), int(blob[17]), int(blob[18]), int(blob[19]), int(blob[24])):
+        out.append(blob[off: off + ln])
+        off += ln
+    return tuple(out)
 
 
 class Buffer:

@@ -76,19 +76,29 @@ def test_rotate_prove_small(ctx, vx):
     why, want = R.rotate(e.padded.tobytes(), e.size, 140000, 5, e.start_position, e.new_pubkeys, 3, sj.authority_set_hash, sj, max_authorities=12)
     assert why is None and out32 == want == e.new_authority_set_hash
     assert blob[4:8].tobytes() == e.hash and blob[8:12].tobytes() == sj.authority_set_hash and blob[12:16].tobytes() == out32
-    p0, p1, p2 = vx.lib.split_rotate_blob(blob)
+    p0, p1, p2, p_ed, p_h = vx.lib.split_rotate_blob(blob)
     limbs = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "little") for j in range(8)]  # noqa: E731
     info = S.verify(p0, pcfg, expect_air=B.ID)
     assert info["public_inputs"] == limbs(e.bytes[:32]) + limbs(e.hash) + [140000, 140000, 0, 0]  # stand-alone: nothing on the bus
     be = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "big") for j in range(8)]  # noqa: E731
-    assert S.verify(p1, pcfg, expect_air=A.ID)["public_inputs"][:8] == be(sj.authority_set_hash)
-    assert S.verify(p2, pcfg, expect_air=A.ID)["public_inputs"][:8] == be(out32)
+    assert S.verify(p2, pcfg, expect_air=A.ID)["public_inputs"] == be(out32) + [5, 0]  # the new set: 5 keys, stand-alone
+    # the justification by the current set: commitment, Ed25519 and SHA-512 tables on one bus (reference verifier)
+    from oracle import ed_air as E
+    from oracle import sha512_air as H5
+
+    for air in (E.make_air(16), H5.make_air(10)):
+        S.register_air(air)
+    tables = [(p1, A.ID), (p_ed, E.IDS[16]), (p_h, H5.IDS[10])]
+    chal = S.shared_challenges_n([S.proof_peek(p, 4) for p, _ in tables], 4)
+    infos = [S.verify(p, pcfg, expect_air=air, ext_chal=chal) for p, air in tables]
+    assert infos[0]["public_inputs"] == be(sj.authority_set_hash) + [7, 1] and infos[1]["public_inputs"] == [5, 1]
+    assert all(sum(i["aux_public"][q] * (1 << i["degree_bits"]) for i in infos) % B.P == 0 for q in range(2)), "bus does not balance"
     # product verifier: accepts, and is bound to the request and the claimed output
     vx.lib.rotate_verify(blob, 3, sj.authority_set_hash, out32, cfg)
     for args in ((4, sj.authority_set_hash, out32), (3, bytes(32), out32), (3, sj.authority_set_hash, bytes(32))):
         with pytest.raises(vx.VxError):
             vx.lib.rotate_verify(blob, *args, cfg)
-    for word in (5, 21, 24 + int(blob[16]) // 2, 24 + int(blob[16]) + 40, len(blob) - 7):
+    for word in (5, 21, 25, 26 + int(blob[16]) // 2, 26 + int(blob[16]) + 40, len(blob) - 7):  # (25: the precommit's round)
         bad = blob.copy()
         bad[word] ^= np.uint64(1)
         with pytest.raises(vx.VxError):

@@ -18,7 +18,7 @@ end = next((i for i in range(s, len(rows)) if rows[i][0].startswith("k_fill_rand
 rows = rows[:end]
 agg = {}
 for r in rows[s:]:
-    nm = r[0].split("(")[0].replace("void ", "")[:44]
+    nm = r[0].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:44]
     d = (r[2] - r[1]) / 1e3
     if "--timeline" in sys.argv:
         print(f"{(r[1] - t0) / 1e6:9.3f} ms  {d:9.1f} us  {nm:46s} grid={r[3]:>10} vgpr={r[5]} scratch={r[6]}")
