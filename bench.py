@@ -447,11 +447,12 @@ def main():
                 "workload": "rotate: 15,360-B synthetic epoch-end header carrying a 300-validator ScheduledChange log, justified by 201 of 300 "
                             "current authorities; one input per GPU",
                 "complete_proof": False,
-                "stages": ["BlakeChainAir witness + STARK over the header's 120 compressions (2^16 x 999: one copy of the XOR lookup tables)",
+                "stages": ["BlakeChainAir witness + STARK over the header's 120 compressions (2^16 x 1018: one copy of the XOR lookup tables)",
                            "verify_simple_justification (native on GPU: 201 Ed25519 verifications, precommit, threshold)",
                            "verify_epoch_end_header (native on GPU: prefix, 300 x (pubkey, weight), delay)",
-                           "two ShaChainAir witnesses + STARKs: current and new authority-set commitments (2^16 x 731 each)"],
-                "missing": ["epoch-end header parsing and EdDSA inside a STARK", "recursive aggregation into one proof"],
+                           "two ShaChainAir witnesses + STARKs: current and new authority-set commitments (2^16 x 737 each)",
+                           "the justification by the current set in-proof: EdAir (201 signatures, 2^16 x 1527) + Sha512Air (2^15 x 1059) on one logUp bus with the current set's commitment"],
+                "missing": ["epoch-end header parsing inside a STARK", "recursive aggregation into one proof"],
             }
         elif not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline(vx, ctx)
