@@ -3,8 +3,9 @@
 // reference generates this witness inside curta's EdDSA gadget, starkyx v1.0.0, not vendored).
 //   k_ed_slots   one lane per slot: decode A and R (RFC 8032 5.1.3), B - A in affine form, H = SHA-512(R || A || M),
 //                H = qq l + hr with its carries, the canonical-range witnesses -- everything that is not a gadget result
-//   k_ed_rows    16 lanes per slot (lane k owns limb k of every field element), 4 slots per wave: the 256 rows of a slot in
-//                order; a gadget = 16 multiply-accumulates per lane from operands broadcast through LDS, then the carry
+//   k_ed_rows    one wave per slot, four groups of 16 lanes (lane k of a group owns limb k of every field element): the 256 rows
+//                of a slot in order, the four groups working on the (up to four) independent gadgets of a dependency layer side by
+//                side; a gadget = 16 multiply-accumulates per lane from operands broadcast through LDS, then the carry
 //                normalisation (c = F mod 2q, r_k) which every lane runs redundantly on the 16 coefficients.  Rows go to a
 //                row-major int32 staging buffer (16 lanes write 16 neighbouring cells)
 //   k_ed_expand  staging [n][838] int32 -> trace [838][n] field elements through an LDS tile (negative limbs -> p + v)
@@ -159,50 +160,59 @@ __device__ __forceinline__ void ed_normalise(const int64_t* F, int k, int32_t& c
     }
 }
 
-constexpr int ED_SLOTS_PER_BLOCK = 4;
+// One wave per slot: four groups of 16 lanes (lane k of a group owns limb k).  The gadgets of a row depend on each other in
+// four layers (squares -> doubling products -> addend products -> sums), so the four groups work on the gadgets of one layer
+// side by side and exchange their results through LDS: four gadget latencies per row instead of fourteen.
 __global__ __launch_bounds__(64) void k_ed_rows(const EdSlot* slots, int32_t* stage, size_t k_active, uint32_t* bad) {
-    __shared__ int32_t As[ED_SLOTS_PER_BLOCK][16], Bs[ED_SLOTS_PER_BLOCK][16];
-    __shared__ int64_t Fs[ED_SLOTS_PER_BLOCK][16];
-    const int sl = threadIdx.x >> 4, k = threadIdx.x & 15;
-    const size_t slot = blockIdx.x * (size_t)ED_SLOTS_PER_BLOCK + sl;       // the grid covers slots 0 .. k_active rounded up to 4:
-    const EdSlot& in = slots[slot < k_active ? slot : k_active];             // the extra ones repeat the idle slot
+    __shared__ int32_t As[4][16], Bs[4][16], Cs[4][16];
+    __shared__ int64_t Fs[4][16];
+    const int gi = threadIdx.x >> 4, k = threadIdx.x & 15;
+    const size_t slot = blockIdx.x;                                // slots 0 .. k_active; the last one is the idle slot
+    const EdSlot& in = slots[slot];
     int32_t* row = stage + slot * 256 * (size_t)COLS;
-    // F_k of a * b (both operands: this lane's limb)
+    // F_k of a * b within this lane's group (both operands: this lane's limb)
     auto fold = [&](int32_t a, int32_t b) -> int64_t {
         __syncthreads();
-        As[sl][k] = a, Bs[sl][k] = b;
+        As[gi][k] = a, Bs[gi][k] = b;
         __syncthreads();
         int64_t acc = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int j = k - i;
-            acc += (int64_t)As[sl][i] * (j >= 0 ? (int64_t)Bs[sl][j] : 38 * (int64_t)Bs[sl][j + 16]);
+            acc += (int64_t)As[gi][i] * (j >= 0 ? (int64_t)Bs[gi][j] : 38 * (int64_t)Bs[gi][j + 16]);
         }
         return acc;
     };
-    // gadget g of the current row from its coefficient F_k: writes c (or `store` for a zero-check) and the carry cells; returns c_k
+    // gadget g (< 0: this group idles) of the current row from its coefficient F_k: writes c (or `store` for a zero-check) and
+    // the carry cells, publishes c to the other groups; returns c_k
     auto finish = [&](int g, int64_t Fk, bool has_c, int32_t store) -> int32_t {
         __syncthreads();
-        Fs[sl][k] = has_c ? Fk : 2 * Fk;
+        Fs[gi][k] = has_c ? Fk : 2 * Fk;
         __syncthreads();
         int32_t c = 0;
         int64_t r = 0;
-        ed_normalise(Fs[sl], k, c, r);
-        if (!has_c && c != 0) atomicAdd(bad, 1u);  // a zero-check that does not vanish: the signature equation fails
-        const int64_t rr = r + (1LL << 31);
-        row[C(g, k)] = has_c ? c : store;
-        row[RL(g, k)] = (int32_t)(rr & 0xFFFF), row[RH(g, k)] = (int32_t)(rr >> 16);
+        ed_normalise(Fs[gi], k, c, r);
+        if (g >= 0) {
+            if (!has_c && c != 0) atomicAdd(bad, 1u);  // a zero-check that does not vanish: the signature equation fails
+            const int64_t rr = r + (1LL << 31);
+            row[C(g, k)] = has_c ? c : store;
+            row[RL(g, k)] = (int32_t)(rr & 0xFFFF), row[RH(g, k)] = (int32_t)(rr >> 16);
+        }
+        Cs[gi][k] = c;
+        __syncthreads();
         return c;
     };
-    auto mul = [&](int g, int32_t a, int32_t b) -> int32_t { return finish(g, fold(a, b), true, 0); };
     auto kk = [&](int t) -> int32_t { return (int32_t)KT[t][k]; };
+    auto pick = [&](int32_t v0, int32_t v1, int32_t v2, int32_t v3) -> int32_t { return gi == 0 ? v0 : gi == 1 ? v1 : gi == 2 ? v2 : v3; };
     const int32_t xa = in.xa[k], ya = in.ya[k], x3 = in.x3[k], y3 = in.y3[k], one_k = k == 0;
-    // every row: the slot registers; rows other than STEP rows: zero cells first
     auto clear = [&]() {
-        for (int col = k; col < COLS; col += 16) row[col] = 0;
+        for (int col = threadIdx.x; col < COLS; col += 64) row[col] = 0;
+        __syncthreads();
     };
     int32_t nt = 0, bt = 0;
+    // the slot registers of a row (group 0 writes them)
     auto registers = [&](int32_t bs, int32_t bh, int32_t lah) {
+        if (gi) return;
         row[XA0 + k] = xa, row[YA0 + k] = ya, row[NT0 + k] = nt, row[X30 + k] = x3, row[Y30 + k] = y3, row[BT0 + k] = bt, row[HR0 + k] = in.hr[k];
         const int32_t w11 = bs & bh, w10 = bs - w11, w01 = bh - w11, w00 = 1 - bs - bh + w11;
         row[SEL0 + k] = w00 * one_k + w10 * kk(K_BC0) + w01 * (ya + xa) + w11 * (y3 - x3);
@@ -210,33 +220,41 @@ __global__ __launch_bounds__(64) void k_ed_rows(const EdSlot* slots, int32_t* st
         row[SEL0 + 32 + k] = w10 * kk(K_BC2) + w01 * nt + w11 * bt;
         if (k < 7) row[BS + k] = k == 0 ? bs : k == 1 ? bh : k == 2 ? lah : k == 3 ? (int32_t)in.sg : k == 4 ? (int32_t)in.cnt : k == 5 ? 0 : (int32_t)in.aidx;  // BS BH LAH SG CNT MULT AIDX
     };
-    // ---- row 0: SETUP-A
+    // ---- row 0: SETUP-A.  Layers: (u, xx, yy, v) -> (nt2d, dxx, t, bt2d) -> the three zero-checks
     clear();
     {
-        const int32_t u = mul(0, xa, ya);
-        nt = mul(1, u, kk(K_2DN));
-        const int32_t xx = mul(2, xa, xa), yy = mul(3, ya, ya), dxx = mul(4, xx, kk(K_D));
-        finish(5, (int64_t)yy - xx - one_k - fold(dxx, yy), false, xa);
-        const int32_t t = mul(6, u, kk(K_BD));
-        finish(7, fold(x3, one_k + t) - fold(ya, kk(K_XB)) + fold(xa, kk(K_YB)), false, ya);
-        finish(8, fold(y3, one_k - t) - fold(ya, kk(K_YB)) + fold(xa, kk(K_XB)), false, x3);
-        const int32_t v = mul(9, x3, y3);
-        bt = mul(10, v, kk(K_2D));
-        row[C(11, k)] = y3;
-        row[C(12, k)] = in.wxa[k], row[C(13, k)] = in.wya[k];
-        if (k < 15) row[RL(12, k)] = in.cxa[k], row[RL(13, k)] = in.cya[k];
-        if (k == 0) row[RH(12, 0)] = xa >> 1;
+        const int g1[4] = {0, 2, 3, 9};
+        (void)finish(g1[gi], fold(pick(xa, xa, ya, x3), pick(ya, xa, ya, y3)), true, 0);
+        const int32_t u = Cs[0][k], xx = Cs[1][k], yy = Cs[2][k], v = Cs[3][k];
+        const int g2[4] = {1, 4, 6, 10};
+        (void)finish(g2[gi], fold(pick(u, xx, u, v), pick(kk(K_2DN), kk(K_D), kk(K_BD), kk(K_2D))), true, 0);
+        nt = Cs[0][k], bt = Cs[3][k];
+        const int32_t dxx = Cs[1][k], t = Cs[2][k];
+        // group 0: yy - xx - 1 - dxx yy; group 1: x3 (1 + t) - yA xB + xA yB; group 2: y3 (1 - t) - yA yB + xA xB
+        const int64_t f1 = fold(pick(dxx, x3, y3, 0), pick(yy, one_k + t, one_k - t, 0));
+        const int64_t f2 = fold(pick(0, ya, ya, 0), pick(0, kk(K_XB), kk(K_YB), 0));
+        const int64_t f3 = fold(pick(0, xa, xa, 0), pick(0, kk(K_YB), kk(K_XB), 0));
+        const int g3[4] = {5, 7, 8, -1};
+        (void)finish(g3[gi], gi == 0 ? (int64_t)yy - xx - one_k - f1 : f1 - f2 + f3, false, pick(xa, ya, x3, 0));
+        if (gi == 0) {
+            row[C(11, k)] = y3;
+            row[C(12, k)] = in.wxa[k], row[C(13, k)] = in.wya[k];
+            if (k < 15) row[RL(12, k)] = in.cxa[k], row[RL(13, k)] = in.cya[k];
+            if (k == 0) row[RH(12, 0)] = xa >> 1;
+        }
         registers((int32_t)in.sign_a, 0, 0);
     }
     // ---- row 1: SETUP-B
     row += COLS;
     clear();
-    row[C(0, k)] = in.hl[k], row[RL(0, k)] = in.hl[16 + k], row[RH(0, k)] = in.qq[k];
-    row[RL(1, k)] = in.hr[k], row[RH(1, k)] = in.hw[k];
-    row[C(2, k)] = in.crlo[k], row[RL(2, k)] = in.crlo[16 + k], row[C(3, k)] = in.crhi[k], row[RL(3, k)] = in.crhi[16 + k];
-    if (k < 15) row[C(4, k)] = in.chr[k];
-    if (k == 0) row[C(1, 0)] = in.qq[16], row[C(12, 0)] = 1, row[C(13, 0)] = 1;
-    for (int j = k; j < 64; j += 16) row[BYA(j)] = in.dig[j], row[BYB(j)] = 256 * (int32_t)in.dig[j];  // (cell columns are congruent to j mod 16)
+    if (gi == 0) {
+        row[C(0, k)] = in.hl[k], row[RL(0, k)] = in.hl[16 + k], row[RH(0, k)] = in.qq[k];
+        row[RL(1, k)] = in.hr[k], row[RH(1, k)] = in.hw[k];
+        row[C(2, k)] = in.crlo[k], row[RL(2, k)] = in.crlo[16 + k], row[C(3, k)] = in.crhi[k], row[RL(3, k)] = in.crhi[16 + k];
+        if (k < 15) row[C(4, k)] = in.chr[k];
+        if (k == 0) row[C(1, 0)] = in.qq[16], row[C(12, 0)] = 1, row[C(13, 0)] = 1;
+        for (int j = k; j < 64; j += 16) row[BYA(j)] = in.dig[j], row[BYB(j)] = 256 * (int32_t)in.dig[j];  // (cell columns are congruent to j mod 16)
+    }
     registers(0, 0, 0);
     // ---- rows 2..254: STEP
     int32_t X = 0, Y = one_k, Z = one_k, lah = 0;
@@ -246,24 +264,33 @@ __global__ __launch_bounds__(64) void k_ed_rows(const EdSlot* slots, int32_t* st
         const int32_t bs = (in.s[bit >> 5] >> (bit & 31)) & 1, bh = (in.h[bit >> 5] >> (bit & 31)) & 1;
         lah = ((bit == 252 || (bit & 15) == 15) ? 0 : 2 * lah) + bh;
         registers(bs, bh, lah);
-        const int32_t s0 = row[SEL0 + k], s1 = row[SEL0 + 16 + k], s2 = row[SEL0 + 32 + k];
-        const int32_t c0 = mul(0, X, X), c1 = mul(1, Y, Y), c2 = mul(2, Z, Z), c3 = mul(3, X + Y, X + Y);
+        const int32_t w11 = bs & bh, w10 = bs - w11, w01 = bh - w11, w00 = 1 - bs - bh + w11;
+        const int32_t s0 = w00 * one_k + w10 * kk(K_BC0) + w01 * (ya + xa) + w11 * (y3 - x3), s1 = w00 * one_k + w10 * kk(K_BC1) + w01 * (ya - xa) + w11 * (y3 + x3);
+        const int32_t s2 = w10 * kk(K_BC2) + w01 * nt + w11 * bt;
+        const int32_t q = pick(X, Y, Z, X + Y);
+        (void)finish(gi, fold(q, q), true, 0);
+        const int32_t c0 = Cs[0][k], c1 = Cs[1][k], c2 = Cs[2][k], c3 = Cs[3][k];
         const int32_t E = c3 - c0 - c1, G = c1 - c0, F = G - 2 * c2, H = -c0 - c1;
-        const int32_t c4 = mul(4, E, F), c5 = mul(5, G, H), c6 = mul(6, E, H), c7 = mul(7, F, G);
-        const int32_t c8 = mul(8, c5 - c4, s0), c9 = mul(9, c5 + c4, s1), c10 = mul(10, c6, s2);
+        (void)finish(4 + gi, fold(pick(E, G, E, F), pick(F, H, H, G)), true, 0);
+        const int32_t c4 = Cs[0][k], c5 = Cs[1][k], c6 = Cs[2][k], c7 = Cs[3][k];
+        (void)finish(gi < 3 ? 8 + gi : -1, fold(pick(c5 - c4, c5 + c4, c6, 0), pick(s0, s1, s2, 0)), true, 0);
+        const int32_t c8 = Cs[0][k], c9 = Cs[1][k], c10 = Cs[2][k];
         const int32_t E2 = c9 - c8, F2 = 2 * c7 - c10, G2 = 2 * c7 + c10, H2 = c9 + c8;
-        X = mul(11, E2, F2), Y = mul(12, G2, H2), Z = mul(13, F2, G2);
+        (void)finish(gi < 3 ? 11 + gi : -1, fold(pick(E2, G2, F2, 0), pick(F2, H2, G2, 0)), true, 0);
+        X = Cs[0][k], Y = Cs[1][k], Z = Cs[2][k];
     }
     // ---- row 255: FINAL
     row += COLS;
     clear();
     {
         const int32_t xr = in.xr[k], yr = in.yr[k];
-        finish(0, fold(xr, Z) - X, false, xr);
-        finish(1, fold(yr, Z) - Y, false, yr);
-        row[C(2, k)] = in.wxr[k], row[C(3, k)] = in.wyr[k];
-        if (k < 15) row[RL(2, k)] = in.cxr[k], row[RL(3, k)] = in.cyr[k];
-        if (k == 0) row[RH(2, 0)] = xr >> 1;
+        const int64_t f = fold(pick(xr, yr, 0, 0), pick(Z, Z, 0, 0));
+        (void)finish(gi < 2 ? gi : -1, f - pick(X, Y, 0, 0), false, pick(xr, yr, 0, 0));
+        if (gi == 0) {
+            row[C(2, k)] = in.wxr[k], row[C(3, k)] = in.wyr[k];
+            if (k < 15) row[RL(2, k)] = in.cxr[k], row[RL(3, k)] = in.cyr[k];
+            if (k == 0) row[RH(2, 0)] = xr >> 1;
+        }
         registers((int32_t)in.sign_r, 0, lah);
     }
 }
@@ -392,7 +419,7 @@ int32_t vx_ed_trace_dev(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* sigs
     std::vector<uint32_t> idx;  // compact slots: slot s verifies the s-th flagged authority
     for (size_t s = 0; s < n_sigs; ++s)
         if (signed_flags[s]) idx.push_back((uint32_t)s);
-    const size_t k = idx.size(), k4 = (k + 1 + ED_SLOTS_PER_BLOCK - 1) / ED_SLOTS_PER_BLOCK * ED_SLOTS_PER_BLOCK;  // staged slots: the active ones + the idle one, rounded up
+    const size_t k = idx.size(), k4 = k + 1;  // staged slots: the active ones + the idle one
     VX_CHECK(k < m, "ed trace: %zu signatures do not fit the %zu slots of 2^%d rows (one slot stays idle)", k, m - 1, log_n);
     // device scratch: keys | sigs | msg | idx | bad | slots | hist, then the staging buffer from the pool
     const size_t w_keys = 4 * n_sigs + 1, w_sigs = 8 * n_sigs + 1, w_msg = 8, w_idx = (k + 1) / 2 + 1, w_slots = ((k + 1) * sizeof(EdSlot) + 7) / 8;
@@ -417,7 +444,7 @@ int32_t vx_ed_trace_dev(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* sigs
     int32_t* stage = (int32_t*)vx_pool_alloc(ctx, k4 * 256 * (size_t)COLS * 4);
     if (!stage) return vx_fail(ctx, VX_ERR_OOM, "ed trace: out of device memory");
     hipLaunchKernelGGL(k_ed_slots, dim3((unsigned)((k + 1 + 63) / 64)), dim3(64), 0, ctx->stream, d_keys, d_sigs, d_msg, msg_len, (const uint32_t*)d_idx, k, d_slots, d_bad);
-    hipLaunchKernelGGL(k_ed_rows, dim3((unsigned)(k4 / ED_SLOTS_PER_BLOCK)), dim3(64), 0, ctx->stream, (const EdSlot*)d_slots, stage, k, d_bad);
+    hipLaunchKernelGGL(k_ed_rows, dim3((unsigned)k4), dim3(64), 0, ctx->stream, (const EdSlot*)d_slots, stage, k, d_bad);
     hipLaunchKernelGGL(k_ed_expand, dim3((unsigned)(n / 64), (COLS + 63) / 64), dim3(256), 0, ctx->stream, (const int32_t*)stage, trace_d, n, k);
     hipLaunchKernelGGL(k_ed_hist, dim3((unsigned)((k + 1) * 256)), dim3(256), 0, ctx->stream, (const int32_t*)stage, k, (uint32_t)(m - k), d_hist);
     hipLaunchKernelGGL(k_ed_mult, dim3(256), dim3(256), 0, ctx->stream, (const uint32_t*)d_hist, trace_d + (size_t)MULT * n);
