@@ -3,8 +3,8 @@
 // of compute_authority_set_commitment (/root/reference circuits/builder/justification.rs:127-162;
 // native mirror circuits/input/mod.rs:250-260).  The reference proves SHA-256 with curta's STARK
 // (starkyx v1.0.0, not vendored); this AIR is a from-scratch FIPS 180-4 arithmetisation, degree <= 3:
-// one row per round, 64 rows per compression; three-input XORs as x + y + z = r + 2c, Ch as a
-// degree-2 expression, Maj through (maj, parity) bits; block types FIRST / DATA / PAD / IDLE.  731 columns: only the
+// one row per round, 64 rows per compression; the schedule's three-input XORs as x + y + z = r + 2c, Ch as a
+// degree-2 and Sigma0 / Sigma1 / Maj as degree-3 polynomials of bits; block types FIRST / DATA / PAD / IDLE.  539 (+2) columns: only the
 // words an XOR / AND reads are bit-decomposed (see the layout note); the compression rows are shared with ShaTreeAir.
 // Bus to EdAir (air_ed.cuh): a key's block carries a witness flag SGC ("this authority signed"); the key is sent as four
 // tuples (4 index + j, l0 + 2^16 l1, l2 + 2^16 l3, 0, TAG_KEY) of little-endian 16-bit limbs from the rows where its words
@@ -21,12 +21,14 @@ namespace shc {
 // (Sigma0, Maj / Sigma1, Ch), the new a and e, and positions 0, 1, 14 of the 16-word schedule window (w_r enters T1 and a
 // bus, sigma0 reads w_{r+1}, sigma1 reads w_{r+14}).  d, h and the other 13 window positions are single VALUE columns:
 // every such value was, or will be, a bit-decomposed word on another row, and everything downstream works modulo 2^32.
+// Sigma0 / Sigma1 / Ch / Maj have no cells: they are degree-3 polynomials of the state bits inside the (unconditional) round
+// equations; only the schedule's sigma0 / sigma1, whose equation carries a selector, keep (result, carry) bits.
 constexpr int A_ = 0, B_ = 32, C_ = 64, E_ = 96, F_ = 128, G_ = 160, DV = 192, HV = 193, NA0 = 194, NE0 = 226;
 constexpr int W0B = 258, W1B = 290, W14B = 322, WV0 = 354, WV15 = 366;
-constexpr int S0R = 367, S0C = 399, S1R = 431, S1C = 463, E1R = 495, E1C = 527, A0R = 559, A0C = 591, MAJ = 623, PAR = 655;
-constexpr int CE0 = 687, CA0 = 690, CW0 = 693, FFV0 = 695, FFC0 = 703, HIN0 = 711, DG0 = 719;
-constexpr int T_FIRST = 727, T_DATA = 728, T_PAD = 729, T_IDLE = 730, COLS = 731;  // COLS: the compression layout every SHA-256 table shares
-constexpr int SGC = 731, KC = 732, CHAIN_COLS = 733, TAG_KEY = 5;                    // ShaChainAir only
+constexpr int S0R = 367, S0C = 399, S1R = 431, S1C = 463;
+constexpr int CE0 = 495, CA0 = 498, CW0 = 501, FFV0 = 503, FFC0 = 511, HIN0 = 519, DG0 = 527;
+constexpr int T_FIRST = 535, T_DATA = 536, T_PAD = 537, T_IDLE = 538, COLS = 539;  // COLS: the compression layout every SHA-256 table shares
+constexpr int SGC = 539, KC = 540, CHAIN_COLS = 541, TAG_KEY = 5;                    // ShaChainAir only
 VX_HD constexpr int WV(int p) { return p == 15 ? WV15 : WV0 + p - 2; }  // value column of window position p (2..13, 15)
 VX_HD constexpr int st_bits(int wd) { return wd == 0 ? A_ : wd == 1 ? B_ : wd == 2 ? C_ : wd == 4 ? E_ : wd == 5 ? F_ : wd == 6 ? G_ : -1; }
 #define SHC_IV_INIT {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19}
@@ -90,21 +92,34 @@ __host__ __device__ inline void sha_compression_constraints(const Row& loc, cons
     };
     xor3(W1B, 7, 18, 0, 3, S0R, S0C);
     xor3(W14B, 17, 19, 0, 10, S1R, S1C);
-    xor3(E_, 6, 11, 25, -1, E1R, E1C);
-    xor3(A_, 2, 13, 22, -1, A0R, A0C);
-#pragma unroll 1
-    for (int i = 0; i < 32; ++i) c.constraint(loc[A_ + i] + loc[B_ + i] + loc[C_ + i] - two * loc[MAJ + i] - loc[PAR + i]);
-    // ---- 3. the round
+    // ---- 3. the round (local, every row): Sigma / Ch / Maj as degree-3 polynomials of the state bits
     {
-        F ch = F::from(0);
+        const F four = F::from(4);
+        auto x3 = [&](int col0, int r0, int r1, int r2) -> F {
+            F acc = F::from(0);
+#pragma unroll 1
+            for (int i = 31; i >= 0; --i) {
+                const F x = loc[col0 + ((i + r0) & 31)], y = loc[col0 + ((i + r1) & 31)], z = loc[col0 + ((i + r2) & 31)];
+                const F xy = x * y;
+                acc = acc + acc + (x + y + z - two * (xy + (x + y) * z) + four * (xy * z));
+            }
+            return acc;
+        };
+        F ch = F::from(0), mj = F::from(0);
 #pragma unroll 1
         for (int i = 31; i >= 0; --i) {
             const F e = loc[E_ + i], f = loc[F_ + i], g = loc[G_ + i];
             ch = ch + ch + (e * f + (one - e) * g);
         }
-        const F t1 = loc[HV] + val(loc, E1R, 32) + ch + kr + val(loc, W0B, 32);
+#pragma unroll 1
+        for (int i = 31; i >= 0; --i) {
+            const F a = loc[A_ + i], b = loc[B_ + i], cc = loc[C_ + i];
+            const F ab = a * b;
+            mj = mj + mj + (ab + (a + b) * cc - two * (ab * cc));
+        }
+        const F t1 = loc[HV] + x3(E_, 6, 11, 25) + ch + kr + val(loc, W0B, 32);
         c.constraint(val(loc, NE0, 32) + two32 * val(loc, CE0, 3) - (loc[DV] + t1));
-        c.constraint(val(loc, NA0, 32) + two32 * val(loc, CA0, 3) - (t1 + val(loc, A0R, 32) + val(loc, MAJ, 32)));
+        c.constraint(val(loc, NA0, 32) + two32 * val(loc, CA0, 3) - (t1 + x3(A_, 2, 13, 22) + mj));
     }
     // ---- 4. state shift inside a block
 #pragma unroll 1

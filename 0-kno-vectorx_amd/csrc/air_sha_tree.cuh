@@ -6,7 +6,7 @@
 // the Blake2b AIR (air_blake.cuh) over a logUp bus, so the roots are bound to the very header bytes that were hashed.
 // A node takes 128 rows: the DATA compression of l || r (start state IV) and the constant PAD compression of a 64-byte
 // message; node g of tree t sits at rows 128 (t N + g) in heap numbering (1 = root, children 2g / 2g+1, leaves N..2N-1,
-// slot 0 a dummy).  Compression rows and column layout are ShaChainAir's (air_sha.cuh, 731 columns); everything positional is a
+// slot 0 a dummy).  Compression rows and column layout are ShaChainAir's (air_sha.cuh, 539 columns); everything positional is a
 // PERIODIC column; the only other witness is the pair of leaf-enable flags ENL / ENR of a bottom-level node (a disabled
 // leaf must be zero and takes nothing from the bus).  Row r < 16 of a DATA block receives message word r:
 //   inner nodes and the bottom level of tree 0:  (tree, child id, r mod 8, word, TAG_WORD)

@@ -75,13 +75,6 @@ __global__ __launch_bounds__(256) void k_sha_trace(const ShaBlock* blocks, uint6
     const uint32_t w1 = w[r + 1], w14 = w[r + 14];
     sxor3(tr, n, row, s_rotr(w1, 7), s_rotr(w1, 18), w1 >> 3, S0R, S0C);
     sxor3(tr, n, row, s_rotr(w14, 17), s_rotr(w14, 19), w14 >> 10, S1R, S1C);
-    sxor3(tr, n, row, s_rotr(e, 6), s_rotr(e, 11), s_rotr(e, 25), E1R, E1C);
-    sxor3(tr, n, row, s_rotr(a, 2), s_rotr(a, 13), s_rotr(a, 22), A0R, A0C);
-    for (int i = 0; i < 32; ++i) {
-        const uint32_t sm = ((a >> i) & 1) + ((bb >> i) & 1) + ((c >> i) & 1);
-        tr[(size_t)(MAJ + i) * n + row] = sm >> 1;
-        tr[(size_t)(PAR + i) * n + row] = sm & 1;
-    }
     sbits(tr, n, row, CE0, ne_full >> 32, 3);
     sbits(tr, n, row, CA0, na_full >> 32, 3);
     uint64_t cw = 0;
@@ -105,7 +98,7 @@ __global__ __launch_bounds__(256) void k_sha_trace(const ShaBlock* blocks, uint6
     tr[(size_t)T_DATA * n + row] = b.type == SB_DATA;
     tr[(size_t)T_PAD * n + row] = b.type == SB_PAD;
     tr[(size_t)T_IDLE * n + row] = b.type == SB_IDLE;
-    if (b.type != SB_TREE) tr[(size_t)SGC * n + row] = b.sgc, tr[(size_t)KC * n + row] = b.kc;  // (the tree table has 731 columns)
+    if (b.type != SB_TREE) tr[(size_t)SGC * n + row] = b.sgc, tr[(size_t)KC * n + row] = b.kc;  // (the tree table has 539 columns)
 }
 
 // auxiliary columns of ShaChainAir: the key sends of signed blocks, one lane per row

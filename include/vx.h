@@ -219,12 +219,12 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
 
 /* ---- K8: ShaChainAir trace generation (compute_authority_set_commitment, justification.rs:127-162):
  * the chained SHA-256 commitment h_0 = SHA256(pk_0), h_i = SHA256(h_{i-1} || pk_i) over n_keys 32-byte
- * keys (host buffer).  Writes the 733-column trace (64 rows per compression, 2*n_keys - 1
+ * keys (host buffer).  Writes the 541-column trace (64 rows per compression, 2*n_keys - 1
  * compressions, padded with idle blocks), the 10 public inputs (the commitment as big-endian words, the
  * number of keys, bus_on) and optionally the 32 commitment bytes.  signed_flags (may be NULL = none) marks
  * the keys whose signatures the EdDSA table verifies; with bus_on they are sent to it over the lookup bus
  * (bus_on = 0: a stand-alone proof).  Prove with vx_stark_prove(ctx, VX_AIR_SHA_CHAIN, ...). */
-enum { VX_AIR_SHA_CHAIN = 4, VX_SHA_AIR_COLS = 733, VX_SHA_AIR_AUX_COLS = 4, VX_SHA_TREE_AIR_COLS = 731 /* the Merkle AIRs 7 / 8 / 9 */ };
+enum { VX_AIR_SHA_CHAIN = 4, VX_SHA_AIR_COLS = 541, VX_SHA_AIR_AUX_COLS = 4, VX_SHA_TREE_AIR_COLS = 539 /* the Merkle AIRs 7 / 8 / 9 */ };
 int32_t vx_sha_chain_trace(vx_ctx* ctx, const uint8_t* pubkeys, size_t n_keys, const uint8_t* signed_flags, uint32_t bus_on, int log_n, vx_buf* trace_out,
                            uint64_t public_inputs_out[10], uint8_t commitment_out[32]);
 

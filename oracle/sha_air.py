@@ -42,7 +42,9 @@ TAIL32 = [0x80000000] + [0] * 6 + [256]  # words 8..15 of the single block of a 
 # state (Sigma0, Maj / Sigma1, Ch), the new a and e, and positions 0, 1, 14 of the 16-word schedule window (w_r enters T1
 # and the bus, sigma0 reads w_{r+1}, sigma1 reads w_{r+14}).  d, h and the other 13 window positions are single VALUE
 # columns: every such value was, or will be, a bit-decomposed word on another row (d = c of the previous row, a window
-# word reaches position 14 and later position 1), and everything downstream works modulo 2^32.
+# word reaches position 14 and later position 1), and everything downstream works modulo 2^32.  Sigma0 / Sigma1 / Ch / Maj
+# have NO cells: they are degree-3 polynomials of the state bits inside the (unconditional) round equations; only the
+# schedule's sigma0 / sigma1, whose equation carries a selector, keep (result, carry) bits.
 A_, B_, C_, E_, F_, G_ = 0, 32, 64, 96, 128, 160   # state words held as bits
 DV, HV = 192, 193                                  # state words d, h as values
 NA0, NE0 = 194, 226
@@ -50,16 +52,14 @@ W0B, W1B, W14B = 258, 290, 322                     # window positions 0, 1, 14 a
 WV0 = 354                                          # WV(p) = WV0 + p - 2 for p = 2..13; position 15 at WV15
 WV15 = 366
 S0R, S0C, S1R, S1C = 367, 399, 431, 463            # sigma0(W[1]), sigma1(W[14]): result and carry bits
-E1R, E1C, A0R, A0C = 495, 527, 559, 591            # Sigma1(e), Sigma0(a)
-MAJ, PAR = 623, 655
-CE0, CA0, CW0 = 687, 690, 693                      # carries: 3 + 3 + 2 bits
-FFV0 = 695         # feed-forward words (values): H_in + state_64 - 2^32 carry
-FFC0 = 703         # 8 feed-forward carry bits
-HIN0 = 711         # 8 initial-state words (values)
-DG0 = 719          # digest register, 8 words (values)
-T_FIRST, T_DATA, T_PAD, T_IDLE = 727, 728, 729, 730
-COLS = 731         # the compression layout every SHA-256 table shares
-SGC, KC, CHAIN_COLS = 731, 732, 733   # ShaChainAir only: the "signed" flag of a key's block, the key counter
+CE0, CA0, CW0 = 495, 498, 501                      # carries: 3 + 3 + 2 bits
+FFV0 = 503         # feed-forward words (values): H_in + state_64 - 2^32 carry
+FFC0 = 511         # 8 feed-forward carry bits
+HIN0 = 519         # 8 initial-state words (values)
+DG0 = 527          # digest register, 8 words (values)
+T_FIRST, T_DATA, T_PAD, T_IDLE = 535, 536, 537, 538
+COLS = 539         # the compression layout every SHA-256 table shares
+SGC, KC, CHAIN_COLS = 539, 540, 541   # ShaChainAir only: the "signed" flag of a key's block, the key counter
 BIT_RANGES = [(0, DV), (NA0, WV0), (S0R, FFV0), (FFC0, HIN0)]  # every boolean column
 PUB = 10           # digest words, number of keys, bus_on
 PERIODIC = 4       # sel_0, sel_63, sched_on (r <= 47), K_r  (+ 3 for ShaChainAir: key-send rows of FIRST / DATA blocks, j)
@@ -165,11 +165,6 @@ def fill_block(tr, base, h_in, block):
             tr[WV(p), row] = w[p]
         xor3(row, rotr(w[1], 7), rotr(w[1], 18), w[1] >> 3, S0R, S0C)
         xor3(row, rotr(w[14], 17), rotr(w[14], 19), w[14] >> 10, S1R, S1C)
-        xor3(row, rotr(e, 6), rotr(e, 11), rotr(e, 25), E1R, E1C)
-        xor3(row, rotr(a, 2), rotr(a, 13), rotr(a, 22), A0R, A0C)
-        for i in range(32):
-            sm = ((a >> i) & 1) + ((b >> i) & 1) + ((c >> i) & 1)
-            tr[MAJ + i, row], tr[PAR + i, row] = sm >> 1, sm & 1
         bits(row, CE0, rec["ce"], 3)
         bits(row, CA0, rec["ca"], 3)
         if r <= 47:
@@ -254,19 +249,31 @@ def compression_constraints(loc, nxt, per, c, data_flag):
 
     xor3(W1B, (7, 18), 3, S0R, S0C)
     xor3(W14B, (17, 19), 10, S1R, S1C)
-    xor3(E_, (6, 11, 25), None, E1R, E1C)
-    xor3(A_, (2, 13, 22), None, A0R, A0C)
-    for i in range(32):
-        c.constraint(loc[A_ + i] + loc[B_ + i] + loc[C_ + i] - 2 * loc[MAJ + i] - loc[PAR + i])
-    # ---- 3. the round (local): T1 = h + Sigma1(e) + Ch(e,f,g) + K_r + w_r
-    ch = None
-    for i in range(31, -1, -1):
-        e, f, g = loc[E_ + i], loc[F_ + i], loc[G_ + i]
-        bit = e * f + (1 - e) * g
-        ch = bit if ch is None else ch + ch + bit
-    t1 = loc[HV] + val(loc, E1R) + ch + kr + val(loc, W0B)
+
+    # ---- 3. the round (local, every row): T1 = h + Sigma1(e) + Ch(e,f,g) + K_r + w_r; Sigma / Ch / Maj as polynomials of bits
+    def poly(fn):
+        acc = None
+        for i in range(31, -1, -1):
+            bit = fn(i)
+            acc = bit if acc is None else acc + acc + bit
+        return acc
+
+    def x3(col0, rots):
+        def bit(i):
+            x, y, z = loc[col0 + (i + rots[0]) % 32], loc[col0 + (i + rots[1]) % 32], loc[col0 + (i + rots[2]) % 32]
+            xy = x * y
+            return x + y + z - 2 * (xy + (x + y) * z) + 4 * (xy * z)
+        return bit
+
+    def maj_bit(i):
+        a, b, cc = loc[A_ + i], loc[B_ + i], loc[C_ + i]
+        ab = a * b
+        return ab + (a + b) * cc - 2 * (ab * cc)
+
+    ch = poly(lambda i: loc[E_ + i] * loc[F_ + i] + (1 - loc[E_ + i]) * loc[G_ + i])
+    t1 = loc[HV] + poly(x3(E_, (6, 11, 25))) + ch + kr + val(loc, W0B)
     c.constraint(val(loc, NE0) + two32 * val(loc, CE0, 3) - (loc[DV] + t1))
-    c.constraint(val(loc, NA0) + two32 * val(loc, CA0, 3) - (t1 + val(loc, A0R) + val(loc, MAJ)))
+    c.constraint(val(loc, NA0) + two32 * val(loc, CA0, 3) - (t1 + poly(x3(A_, (2, 13, 22))) + poly(maj_bit)))
     # ---- 4. state shift inside a block
     for i in range(32):
         c.constraint(in_block * (nxt[A_ + i] - loc[NA0 + i]))
