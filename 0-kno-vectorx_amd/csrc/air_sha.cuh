@@ -3,8 +3,8 @@
 // of compute_authority_set_commitment (/root/reference circuits/builder/justification.rs:127-162;
 // native mirror circuits/input/mod.rs:250-260).  The reference proves SHA-256 with curta's STARK
 // (starkyx v1.0.0, not vendored); this AIR is a from-scratch FIPS 180-4 arithmetisation, degree <= 3:
-// one row per round, 64 rows per compression; the schedule's three-input XORs as x + y + z = r + 2c, Ch as a
-// degree-2 and Sigma0 / Sigma1 / Maj as degree-3 polynomials of bits; block types FIRST / DATA / PAD / IDLE.  539 (+2) columns: only the
+// one row per round, 64 rows per compression; Ch as a
+// degree-2 and every Sigma / sigma / Maj as degree-3 polynomials of bits; block types FIRST / DATA / PAD / IDLE.  412 (+2) columns: only the
 // words an XOR / AND reads are bit-decomposed (see the layout note); the compression rows are shared with ShaTreeAir.
 // Bus to EdAir (air_ed.cuh): a key's block carries a witness flag SGC ("this authority signed"); the key is sent as four
 // tuples (4 index + j, l0 + 2^16 l1, l2 + 2^16 l3, 0, TAG_KEY) of little-endian 16-bit limbs from the rows where its words
@@ -22,13 +22,14 @@ namespace shc {
 // bus, sigma0 reads w_{r+1}, sigma1 reads w_{r+14}).  d, h and the other 13 window positions are single VALUE columns:
 // every such value was, or will be, a bit-decomposed word on another row, and everything downstream works modulo 2^32.
 // Sigma0 / Sigma1 / Ch / Maj have no cells: they are degree-3 polynomials of the state bits inside the (unconditional) round
-// equations; only the schedule's sigma0 / sigma1, whose equation carries a selector, keep (result, carry) bits.
+// equations.  The schedule's equation carries a selector, so sigma0(w_{r+1}) + sigma1(w_{r+14}) gets ONE value cell SV, itself
+// defined by an unconditional degree-3 polynomial identity.
 constexpr int A_ = 0, B_ = 32, C_ = 64, E_ = 96, F_ = 128, G_ = 160, DV = 192, HV = 193, NA0 = 194, NE0 = 226;
 constexpr int W0B = 258, W1B = 290, W14B = 322, WV0 = 354, WV15 = 366;
-constexpr int S0R = 367, S0C = 399, S1R = 431, S1C = 463;
-constexpr int CE0 = 495, CA0 = 498, CW0 = 501, FFV0 = 503, FFC0 = 511, HIN0 = 519, DG0 = 527;
-constexpr int T_FIRST = 535, T_DATA = 536, T_PAD = 537, T_IDLE = 538, COLS = 539;  // COLS: the compression layout every SHA-256 table shares
-constexpr int SGC = 539, KC = 540, CHAIN_COLS = 541, TAG_KEY = 5;                    // ShaChainAir only
+constexpr int SV = 367;  // sigma0(W[1]) + sigma1(W[14]), a value below 2^33
+constexpr int CE0 = 368, CA0 = 371, CW0 = 374, FFV0 = 376, FFC0 = 384, HIN0 = 392, DG0 = 400;
+constexpr int T_FIRST = 408, T_DATA = 409, T_PAD = 410, T_IDLE = 411, COLS = 412;  // COLS: the compression layout every SHA-256 table shares
+constexpr int SGC = 412, KC = 413, CHAIN_COLS = 414, TAG_KEY = 5;                    // ShaChainAir only
 VX_HD constexpr int WV(int p) { return p == 15 ? WV15 : WV0 + p - 2; }  // value column of window position p (2..13, 15)
 VX_HD constexpr int st_bits(int wd) { return wd == 0 ? A_ : wd == 1 ? B_ : wd == 2 ? C_ : wd == 4 ? E_ : wd == 5 ? F_ : wd == 6 ? G_ : -1; }
 #define SHC_IV_INIT {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19}
@@ -71,7 +72,7 @@ __host__ __device__ inline void sha_compression_constraints(const Row& loc, cons
     auto state_word = [&](const Row& row, int wd) -> F { return wd == 3 ? row[DV] : wd == 7 ? row[HV] : val(row, st_bits(wd), 32); };
     // ---- 1. booleans
     {
-        const int lo[4] = {0, NA0, S0R, FFC0}, hi[4] = {DV, WV0, FFV0, HIN0};
+        const int lo[4] = {0, NA0, CE0, FFC0}, hi[4] = {DV, WV0, FFV0, HIN0};
 #pragma unroll 1
         for (int q = 0; q < 4; ++q)
 #pragma unroll 1
@@ -80,18 +81,25 @@ __host__ __device__ inline void sha_compression_constraints(const Row& loc, cons
                 c.constraint(x * (x - one));
             }
     }
-    // ---- 2. three-input XORs: x + y + z = r + 2c
-    auto xor3 = [&](int col0, int r0, int r1, int r2, int shift, int colr, int colc) {
+    // ---- 2. SV = sigma0(W[1]) + sigma1(W[14]): XORs as polynomials of the window bits (shifted-out bits are absent)
+    {
+        const F four = F::from(4);
+        auto sig = [&](int col0, int r0, int r1, int shift) -> F {
+            F acc = F::from(0);
 #pragma unroll 1
-        for (int i = 0; i < 32; ++i) {
-            F acc = loc[col0 + ((i + r0) & 31)] + loc[col0 + ((i + r1) & 31)];
-            if (shift < 0) acc = acc + loc[col0 + ((i + r2) & 31)];
-            else if (i + shift < 32) acc = acc + loc[col0 + i + shift];
-            c.constraint(acc - loc[colr + i] - two * loc[colc + i]);
-        }
-    };
-    xor3(W1B, 7, 18, 0, 3, S0R, S0C);
-    xor3(W14B, 17, 19, 0, 10, S1R, S1C);
+            for (int i = 31; i >= 0; --i) {
+                const F x = loc[col0 + ((i + r0) & 31)], y = loc[col0 + ((i + r1) & 31)];
+                const F xy = x * y;
+                if (i + shift >= 32) acc = acc + acc + (x + y - two * xy);
+                else {
+                    const F z = loc[col0 + i + shift];
+                    acc = acc + acc + (x + y + z - two * (xy + (x + y) * z) + four * (xy * z));
+                }
+            }
+            return acc;
+        };
+        c.constraint(loc[SV] - sig(W1B, 7, 18, 3) - sig(W14B, 17, 19, 10));
+    }
     // ---- 3. the round (local, every row): Sigma / Ch / Maj as degree-3 polynomials of the state bits
     {
         const F four = F::from(4);
@@ -138,7 +146,7 @@ __host__ __device__ inline void sha_compression_constraints(const Row& loc, cons
     for (int i = 0; i < 32; ++i) c.constraint(in_block * (nxt[W0B + i] - loc[W1B + i]));
 #pragma unroll 1
     for (int p = 1; p < 15; ++p) c.constraint(in_block * (window(nxt, p) - window(loc, p + 1)));
-    c.constraint(sched_on * (nxt[WV15] + two32 * val(loc, CW0, 2) - (val(loc, S1R, 32) + loc[WV(9)] + val(loc, S0R, 32) + val(loc, W0B, 32))));
+    c.constraint(sched_on * (nxt[WV15] + two32 * val(loc, CW0, 2) - (loc[SV] + loc[WV(9)] + val(loc, W0B, 32))));
     // ---- 6. feed-forward at r = 63: FF = H_in + (NA, a, b, c, NE, e, f, g)
     {
         const int s64[8] = {NA0, A_, B_, C_, NE0, E_, F_, G_};

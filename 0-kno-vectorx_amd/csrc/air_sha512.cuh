@@ -4,8 +4,9 @@
 // circuits/input/mod.rs:241-247).  FIPS 180-4, one round per row; 64-bit words are split in 32-bit halves wherever
 // arithmetic happens.  A slot takes 160 rows: block 1 = R || A || M || 80 00.. (80 rows), block 2 = the constant length
 // block (80 rows, continues from block 1).  Everything positional is a periodic column of full period.  Only words an
-// XOR reads are bit columns (a, b, c, e, f, g, new a, new e, window positions 0, 1, 14); Sigma0 / Sigma1 / Ch / Maj are degree-3 polynomials of those bits, sigma0 /
-// sigma1 have result + carry bits.  R || A arrives over the bus from EdAir (air_ed.cuh) at rows 0, 2, 4, 6 of block 1 (8
+// XOR reads are bit columns (a, b, c, e, f, g, new a, new e, window positions 0, 1, 14); Sigma0 / Sigma1 / Ch / Maj are
+// degree-3 polynomials of those bits (no cells); the schedule's sigma0 + sigma1 is one value (two halves) defined by an
+// unconditional polynomial identity, because the schedule equation itself carries a selector.  R || A arrives over the bus from EdAir (air_ed.cuh) at rows 0, 2, 4, 6 of block 1 (8
 // little-endian 16-bit limbs per tuple, cut from the bits of window positions 0 / 1); the digest goes back from rows 74..79
 // of block 2 as three 32-bit feed-forward halves per tuple (held in FFV from row 74 on; EdAir's byte cells bound them), all
 // under the slot's flag SGF.
@@ -21,8 +22,8 @@
 namespace s5 {
 constexpr int A_ = 0, B_ = 64, C_ = 128, E_ = 192, F_ = 256, G_ = 320, DV = 384, HV = 386, NA0 = 388, NE0 = 452;
 constexpr int W0B = 516, W1B = 580, W14B = 644, WV0 = 708, WV15 = 732;
-constexpr int S0R = 734, S0C = 798, S1R = 862, S1C = 926, CE0 = 990, CA0 = 996, CW0 = 1002;
-constexpr int FFV0 = 1006, FFC0 = 1022, HIN0 = 1038, SGF = 1054, COLS = 1055;
+constexpr int SV = 734;  // sigma0(W[1]) + sigma1(W[14]) as (lo, hi) halves (values below 2^33)
+constexpr int CE0 = 736, CA0 = 742, CW0 = 748, FFV0 = 752, FFC0 = 768, HIN0 = 784, SGF = 800, COLS = 801;
 constexpr int SLOT_ROWS = 160, SEND0 = 80 + 74, MSG_LEN = 53;
 enum { P_B1, P_INB, P_SCHED, P_KLO, P_KHI, P_LAST, P_CONT, P_HSET, P_RCV, P_T0, P_FFK, P_SGK, P_SD0, N_PERIODIC = 18 };
 VX_HD constexpr int WV(int p) { return p == 15 ? WV15 : WV0 + 2 * (p - 2); }
@@ -89,7 +90,7 @@ struct Sha512AirT {
         auto state_word = [&](const Row& row, int wd, int h) -> F { return wd == 3 ? row[DV + h] : wd == 7 ? row[HV + h] : val(row, st_bits(wd) + 32 * h, 32); };
         // ---- 1. booleans
         {
-            const int lo[5] = {0, NA0, S0R, FFC0, SGF}, hi[5] = {DV, WV0, FFV0, HIN0, SGF + 1};
+            const int lo[5] = {0, NA0, CE0, FFC0, SGF}, hi[5] = {DV, WV0, FFV0, HIN0, SGF + 1};
 #pragma unroll 1
             for (int q = 0; q < 5; ++q)
 #pragma unroll 1
@@ -98,17 +99,26 @@ struct Sha512AirT {
                     c.constraint(x * (x - one));
                 }
         }
-        // ---- 2. sigma0(W[1]), sigma1(W[14]): x + y + z = r + 2c (shifted-out bits are absent)
-        auto xor3 = [&](int col0, int r0, int r1, int shift, int colr, int colc) {
+        // ---- 2. SV = sigma0(W[1]) + sigma1(W[14]), per half: XORs as polynomials of the window bits (shifted-out bits are absent)
+        {
+            auto sig_half = [&](int col0, int r0, int r1, int shift, int h) -> F {
+                F acc = zero;
 #pragma unroll 1
-            for (int i = 0; i < 64; ++i) {
-                F acc = loc[col0 + ((i + r0) & 63)] + loc[col0 + ((i + r1) & 63)];
-                if (i + shift < 64) acc = acc + loc[col0 + i + shift];
-                c.constraint(acc - loc[colr + i] - two * loc[colc + i]);
-            }
-        };
-        xor3(W1B, 1, 8, 7, S0R, S0C);
-        xor3(W14B, 19, 61, 6, S1R, S1C);
+                for (int i = 31; i >= 0; --i) {
+                    const int b = 32 * h + i;
+                    const F x = loc[col0 + ((b + r0) & 63)], y = loc[col0 + ((b + r1) & 63)];
+                    const F xy = x * y;
+                    if (b + shift >= 64) acc = acc + acc + (x + y - two * xy);
+                    else {
+                        const F z = loc[col0 + b + shift];
+                        acc = acc + acc + (x + y + z - two * (xy + (x + y) * z) + four * (xy * z));
+                    }
+                }
+                return acc;
+            };
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) c.constraint(loc[SV + h] - sig_half(W1B, 1, 8, 7, h) - sig_half(W14B, 19, 61, 6, h));
+        }
         // ---- 3. the round (local, every row): Sigma / Ch / Maj are degree-3 polynomials of the state bits
         {
             auto x3half = [&](int col0, int r0, int r1, int r2, int h) -> F {
@@ -180,7 +190,7 @@ struct Sha512AirT {
 #pragma unroll 1
             for (int h = 0; h < 2; ++h) {
                 const F cw = val(loc, CW0 + 2 * h, 2);
-                F rhs = val(loc, S1R + 32 * h, 32) + loc[WV(9) + h] + val(loc, S0R + 32 * h, 32) + val(loc, W0B + 32 * h, 32);
+                F rhs = loc[SV + h] + loc[WV(9) + h] + val(loc, W0B + 32 * h, 32);
                 if (h) rhs = rhs + cin;
                 c.constraint(sched_on * (nxt[WV15 + h] + two32 * cw - rhs));
                 cin = cw;

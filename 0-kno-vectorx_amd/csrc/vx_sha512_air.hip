@@ -60,12 +60,6 @@ __device__ __forceinline__ void put_bits(uint64_t* tr, size_t n, size_t row, int
 __device__ __forceinline__ void put_halves(uint64_t* tr, size_t n, size_t row, int col, uint64_t v) {
     tr[(size_t)col * n + row] = v & 0xFFFFFFFFULL, tr[(size_t)(col + 1) * n + row] = v >> 32;
 }
-__device__ __forceinline__ void put_xor3(uint64_t* tr, size_t n, size_t row, uint64_t x, uint64_t y, uint64_t z, int colr, int colc) {
-    for (int i = 0; i < 64; ++i) {
-        const uint64_t s = ((x >> i) & 1) + ((y >> i) & 1) + ((z >> i) & 1);
-        tr[(size_t)(colr + i) * n + row] = s & 1, tr[(size_t)(colc + i) * n + row] = s >> 1;
-    }
-}
 // sum of the 32-bit halves of `cnt` 64-bit terms: (low-half carry, high-half carry, the 64-bit result)
 __device__ __forceinline__ void add_halves(const uint64_t* t, int cnt, uint64_t& c_lo, uint64_t& c_hi, uint64_t& res) {
     uint64_t lo = 0, hi = 0;
@@ -110,8 +104,10 @@ __global__ __launch_bounds__(256) void k_s512_rows(const S5Slot* slots, size_t m
     for (int p = 2; p < 14; ++p) put_halves(tr, n, row, WV(p), w[r + p]);
     put_halves(tr, n, row, WV15, w[r + 15]);
     const uint64_t w1 = w[r + 1], w14 = w[r + 14];
-    put_xor3(tr, n, row, rr(w1, 1), rr(w1, 8), w1 >> 7, S0R, S0C);
-    put_xor3(tr, n, row, rr(w14, 19), rr(w14, 61), w14 >> 6, S1R, S1C);
+    {
+        const uint64_t s0 = sg0(w1), s1 = sg1(w14);
+        tr[(size_t)SV * n + row] = (s0 & 0xFFFFFFFFULL) + (s1 & 0xFFFFFFFFULL), tr[(size_t)(SV + 1) * n + row] = (s0 >> 32) + (s1 >> 32);
+    }
     put_bits(tr, n, row, CE0, ce_lo, 3), put_bits(tr, n, row, CE0 + 3, ce_hi, 3), put_bits(tr, n, row, CA0, ca_lo, 3), put_bits(tr, n, row, CA0 + 3, ca_hi, 3);
     uint64_t cw_lo = 0, cw_hi = 0;
     if (r <= 63) {

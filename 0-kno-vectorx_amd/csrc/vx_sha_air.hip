@@ -29,13 +29,6 @@ static void h_compress(const uint32_t* h_in, const uint32_t* block, uint32_t* ou
 __device__ __forceinline__ void sbits(uint64_t* tr, size_t n, size_t row, int col0, uint64_t v, int nb = 32) {
     for (int i = 0; i < nb; ++i) tr[(size_t)(col0 + i) * n + row] = (v >> i) & 1;
 }
-__device__ __forceinline__ void sxor3(uint64_t* tr, size_t n, size_t row, uint32_t x, uint32_t y, uint32_t z, int colr, int colc) {
-    for (int i = 0; i < 32; ++i) {
-        const uint32_t s = ((x >> i) & 1) + ((y >> i) & 1) + ((z >> i) & 1);
-        tr[(size_t)(colr + i) * n + row] = s & 1;
-        tr[(size_t)(colc + i) * n + row] = s >> 1;
-    }
-}
 
 __global__ __launch_bounds__(256) void k_sha_trace(const ShaBlock* blocks, uint64_t* tr, size_t n) {
     using namespace shc;
@@ -73,8 +66,7 @@ __global__ __launch_bounds__(256) void k_sha_trace(const ShaBlock* blocks, uint6
     for (int p = 2; p < 14; ++p) tr[(size_t)WV(p) * n + row] = w[r + p];
     tr[(size_t)WV15 * n + row] = w[r + 15];
     const uint32_t w1 = w[r + 1], w14 = w[r + 14];
-    sxor3(tr, n, row, s_rotr(w1, 7), s_rotr(w1, 18), w1 >> 3, S0R, S0C);
-    sxor3(tr, n, row, s_rotr(w14, 17), s_rotr(w14, 19), w14 >> 10, S1R, S1C);
+    tr[(size_t)SV * n + row] = (uint64_t)(s_rotr(w1, 7) ^ s_rotr(w1, 18) ^ (w1 >> 3)) + (s_rotr(w14, 17) ^ s_rotr(w14, 19) ^ (w14 >> 10));
     sbits(tr, n, row, CE0, ne_full >> 32, 3);
     sbits(tr, n, row, CA0, na_full >> 32, 3);
     uint64_t cw = 0;
@@ -98,7 +90,7 @@ __global__ __launch_bounds__(256) void k_sha_trace(const ShaBlock* blocks, uint6
     tr[(size_t)T_DATA * n + row] = b.type == SB_DATA;
     tr[(size_t)T_PAD * n + row] = b.type == SB_PAD;
     tr[(size_t)T_IDLE * n + row] = b.type == SB_IDLE;
-    if (b.type != SB_TREE) tr[(size_t)SGC * n + row] = b.sgc, tr[(size_t)KC * n + row] = b.kc;  // (the tree table has 539 columns)
+    if (b.type != SB_TREE) tr[(size_t)SGC * n + row] = b.sgc, tr[(size_t)KC * n + row] = b.kc;  // (the tree table has 412 columns)
 }
 
 // auxiliary columns of ShaChainAir: the key sends of signed blocks, one lane per row

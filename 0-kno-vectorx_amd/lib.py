@@ -33,11 +33,11 @@ SYMBOLS = [
 VX_AIR_FIBONACCI, VX_AIR_MIX, VX_AIR_BLAKE_CHAIN, VX_AIR_LOOKUP = 1, 2, 6, 5
 VX_BLAKE_AIR_COLS, VX_BLAKE_AIR_AUX_COLS = 740, 278
 VX_AIR_SHA_TREE = {256: 7, 512: 8, 16: 9}
-VX_AIR_SHA_CHAIN, VX_SHA_AIR_COLS, VX_SHA_AIR_AUX_COLS, VX_SHA_TREE_AIR_COLS = 4, 541, 4, 539
+VX_AIR_SHA_CHAIN, VX_SHA_AIR_COLS, VX_SHA_AIR_AUX_COLS, VX_SHA_TREE_AIR_COLS = 4, 414, 4, 412
 VX_AIR_ED25519 = {17: 10, 16: 12}
 VX_ED_AIR_COLS, VX_ED_AIR_AUX_COLS = 839, 688
 VX_AIR_SHA512 = {16: 11, 15: 14, 10: 13}
-VX_SHA512_AIR_COLS, VX_SHA512_AIR_AUX_COLS = 1055, 4
+VX_SHA512_AIR_COLS, VX_SHA512_AIR_AUX_COLS = 801, 4
 
 
 class JustificationStruct(C.Structure):
@@ -487,7 +487,7 @@ class Context:
         return trace_buf, pub, dig
 
     def sha_chain_trace(self, pubkeys, log_n, trace_buf=None, signed=None, bus_on=0):
-        """ShaChainAir trace -> (Buffer [541][2^log_n], the 10 public inputs, the commitment).  signed: the flags of the
+        """ShaChainAir trace -> (Buffer [414][2^log_n], the 10 public inputs, the commitment).  signed: the flags of the
         authorities whose keys go to the EdDSA table over the bus (bus_on)."""
         pk = np.ascontiguousarray(np.frombuffer(b"".join(pubkeys), dtype=np.uint8))
         trace_buf = trace_buf or self.alloc(VX_SHA_AIR_COLS << log_n)
@@ -510,7 +510,7 @@ class Context:
         return trace_buf, pub
 
     def sha512_trace(self, pubkeys, sigs, msg, signed, log_n, bus_on=0, trace_buf=None):
-        """Sha512Air trace (H = SHA-512(R || A || msg) per signed slot) -> (Buffer [1055][2^log_n], public inputs)."""
+        """Sha512Air trace (H = SHA-512(R || A || msg) per signed slot) -> (Buffer [801][2^log_n], public inputs)."""
         n = len(pubkeys)
         pk = np.ascontiguousarray(np.frombuffer(b"".join(pubkeys), dtype=np.uint8)) if n else None
         sg = np.ascontiguousarray(np.frombuffer(b"".join(sigs), dtype=np.uint8)) if n else None

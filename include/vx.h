@@ -219,12 +219,12 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
 
 /* ---- K8: ShaChainAir trace generation (compute_authority_set_commitment, justification.rs:127-162):
  * the chained SHA-256 commitment h_0 = SHA256(pk_0), h_i = SHA256(h_{i-1} || pk_i) over n_keys 32-byte
- * keys (host buffer).  Writes the 541-column trace (64 rows per compression, 2*n_keys - 1
+ * keys (host buffer).  Writes the 414-column trace (64 rows per compression, 2*n_keys - 1
  * compressions, padded with idle blocks), the 10 public inputs (the commitment as big-endian words, the
  * number of keys, bus_on) and optionally the 32 commitment bytes.  signed_flags (may be NULL = none) marks
  * the keys whose signatures the EdDSA table verifies; with bus_on they are sent to it over the lookup bus
  * (bus_on = 0: a stand-alone proof).  Prove with vx_stark_prove(ctx, VX_AIR_SHA_CHAIN, ...). */
-enum { VX_AIR_SHA_CHAIN = 4, VX_SHA_AIR_COLS = 541, VX_SHA_AIR_AUX_COLS = 4, VX_SHA_TREE_AIR_COLS = 539 /* the Merkle AIRs 7 / 8 / 9 */ };
+enum { VX_AIR_SHA_CHAIN = 4, VX_SHA_AIR_COLS = 414, VX_SHA_AIR_AUX_COLS = 4, VX_SHA_TREE_AIR_COLS = 412 /* the Merkle AIRs 7 / 8 / 9 */ };
 int32_t vx_sha_chain_trace(vx_ctx* ctx, const uint8_t* pubkeys, size_t n_keys, const uint8_t* signed_flags, uint32_t bus_on, int log_n, vx_buf* trace_out,
                            uint64_t public_inputs_out[10], uint8_t commitment_out[32]);
 
@@ -240,10 +240,10 @@ int32_t vx_ed_trace(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* signatur
 
 /* ---- K8: Sha512Air trace generation (the hash half of the same verifications): H_i = SHA-512(R_i || A_i || message) for
  * every flagged authority, in compact slots of 160 rows in EdAir's order (2^15 rows hold 204 slots).  Writes the
- * 1055-column trace and the 15 public inputs (message words 8..14 of the first block as (lo, hi) halves, bus_on).
+ * 801-column trace and the 15 public inputs (message words 8..14 of the first block as (lo, hi) halves, bus_on).
  * message_len must be 53 (the precommit).  Prove with vx_stark_prove(ctx, VX_AIR_SHA512 (2^16 rows), VX_AIR_SHA512_15
  * (2^15) or VX_AIR_SHA512_10 (2^10), ...). */
-enum { VX_AIR_SHA512 = 11, VX_AIR_SHA512_10 = 13, VX_AIR_SHA512_15 = 14, VX_SHA512_AIR_COLS = 1055, VX_SHA512_AIR_AUX_COLS = 4 };
+enum { VX_AIR_SHA512 = 11, VX_AIR_SHA512_10 = 13, VX_AIR_SHA512_15 = 14, VX_SHA512_AIR_COLS = 801, VX_SHA512_AIR_AUX_COLS = 4 };
 int32_t vx_sha512_trace(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* signatures, const uint8_t* message, uint32_t message_len, const uint8_t* signed_flags,
                         size_t n_signatures, int log_n, uint32_t bus_on, vx_buf* trace_out, uint64_t public_inputs_out[15]);
 

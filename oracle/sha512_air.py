@@ -10,7 +10,8 @@ A slot takes 160 rows: block 1 = R || A || M || 80 00 00 | 0^8 (80 rows), block 
 from block 1's output).  Everything positional is a periodic column of full period: selectors, round constants, the bus
 tuple index.  Rows after the last slot are idle (all zero).  204 slots fit 2^15 rows (2/3 of 300 authorities + 1 = 201).
 Only words an XOR reads are bit columns (a, b, c, e, f, g, new a, new e, window positions 0, 1, 14); Sigma0 / Sigma1 /
-Ch / Maj are degree-3 polynomials of those bits, sigma0 / sigma1 have result + carry bits (x + y + z = r + 2c).
+Ch / Maj are degree-3 polynomials of those bits (no cells); the schedule's sigma0(w_{r+1}) + sigma1(w_{r+14}) is one value
+(two halves, SV) defined by an unconditional polynomial identity, because the schedule equation itself carries a selector.
 Bus (oracle/ed_air.py), under the slot's flag SGF:
   received at rows 0, 2, 4, 6 of block 1 (TAG_EDMSG, index 4 slot + j): message words 2j, 2j+1 (window positions 0 / 1, bits)
     as 8 limbs -- limb j of a word = bytes (2j, 2j+1) of its big-endian byte string, little-endian --
@@ -54,12 +55,12 @@ DV, HV = 384, 386                                   # d, h as (lo, hi) values
 NA0, NE0 = 388, 452
 W0B, W1B, W14B = 516, 580, 644
 WV0, WV15 = 708, 732                                # WV(p) = WV0 + 2 (p - 2) for p = 2..13 (lo, hi)
-S0R, S0C, S1R, S1C = 734, 798, 862, 926
-CE0, CA0, CW0 = 990, 996, 1002                      # carries: (3 + 3), (3 + 3), (2 + 2) bits, low half first
-FFV0, FFC0, HIN0 = 1006, 1022, 1038                 # 8 x (lo, hi) values; 16 carry bits; 8 x (lo, hi)
-SGF = 1054
-COLS = 1055
-BIT_RANGES = [(0, DV), (NA0, WV0), (S0R, FFV0), (FFC0, HIN0), (SGF, SGF + 1)]
+SV = 734                                            # sigma0(W[1]) + sigma1(W[14]), (lo, hi) halves (values below 2^33)
+CE0, CA0, CW0 = 736, 742, 748                       # carries: (3 + 3), (3 + 3), (2 + 2) bits, low half first
+FFV0, FFC0, HIN0 = 752, 768, 784                    # 8 x (lo, hi) values; 16 carry bits; 8 x (lo, hi)
+SGF = 800
+COLS = 801
+BIT_RANGES = [(0, DV), (NA0, WV0), (CE0, FFV0), (FFC0, HIN0), (SGF, SGF + 1)]
 ST_BITS = {0: A_, 1: B_, 2: C_, 4: E_, 5: F_, 6: G_}
 AUX, CHAL, AUXPUB, PUB = 4, 4, 1, 15
 P_B1, P_INB, P_SCHED, P_KLO, P_KHI, P_LAST, P_CONT, P_HSET, P_RCV, P_T0, P_FFK, P_SGK, P_SD0, PERIODIC = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 18
@@ -142,11 +143,6 @@ def fill_block(tr, base, h_in, block):
     def halves(row, col, val):
         tr[col, row], tr[col + 1, row] = val & M32, val >> 32
 
-    def xor3(row, x, y, z, colr, colc):
-        for i in range(64):
-            sm = ((x >> i) & 1) + ((y >> i) & 1) + ((z >> i) & 1)
-            tr[colr + i, row], tr[colc + i, row] = sm & 1, sm >> 1
-
     for r in range(80):
         row, rec = base + r, rows[r]
         for wd, col in ST_BITS.items():
@@ -163,8 +159,7 @@ def fill_block(tr, base, h_in, block):
             halves(row, WV(p), w[p])
         s0 = rotr(w[1], 1) ^ rotr(w[1], 8) ^ (w[1] >> 7)
         s1 = rotr(w[14], 19) ^ rotr(w[14], 61) ^ (w[14] >> 6)
-        xor3(row, rotr(w[1], 1), rotr(w[1], 8), w[1] >> 7, S0R, S0C)
-        xor3(row, rotr(w[14], 19), rotr(w[14], 61), w[14] >> 6, S1R, S1C)
+        tr[SV, row], tr[SV + 1, row] = (s0 & M32) + (s1 & M32), (s0 >> 32) + (s1 >> 32)
         bits(row, CE0, rec["ce"][0], 3)
         bits(row, CE0 + 3, rec["ce"][1], 3)
         bits(row, CA0, rec["ca"][0], 3)
@@ -291,16 +286,23 @@ def eval(loc, nxt, per, pub, c, chal, aux_pub):  # noqa: A001
         for col in range(lo, hi):
             c.constraint(loc[col] * (loc[col] - 1))
 
-    # ---- 2. sigma0(W[1]), sigma1(W[14]) as x + y + z = r + 2 c (shifted-out bits are absent)
-    def xor3(col0, rots, shift, colr, colc):
-        for i in range(64):
-            acc = loc[col0 + (i + rots[0]) % 64] + loc[col0 + (i + rots[1]) % 64]
-            if i + shift < 64:
-                acc = acc + loc[col0 + i + shift]
-            c.constraint(acc - loc[colr + i] - 2 * loc[colc + i])
+    # ---- 2. SV = sigma0(W[1]) + sigma1(W[14]), per half: XORs as polynomials of the window bits (shifted-out bits are absent)
+    def sig_half(col0, rots, shift, half):
+        acc = None
+        for i in range(31, -1, -1):
+            b = 32 * half + i
+            x, y = loc[col0 + (b + rots[0]) % 64], loc[col0 + (b + rots[1]) % 64]
+            xy = x * y
+            if b + shift >= 64:
+                bit = x + y - 2 * xy
+            else:
+                z = loc[col0 + b + shift]
+                bit = x + y + z - 2 * (xy + (x + y) * z) + 4 * (xy * z)
+            acc = bit if acc is None else acc + acc + bit
+        return acc
 
-    xor3(W1B, (1, 8), 7, S0R, S0C)
-    xor3(W14B, (19, 61), 6, S1R, S1C)
+    for half in range(2):
+        c.constraint(loc[SV + half] - sig_half(W1B, (1, 8), 7, half) - sig_half(W14B, (19, 61), 6, half))
 
     # ---- 3. the round (local, every row): Sigma / Ch / Maj are degree-3 polynomials of the state bits
     def poly_halves(fn):
@@ -359,11 +361,11 @@ def eval(loc, nxt, per, pub, c, chal, aux_pub):  # noqa: A001
         wn, wl = window(nxt, p), window(loc, p + 1)
         for half in range(2):
             c.constraint(inb * (wn[half] - wl[half]))
-    s1v, s0v, w9 = halves_of_bits(loc, S1R), halves_of_bits(loc, S0R), window(loc, 9)
+    w9 = window(loc, 9)
     cin = None
     for half in range(2):
         cw = val(loc, CW0 + 2 * half, 2)
-        rhs = s1v[half] + w9[half] + s0v[half] + w0[half]
+        rhs = loc[SV + half] + w9[half] + w0[half]
         if half:
             rhs = rhs + cin
         c.constraint(sched_on * (nxt[WV15 + half] + two32 * cw - rhs))

@@ -43,24 +43,25 @@ TAIL32 = [0x80000000] + [0] * 6 + [256]  # words 8..15 of the single block of a 
 # and the bus, sigma0 reads w_{r+1}, sigma1 reads w_{r+14}).  d, h and the other 13 window positions are single VALUE
 # columns: every such value was, or will be, a bit-decomposed word on another row (d = c of the previous row, a window
 # word reaches position 14 and later position 1), and everything downstream works modulo 2^32.  Sigma0 / Sigma1 / Ch / Maj
-# have NO cells: they are degree-3 polynomials of the state bits inside the (unconditional) round equations; only the
-# schedule's sigma0 / sigma1, whose equation carries a selector, keep (result, carry) bits.
+# have NO cells: they are degree-3 polynomials of the state bits inside the (unconditional) round equations.  The schedule's
+# equation carries a selector, so sigma0(w_{r+1}) + sigma1(w_{r+14}) gets ONE value cell SV, itself defined by an
+# unconditional degree-3 polynomial identity.
 A_, B_, C_, E_, F_, G_ = 0, 32, 64, 96, 128, 160   # state words held as bits
 DV, HV = 192, 193                                  # state words d, h as values
 NA0, NE0 = 194, 226
 W0B, W1B, W14B = 258, 290, 322                     # window positions 0, 1, 14 as bits
 WV0 = 354                                          # WV(p) = WV0 + p - 2 for p = 2..13; position 15 at WV15
 WV15 = 366
-S0R, S0C, S1R, S1C = 367, 399, 431, 463            # sigma0(W[1]), sigma1(W[14]): result and carry bits
-CE0, CA0, CW0 = 495, 498, 501                      # carries: 3 + 3 + 2 bits
-FFV0 = 503         # feed-forward words (values): H_in + state_64 - 2^32 carry
-FFC0 = 511         # 8 feed-forward carry bits
-HIN0 = 519         # 8 initial-state words (values)
-DG0 = 527          # digest register, 8 words (values)
-T_FIRST, T_DATA, T_PAD, T_IDLE = 535, 536, 537, 538
-COLS = 539         # the compression layout every SHA-256 table shares
-SGC, KC, CHAIN_COLS = 539, 540, 541   # ShaChainAir only: the "signed" flag of a key's block, the key counter
-BIT_RANGES = [(0, DV), (NA0, WV0), (S0R, FFV0), (FFC0, HIN0)]  # every boolean column
+SV = 367                                           # sigma0(W[1]) + sigma1(W[14]) (a value below 2^33)
+CE0, CA0, CW0 = 368, 371, 374                      # carries: 3 + 3 + 2 bits
+FFV0 = 376         # feed-forward words (values): H_in + state_64 - 2^32 carry
+FFC0 = 384         # 8 feed-forward carry bits
+HIN0 = 392         # 8 initial-state words (values)
+DG0 = 400          # digest register, 8 words (values)
+T_FIRST, T_DATA, T_PAD, T_IDLE = 408, 409, 410, 411
+COLS = 412         # the compression layout every SHA-256 table shares
+SGC, KC, CHAIN_COLS = 412, 413, 414   # ShaChainAir only: the "signed" flag of a key's block, the key counter
+BIT_RANGES = [(0, DV), (NA0, WV0), (CE0, FFV0), (FFC0, HIN0)]  # every boolean column
 PUB = 10           # digest words, number of keys, bus_on
 PERIODIC = 4       # sel_0, sel_63, sched_on (r <= 47), K_r  (+ 3 for ShaChainAir: key-send rows of FIRST / DATA blocks, j)
 CHAIN_PERIODIC = 7
@@ -144,11 +145,6 @@ def fill_block(tr, base, h_in, block):
         for i in range(nb):
             tr[col0 + i, row] = (val >> i) & 1
 
-    def xor3(row, x, y, z, colr, colc):
-        for i in range(32):
-            sm = ((x >> i) & 1) + ((y >> i) & 1) + ((z >> i) & 1)
-            tr[colr + i, row], tr[colc + i, row] = sm & 1, sm >> 1
-
     for r in range(64):
         row, rec = base + r, rows[r]
         a, b, c, d, e, f, g, h = rec["st"]
@@ -163,8 +159,7 @@ def fill_block(tr, base, h_in, block):
         bits(row, W14B, w[14])
         for p in list(range(2, 14)) + [15]:
             tr[WV(p), row] = w[p]
-        xor3(row, rotr(w[1], 7), rotr(w[1], 18), w[1] >> 3, S0R, S0C)
-        xor3(row, rotr(w[14], 17), rotr(w[14], 19), w[14] >> 10, S1R, S1C)
+        tr[SV, row] = (rotr(w[1], 7) ^ rotr(w[1], 18) ^ (w[1] >> 3)) + (rotr(w[14], 17) ^ rotr(w[14], 19) ^ (w[14] >> 10))
         bits(row, CE0, rec["ce"], 3)
         bits(row, CA0, rec["ca"], 3)
         if r <= 47:
@@ -237,18 +232,21 @@ def compression_constraints(loc, nxt, per, c, data_flag):
         for col in range(lo, hi):
             c.constraint(loc[col] * (loc[col] - 1))
 
-    # ---- 2. three-input XORs as x + y + z = r + 2 c  (rotations; shifted-out bits are absent)
-    def xor3(col0, rots, shift, colr, colc):
-        for i in range(32):
-            acc = loc[col0 + (i + rots[0]) % 32] + loc[col0 + (i + rots[1]) % 32]
-            if shift is None:
-                acc = acc + loc[col0 + (i + rots[2]) % 32]
-            elif i + shift < 32:
-                acc = acc + loc[col0 + i + shift]
-            c.constraint(acc - loc[colr + i] - 2 * loc[colc + i])
+    # ---- 2. SV = sigma0(W[1]) + sigma1(W[14]): XORs as polynomials of the window bits (shifted-out bits are absent)
+    def sig(col0, rots, shift):
+        def bit(i):
+            x, y = loc[col0 + (i + rots[0]) % 32], loc[col0 + (i + rots[1]) % 32]
+            xy = x * y
+            if i + shift >= 32:
+                return x + y - 2 * xy
+            z = loc[col0 + i + shift]
+            return x + y + z - 2 * (xy + (x + y) * z) + 4 * (xy * z)
+        acc = None
+        for i in range(31, -1, -1):
+            acc = bit(i) if acc is None else acc + acc + bit(i)
+        return acc
 
-    xor3(W1B, (7, 18), 3, S0R, S0C)
-    xor3(W14B, (17, 19), 10, S1R, S1C)
+    c.constraint(loc[SV] - sig(W1B, (7, 18), 3) - sig(W14B, (17, 19), 10))
 
     # ---- 3. the round (local, every row): T1 = h + Sigma1(e) + Ch(e,f,g) + K_r + w_r; Sigma / Ch / Maj as polynomials of bits
     def poly(fn):
@@ -287,7 +285,7 @@ def compression_constraints(loc, nxt, per, c, data_flag):
         c.constraint(in_block * (nxt[W0B + i] - loc[W1B + i]))
     for p in range(1, 15):
         c.constraint(in_block * (window(nxt, p) - window(loc, p + 1)))
-    c.constraint(sched_on * (nxt[WV15] + two32 * val(loc, CW0, 2) - (val(loc, S1R) + loc[WV(9)] + val(loc, S0R) + val(loc, W0B))))
+    c.constraint(sched_on * (nxt[WV15] + two32 * val(loc, CW0, 2) - (loc[SV] + loc[WV(9)] + val(loc, W0B))))
     # ---- 6. feed-forward at r = 63: FF = H_in + (NA, a, b, c, NE, e, f, g)
     s64 = [val(loc, NA0), val(loc, A_), val(loc, B_), val(loc, C_), val(loc, NE0), val(loc, E_), val(loc, F_), val(loc, G_)]
     for wd in range(8):

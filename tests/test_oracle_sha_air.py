@@ -35,7 +35,7 @@ def test_trace_satisfies_constraints_and_detects_corruption(oracle):
     assert check(tr, pub) is None
     # bit cells, value cells (d / h, window values, feed-forward), registers, flags, carries
     for col, row in ((A.C_ + 5, 70), (A.DV, 100), (A.HV, 64), (A.WV(3), 130), (A.WV15, 10), (A.W14B + 7, 33), (A.NA0 + 7, 200), (A.FFV0 + 1, 127),
-                     (A.DG0 + 2, 300), (A.T_PAD, 140), (A.CE0, 10), (A.HIN0 + 1, 66), (A.S1R + 9, 20), (A.CW0, 5),
+                     (A.DG0 + 2, 300), (A.T_PAD, 140), (A.CE0, 10), (A.HIN0 + 1, 66), (A.SV, 20), (A.CW0, 5),
                      (A.SGC, 70), (A.SGC, 200), (A.KC, 130), (A.KC, 320)):
         bad = tr.copy()
         bad[col, row] ^= np.uint64(1)
