@@ -411,8 +411,8 @@ def main():
                            "sub-proof structure is replaced by flat tables",
             "config": {
                 "workload": f"header_range_{N_HEADERS}: {N_HEADERS} x 15,360-B synthetic Avail headers (P15k), 300 authorities, one input per GPU; "
-                            f"{120 * N_HEADERS:,} Blake2b compressions -> BlakeChainAir (byte-lookup AIR) trace 2^{19 if N_HEADERS == 256 else 20} rows x (740 main + 278 logUp) columns + ShaTreeAir (SHA-256 Merkle table, 2^{16 if N_HEADERS == 256 else 17} x 747) "
-                            "+ ShaChainAir (2^16 x 737) + EdAir (201 signatures, 2^16 x 1527) + Sha512Air (2^15 x 1059) on the same logUp bus",
+                            f"{120 * N_HEADERS:,} Blake2b compressions -> BlakeChainAir (byte-lookup AIR) trace 2^{19 if N_HEADERS == 256 else 20} rows x (740 main + 278 logUp) columns + ShaTreeAir (SHA-256 Merkle table, 2^{16 if N_HEADERS == 256 else 17} x 428) "
+                            "+ ShaChainAir (2^16 x 418) + EdAir (201 signatures, 2^16 x 1527) + Sha512Air (2^15 x 805) on the same logUp bus",
                 "complete_proof": False,
                 "complete_statement": True,
                 "stages": ["verify_subchain: Blake2b header hashes, SCALE decode, link + numbering checks, SHA-256 Merkle roots -> 96-B output (native on GPU)",
@@ -422,7 +422,7 @@ def main():
                            "FRI batch/fold/PoW/queries, proof bytes",
                            "ShaTreeAir witness + STARK: both 256-leaf SHA-256 Merkle trees over the state roots / data roots the hash-chain table decodes "
                            "from the header bytes and sends over the bus (shared lookup challenges; the two roots are its public inputs)",
-                           "ShaChainAir witness + STARK: the 599-compression authority-set SHA-256 commitment (2^16 x 733 trace); sends the keys of the 201 chosen signers over the bus",
+                           "ShaChainAir witness + STARK: the 599-compression authority-set SHA-256 commitment (2^16 x 414 trace); sends the keys of the 201 chosen signers over the bus",
                            "EdAir witness + STARK: [S]B = R + [h]A for 201 signatures -- 253 double-and-add steps of 14 field multiplications each, 16-bit limbs, "
                            "672 logUp range checks per row; h = H mod l in-table",
                            "Sha512Air witness + STARK: H = SHA-512(R || A || precommit) for the same 201 signatures, exchanged with EdAir over the bus"],
@@ -450,8 +450,8 @@ def main():
                 "stages": ["BlakeChainAir witness + STARK over the header's 120 compressions (2^16 x 1018: one copy of the XOR lookup tables)",
                            "verify_simple_justification (native on GPU: 201 Ed25519 verifications, precommit, threshold)",
                            "verify_epoch_end_header (native on GPU: prefix, 300 x (pubkey, weight), delay)",
-                           "two ShaChainAir witnesses + STARKs: current and new authority-set commitments (2^16 x 737 each)",
-                           "the justification by the current set in-proof: EdAir (201 signatures, 2^16 x 1527) + Sha512Air (2^15 x 1059) on one logUp bus with the current set's commitment"],
+                           "two ShaChainAir witnesses + STARKs: current and new authority-set commitments (2^16 x 418 each)",
+                           "the justification by the current set in-proof: EdAir (201 signatures, 2^16 x 1527) + Sha512Air (2^15 x 805) on one logUp bus with the current set's commitment"],
                 "missing": ["epoch-end header parsing inside a STARK", "recursive aggregation into one proof"],
             }
         elif not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
