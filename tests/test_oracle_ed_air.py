@@ -134,3 +134,37 @@ def test_bus_between_the_two_tables_balances(ed):
     te, tsum = total(rows_e), total(rows_s)
     assert keys == 16 and (te.a, te.b) != (0, 0)  # 4 signatures x 4 key quarters
     assert ((te + tsum).a, (te + tsum).b) == (0, 0)
+
+
+def test_keys_between_commitment_and_curve_tables_balance(ed):
+    """The third side of the bus: ShaChainAir sends the keys of the chosen signers (index = key counter - 1), EdAir receives
+    them by its slots' authority index -- the two published key totals cancel (oracle/sha_air.py key_lookup)."""
+    from oracle import sha_air as A
+
+    n_auth = 5
+    keys = [pyref.ed25519_public(bytes([i + 1]) * 32) for i in range(n_auth)]
+    signed = [i != 2 for i in range(n_auth)]
+    tr, pub, _ = A.gen_trace(keys, 10, signed=signed, bus_on=1)
+    beta, gamma = ExtS(CHAL[0], CHAL[1]), ExtS(CHAL[2], CHAL[3])
+    g2 = gamma * gamma
+    g3, g4 = g2 * gamma, g2 * g2
+
+    def total(lookups):
+        acc = ExtS(0)
+        for m, tag, tup in lookups:
+            if m % P:
+                acc = acc + (beta + tup[0] + gamma * tup[1] + g2 * tup[2] + g3 * tup[3] + g4 * tag).inv() * (m % P)
+        return acc
+
+    per_c = A.chain_periodic_values()
+    sends = [A.key_lookup([int(tr[j, i]) for j in range(A.CHAIN_COLS)], [v[i % 64] for v in per_c], pub) for i in range(1 << 10) if i % 64 < 16]
+    per_e = E.periodic_values(1 << 16)
+    recvs = []
+    for s in range(len(ed["sigs"])):
+        i = 256 * s
+        recvs += [lk for lk in E.bus_lookups([int(ed["tr"][j, i]) for j in range(E.COLS)], [v[i % len(v)] for v in per_e], ed["pub"]) if lk[1] == E.TAG_KEY]
+    ts, te = total(sends), total(recvs)
+    assert (ts.a, ts.b) != (0, 0) and ((ts + te).a, (ts + te).b) == (0, 0)
+    # an unsigned authority's key is not sent, and a slot cannot claim it
+    bad = [dict(s) for s in ed["sigs"]]
+    assert [s["idx"] for s in bad] == [0, 1, 3, 4]
