@@ -2,6 +2,7 @@
 // the host verifier (extension field, at zeta).  An AIR is a struct with
 //   static constexpr int COLS, PUB, PERIODIC, PERIOD_LOG;      // PERIOD_LOG = the largest period
 //   static constexpr int AUX, CHAL, AUXPUB;                     // auxiliary round (0 0 0 = none), see below
+//   static constexpr int EXACT_LOG;                             // 1: positional columns have the period of the trace, so log2(rows) must EQUAL PERIOD_LOG
 //   static constexpr int plog(int q);                           // period (log2) of periodic column q
 //   template <class F, class Row, class C> static void eval(const Row& loc, const Row& nxt, const F* per,
 //                                                           const F* pub, const F* chal, const F* apub, C& c);
@@ -238,7 +239,7 @@ struct RowViewN {  // column-major LDE, rows i[0..R) of it
 // ---- AIR 1: Fibonacci (the canonical starky example; used to pin the generic prover) ----
 // columns (x0, x1); public inputs (x0[0], x1[0], x1[n-1]); next.x0 = x1, next.x1 = x0 + x1.
 struct FibAir {
-    static constexpr int ID = 1, COLS = 2, PUB = 3, PERIODIC = 0, PERIOD_LOG = 0, QUOT_ROWS_PER_LANE = 1, AUX = 0, CHAL = 0, AUXPUB = 0;
+    static constexpr int ID = 1, COLS = 2, PUB = 3, PERIODIC = 0, PERIOD_LOG = 0, QUOT_ROWS_PER_LANE = 1, AUX = 0, CHAL = 0, AUXPUB = 0, EXACT_LOG = 0;
     static constexpr int plog(int) { return 0; }
     template <class F, class Row, class C>
     VX_HD static void eval(const Row& loc, const Row& nxt, const F*, const F* pub, const F*, const F*, C& c) {
@@ -256,7 +257,7 @@ struct FibAir {
 //   rows with s = 1: next.a = d         (re-seed; s = (0,0,0,1) so the wrap-around pair re-seeds)
 //   next.b = a + b, next.c = c*c + d    (transition: degree 2 * z_last = 3), d boolean
 struct MixAir {
-    static constexpr int ID = 2, COLS = 4, PUB = 2, PERIODIC = 2, PERIOD_LOG = 2, QUOT_ROWS_PER_LANE = 2, AUX = 0, CHAL = 0, AUXPUB = 0;
+    static constexpr int ID = 2, COLS = 4, PUB = 2, PERIODIC = 2, PERIOD_LOG = 2, QUOT_ROWS_PER_LANE = 2, AUX = 0, CHAL = 0, AUXPUB = 0, EXACT_LOG = 0;
     static constexpr int plog(int) { return 2; }
     template <class F, class Row, class C>
     VX_HD static void eval(const Row& loc, const Row& nxt, const F* per, const F* pub, const F*, const F*, C& c) {
@@ -277,7 +278,7 @@ struct MixAir {
 // table row living in this trace row.  Table (ta, tb, ta ^ tb): periodic, period 2^8.  Challenges beta, gamma (X2).
 // Aux: h = 1/(beta+fp0) + 1/(beta+fp1), ht = m/(beta+fp_t), Z with Z(wx) = Z(x) + h(x) - ht(x) cyclically.
 struct LookupAir {
-    static constexpr int ID = 5, COLS = 7, PUB = 0, PERIODIC = 3, PERIOD_LOG = 8, QUOT_ROWS_PER_LANE = 1, AUX = 6, CHAL = 4, AUXPUB = 0;
+    static constexpr int ID = 5, COLS = 7, PUB = 0, PERIODIC = 3, PERIOD_LOG = 8, QUOT_ROWS_PER_LANE = 1, AUX = 6, CHAL = 4, AUXPUB = 0, EXACT_LOG = 0;
     static constexpr int plog(int) { return 8; }
     template <class F, class Row, class C>
     VX_HD static void eval(const Row& loc, const Row& nxt, const F* per, const F*, const F* chal, const F*, C& c) {

@@ -87,7 +87,7 @@ VX_HD F limb4(const F& b0, const F& b1, const F& b2, const F& b3) {
 #define VX_BLAKE_QR 1  // LDE points per lane in the quotient kernel
 #endif
 struct BlakeAir {
-    static constexpr int ID = 6, COLS = blk::COLS, PUB = 20, PERIODIC = 20, PERIOD_LOG = 16, QUOT_ROWS_PER_LANE = VX_BLAKE_QR, AUX = blk::AUX, CHAL = 4, AUXPUB = 1;
+    static constexpr int ID = 6, COLS = blk::COLS, PUB = 20, PERIODIC = 20, PERIOD_LOG = 16, QUOT_ROWS_PER_LANE = VX_BLAKE_QR, AUX = blk::AUX, CHAL = 4, AUXPUB = 1, EXACT_LOG = 0;
     static constexpr int plog(int q) { return q < 16 ? 4 : 16; }
 
     template <class F, class Row, class C>

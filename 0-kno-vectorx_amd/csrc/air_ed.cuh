@@ -77,7 +77,7 @@ __host__ __device__ __attribute__((noinline)) void fold16(const F* a, const F* b
 
 template <int LOGN, int ID_>
 struct EdAirT {
-    static constexpr int ID = ID_, COLS = edc::COLS, PUB = 2, PERIODIC = edc::N_PERIODIC, PERIOD_LOG = LOGN, QUOT_ROWS_PER_LANE = 1, AUX = edc::AUX, CHAL = 4, AUXPUB = 1;
+    static constexpr int ID = ID_, COLS = edc::COLS, PUB = 2, PERIODIC = edc::N_PERIODIC, PERIOD_LOG = LOGN, QUOT_ROWS_PER_LANE = 1, AUX = edc::AUX, CHAL = 4, AUXPUB = 1, EXACT_LOG = 1;
     static constexpr int plog(int q) { return q < edc::P_SLOT ? 8 : (q == edc::P_SLOT ? LOGN : 16); }
 
     static void periodic_values(std::vector<uint64_t>& v) {

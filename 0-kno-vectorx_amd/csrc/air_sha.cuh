@@ -170,7 +170,7 @@ __host__ __device__ inline void sha_compression_constraints(const Row& loc, cons
 }
 
 struct ShaAir {
-    static constexpr int ID = 4, COLS = shc::CHAIN_COLS, PUB = 10, PERIODIC = 7, PERIOD_LOG = 6, QUOT_ROWS_PER_LANE = 1, AUX = 4, CHAL = 4, AUXPUB = 1;
+    static constexpr int ID = 4, COLS = shc::CHAIN_COLS, PUB = 10, PERIODIC = 7, PERIOD_LOG = 6, QUOT_ROWS_PER_LANE = 1, AUX = 4, CHAL = 4, AUXPUB = 1, EXACT_LOG = 0;
     static constexpr int plog(int) { return 6; }
     static void periodic_values(std::vector<uint64_t>& v) {
         v.assign(7 * 64, 0);

@@ -43,7 +43,7 @@ VX_HD constexpr uint64_t pad2(int p) { return p == 15 ? 8 * (64 + MSG_LEN) : 0; 
 
 template <int LOGN, int ID_>
 struct Sha512AirT {
-    static constexpr int ID = ID_, COLS = s5::COLS, PUB = 15, PERIODIC = s5::N_PERIODIC, PERIOD_LOG = LOGN, QUOT_ROWS_PER_LANE = 1, AUX = 4, CHAL = 4, AUXPUB = 1;
+    static constexpr int ID = ID_, COLS = s5::COLS, PUB = 15, PERIODIC = s5::N_PERIODIC, PERIOD_LOG = LOGN, QUOT_ROWS_PER_LANE = 1, AUX = 4, CHAL = 4, AUXPUB = 1, EXACT_LOG = 1;
     static constexpr int plog(int) { return LOGN; }
     static constexpr size_t max_slots() { return ((size_t)1 << LOGN) / s5::SLOT_ROWS; }
 

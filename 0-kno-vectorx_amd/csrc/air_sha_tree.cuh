@@ -26,7 +26,7 @@ enum { P_SEL0, P_SEL63, P_SCHED, P_K, P_DATA, P_TREE, P_PWA, P_PWL, P_PWR, P_PBL
 
 template <int LOGN, int ID_>
 struct ShaTreeAirT {
-    static constexpr int ID = ID_, COLS = sht::COLS, PUB = 16, PERIODIC = sht::N_PERIODIC, PERIOD_LOG = 8 + LOGN, QUOT_ROWS_PER_LANE = 1, AUX = sht::AUX, CHAL = 4, AUXPUB = 1;
+    static constexpr int ID = ID_, COLS = sht::COLS, PUB = 16, PERIODIC = sht::N_PERIODIC, PERIOD_LOG = 8 + LOGN, QUOT_ROWS_PER_LANE = 1, AUX = sht::AUX, CHAL = 4, AUXPUB = 1, EXACT_LOG = 1;
     static constexpr int TREE_SIZE = 1 << LOGN;
     static constexpr int plog(int q) { return q < 4 ? 6 : (q == 4 ? 7 : 8 + LOGN); }
 

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void k_fri_combine(CombineArgs a) {
 // ------------------------------------------------------------------ AIR registry
 typedef int32_t (*gen_aux_fn)(vx_ctx*, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub);
 struct AirDesc {
-    int id, cols, pub, periodic, period_log;
+    int id, cols, pub, periodic, period_log, exact_log;
     void (*periodic_values)(std::vector<uint64_t>&);  // one period of every periodic column, back to back
     void (*launch)(QuotArgs&, hipStream_t);
     int (*count)();  // number of constraints eval pushes
@@ -364,7 +364,7 @@ static void lookup_periodic(std::vector<uint64_t>& v) {
 }
 template <class Air>
 static AirDesc desc(void (*pv)(std::vector<uint64_t>&), gen_aux_fn ga = nullptr) {
-    return {Air::ID, Air::COLS, Air::PUB, Air::PERIODIC, Air::PERIOD_LOG, pv, launch_q<Air>, count_q<Air>, Air::AUX, Air::CHAL, Air::AUXPUB, Air::plog, ga};
+    return {Air::ID, Air::COLS, Air::PUB, Air::PERIODIC, Air::PERIOD_LOG, Air::EXACT_LOG, pv, launch_q<Air>, count_q<Air>, Air::AUX, Air::CHAL, Air::AUXPUB, Air::plog, ga};
 }
 static const AirDesc AIRS[] = {
     desc<ShaAir>(ShaAir::periodic_values, vx_sha_chain_gen_aux), desc<BlakeAir>(blake_periodic, vx_blake_air_gen_aux), desc<FibAir>(no_periodic), desc<MixAir>(mix_periodic),
@@ -650,6 +650,7 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
                  cfg.pow_bits >= 0 && cfg.pow_bits <= 32, "stark prove: bad FRI config");
     const int L = log_n, r = cfg.rate_bits, LN = L + r;
     VX_CHECK(L >= air->period_log && L >= 2 && LN <= 27, "stark prove: log_n %d out of range", L);
+    VX_CHECK(!air->exact_log || L == air->period_log, "stark prove: AIR %d has positional columns of period 2^%d, the trace must have exactly that many rows", air_id, air->period_log);
     VX_CHECK(cfg.cap_height >= 0 && cfg.cap_height <= LN, "stark prove: cap_height %d > log2(lde size) %d", cfg.cap_height, LN);
     VX_CHECK((int)n_public == air->pub && (n_public == 0 || public_inputs), "stark prove: AIR %d takes %d public inputs", air_id, air->pub);
     // c = every committed trace column (main ++ auxiliary); the first cm come from the caller, the other ca are derived

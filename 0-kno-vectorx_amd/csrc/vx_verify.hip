@@ -114,7 +114,7 @@ Fx fx_pow(Fx x, uint64_t e) {
 bool fx_eq(Fx x, Fx y) { return x.a == y.a && x.b == y.b; }
 
 struct AirV {
-    int id, cols, pub, periodic, period_log;
+    int id, cols, pub, periodic, period_log, exact_log;
     void (*periodic_values)(std::vector<uint64_t>&);
     void (*eval)(const HostRow&, const HostRow&, const Fx*, const Fx*, const Fx*, const Fx*, Consumer<Fx>&);
     int aux, chal, auxpub;
@@ -126,7 +126,7 @@ void eval_host(const HostRow& l, const HostRow& n, const Fx* per, const Fx* pub,
 }
 template <class Air>
 AirV vdesc(void (*pv)(std::vector<uint64_t>&)) {
-    return {Air::ID, Air::COLS, Air::PUB, Air::PERIODIC, Air::PERIOD_LOG, pv, eval_host<Air>, Air::AUX, Air::CHAL, Air::AUXPUB, Air::plog};
+    return {Air::ID, Air::COLS, Air::PUB, Air::PERIODIC, Air::PERIOD_LOG, Air::EXACT_LOG, pv, eval_host<Air>, Air::AUX, Air::CHAL, Air::AUXPUB, Air::plog};
 }
 // coefficients of P(Y), deg < p, with P(w_p^k) = v[k]: in-place radix-2 inverse NTT on the host (a 2^16-entry lookup
 // table is far too long for the O(p^2) sum the short selectors get away with)
@@ -263,6 +263,7 @@ int32_t vx_stark_verify_ext(const vx_stark_config* cfg, const uint64_t* pr, size
     // the proof is untrusted input: the shapes the prover refuses (vx_stark_prove_impl) are refused here too, so no
     // Merkle depth below can go negative (a crafted L = 2 proof used to reach v_merkle with n_sib = SIZE_MAX)
     NEED(r >= 1 && r <= 3 && cap_h >= 0 && LN >= cap_h && LN <= 27 && L >= air->period_log, "degree bits %d out of range for this AIR / cap height", L);
+    NEED(!air->exact_log || L == air->period_log, "this AIR has positional columns of period 2^%d: a trace of 2^%d rows is not acceptable", air->period_log, L);
     {
         int cur = LN;
         for (int a : arities) {

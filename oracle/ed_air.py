@@ -686,7 +686,7 @@ def make_air(L):
 
     EdAir.ID, EdAir.COLS, EdAir.PUB, EdAir.PERIODIC, EdAir.PERIOD_LOG = IDS[L], COLS, PUB, PERIODIC, L
     EdAir.PERIOD_LOGS = period_logs(L)
-    EdAir.AUX, EdAir.CHAL, EdAir.AUXPUB = AUX, CHAL, AUXPUB
+    EdAir.AUX, EdAir.CHAL, EdAir.AUXPUB, EdAir.EXACT_LOG = AUX, CHAL, AUXPUB, 1
     EdAir.periodic_values = staticmethod(lambda: periodic_values(1 << L))
     EdAir.eval = staticmethod(eval)
     EdAir.gen_aux = staticmethod(gen_aux)

@@ -453,7 +453,7 @@ def make_air(L):
 
     Sha512Air.ID, Sha512Air.COLS, Sha512Air.PUB, Sha512Air.PERIODIC, Sha512Air.PERIOD_LOG = IDS[L], COLS, PUB, PERIODIC, L
     Sha512Air.PERIOD_LOGS = [L] * PERIODIC
-    Sha512Air.AUX, Sha512Air.CHAL, Sha512Air.AUXPUB = AUX, CHAL, AUXPUB
+    Sha512Air.AUX, Sha512Air.CHAL, Sha512Air.AUXPUB, Sha512Air.EXACT_LOG = AUX, CHAL, AUXPUB, 1
     Sha512Air.periodic_values = staticmethod(lambda: periodic_values(1 << L))
     Sha512Air.eval = staticmethod(eval)
     Sha512Air.gen_aux = staticmethod(gen_aux)

@@ -180,7 +180,7 @@ def make_air(N):
             return aux, apub
 
     ShaTreeAir.COLS, ShaTreeAir.PUB, ShaTreeAir.PERIODIC, ShaTreeAir.PERIOD_LOG = COLS, PUB, PERIODIC, L
-    ShaTreeAir.AUX, ShaTreeAir.CHAL, ShaTreeAir.AUXPUB = AUX, CHAL, AUXPUB
+    ShaTreeAir.AUX, ShaTreeAir.CHAL, ShaTreeAir.AUXPUB, ShaTreeAir.EXACT_LOG = AUX, CHAL, AUXPUB, 1
     ShaTreeAir.periodic_values = staticmethod(periodic_values)
     return ShaTreeAir
 

@@ -666,6 +666,7 @@ def verify(proof, cfg=None, expect_air=None, expect_public=None, ext_chal=None):
     N = 1 << LN
     _need(final_len == (1 << (LN - sum(arities))) >> r, "final poly length mismatch")
     _need(2 <= L <= 26 and LN >= cap_h and L >= air.PERIOD_LOG, "degree bits out of range for this AIR / cap height")
+    _need(not getattr(air, "EXACT_LOG", 0) or L == air.PERIOD_LOG, "this AIR has positional columns of the trace's period: the row count is fixed")
     cap_words = 4 << cap_h
     cap_t = np.array(take(cap_words), dtype=np.uint64).reshape(-1, 4)
     aux_pub, cap_a = None, None

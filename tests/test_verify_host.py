@@ -56,3 +56,35 @@ def test_short_crafted_proof_is_rejected_not_crashing(vx):
             vx.lib.stark_verify(blob)
         with pytest.raises(S.VerifyError):
             S.verify(blob)
+
+
+def test_positional_airs_fix_the_row_count(vx):
+    """An AIR whose periodic columns have the period of the trace (slot indices, tree positions) must be proven at exactly
+    its row count: a proof of twice the rows would let the positional columns repeat.  Both verifiers refuse it."""
+    import hashlib
+
+    from oracle import sha512_air as H
+
+    msg = b"\x01" + bytes(range(32)) + (100000).to_bytes(4, "little") + (7).to_bytes(8, "little") + (3).to_bytes(8, "little")
+    ok_air = H.make_air(10)
+    S.register_air(ok_air)
+    tr, pub, _ = H.gen_trace([(hashlib.sha256(b"r").digest(), hashlib.sha256(b"a").digest())], msg, 10, bus_on=0)
+    cfg = dict(S.DEFAULT_CFG, num_queries=6)
+    pcfg = vx.lib.default_stark_config(num_queries=6)
+    proof = S.prove(ok_air, tr, pub, cfg)
+    vx.lib.stark_verify(proof, pcfg, expect_air=H.IDS[10], expect_public=pub)
+    # the same AIR id claimed over 2^11 rows (the prover's periodic columns stretched accordingly)
+    H.IDS[11] = H.IDS[10]
+    try:
+        big_air = H.make_air(11)
+        big_air.EXACT_LOG = 0  # a prover that ignores the rule
+        tr2, pub2, _ = H.gen_trace([(hashlib.sha256(b"r").digest(), hashlib.sha256(b"a").digest())], msg, 11, bus_on=0)
+        S.AIRS[H.IDS[10]] = big_air
+        forged = S.prove(big_air, tr2, pub2, cfg)
+    finally:
+        del H.IDS[11]
+        S.register_air(ok_air)
+    with pytest.raises(vx.VxError, match="positional"):
+        vx.lib.stark_verify(forged, pcfg)
+    with pytest.raises(S.VerifyError):
+        S.verify(forged, cfg)
