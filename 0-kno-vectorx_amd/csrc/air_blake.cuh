@@ -29,10 +29,12 @@ namespace blk {
 constexpr int S_A1 = 0, S_D1 = 1, S_C1 = 2, S_B1 = 3, S_A2 = 4, S_D2 = 5, S_C2 = 6, S_L = 7, S_T = 8;
 constexpr int CAR0 = 576, MS0 = 608, MB0 = 640, HL0 = 648, D0 = 664;
 constexpr int ACT = 672, FIN = 673, FIRST = 674, CAP = 675, T = 676, INC = 677, NUM = 678, FA = 679;
-constexpr int TB0 = 680, IB0 = 712, MK0 = 720, CNT = 728, M1 = 729, M2 = 730, SZ = 731, E0 = 732, COLS = 740;
-// helper elements: 128 of the G functions, 4 message-byte range checks, 4 data-root byte sends, 1 state-root word sends,
-// the table helper, the running sum
-constexpr int N_HELP = 139, HM0 = 128, HB0 = 132, HS = 136, HT = 137, ZZ = 138, AUX = 2 * N_HELP, TABLE_LOG = 16;
+constexpr int TB0 = 680, IB0 = 712, MK0 = 720, CNT = 728, M1 = 729, M2 = 730, SZ = 731, E0 = 732;
+// SCALE compact mode of the block number (one-hot, only on first chunks; mode 2 = FIRST - the other three) and, per row, the
+// offset its bus positions are counted from and the tree its bytes go to
+constexpr int MDF0 = 740, MDF1 = 741, MDF3 = 742, KOF = 743, TR = 744, COLS = 745;
+// helper elements: 128 of the G functions, 4 message-byte range checks, 4 root byte sends, the table helper, the running sum
+constexpr int N_HELP = 138, HM0 = 128, HB0 = 132, HT = 136, ZZ = 137, AUX = 2 * N_HELP, TABLE_LOG = 16;
 // bus tuples are (t0, t1, t2, t3, tag): fingerprint t0 + g t1 + g^2 t2 + g^3 t3 + g^4 tag
 constexpr int TAG_T1 = 0, TAG_T2 = 1, TAG_BYTE = 2, TAG_WORD = 3;
 VX_HD constexpr int GC(int k, int slot, int j) { return (k * 9 + slot) * 8 + j; }
@@ -143,6 +145,11 @@ struct BlakeAir {
         boolean(FIRST);
         boolean(CAP);
         boolean(FA);
+        boolean(MDF0);
+        boolean(MDF1);
+        boolean(MDF3);
+        const F mdf2 = loc[FIRST] - loc[MDF0] - loc[MDF1] - loc[MDF3];  // exactly one mode on a first chunk, none elsewhere
+        c.constraint(mdf2 * (mdf2 - one));
         // ---- 2. carries of the three-operand additions
 #pragma unroll 1
         for (int col = CAR0; col < CAR0 + 32; ++col) {
@@ -294,13 +301,25 @@ struct BlakeAir {
         for (int s = 0; s < 4; ++s)
 #pragma unroll 1
             for (int h = 0; h < 2; ++h) c.constraint(sel[0] * first * (loc[MS(s, h)] - loc[D0 + 2 * s + h]));
-        // block number: bytes 32..36 = SCALE compact int, 4-byte mode: 4 * number + 2 (decoder.rs:64-66)
-        c.constraint(sel[0] * first * (loc[MS(4, 0)] - (F::from(4) * loc[NUM] + two)));
+        // the block number, bytes 32.. of a first chunk = the natural word of row 4: SCALE compact, all four modes (decoder.rs:39-92)
+        {
+            const F num = loc[NUM], k8 = F::from(256), k16 = F::from(65536), k24 = F::from(1ULL << 24), four = F::from(4);
+            const F b0 = loc[MB0], b1 = loc[MB0 + 1], b2 = loc[MB0 + 2], b3 = loc[MB0 + 3], b4 = loc[MB0 + 4];
+            c.constraint(sel[4] * (loc[MDF0] * (b0 - num * four) + loc[MDF1] * (b0 + b1 * k8 - num * four - one) +
+                                   mdf2 * (b0 + b1 * k8 + b2 * k16 + b3 * k24 - num * four - two) + loc[MDF3] * (b1 + b2 * k8 + b3 * k16 + b4 * k24 - num)));
+            c.constraint(sel[4] * loc[MDF3] * (b0 - F::from(3)));
+            // the window the row's bus positions are counted from, and its tree: state root on rows 4..8 of a first chunk (right
+            // behind the compact number), data root = the last 32 bytes everywhere else
+            const F s48 = sel[4] + sel[5] + sel[6] + sel[7] + sel[8], srw = first * s48;
+            const F clen = loc[MDF0] + loc[MDF1] * two + mdf2 * four + loc[MDF3] * F::from(5);
+            c.constraint(loc[TR] - (one - srw));
+            c.constraint(loc[KOF] - (s48 * (first * F::from(32) + clen) + (one - srw) * (loc[SZ] - F::from(32))));
+        }
         // ---- 7. per-block registers
         {
-            const int regs[8] = {ACT, FIN, FIRST, CAP, T, INC, NUM, FA};
+            const int regs[11] = {ACT, FIN, FIRST, CAP, T, INC, NUM, FA, MDF0, MDF1, MDF3};
 #pragma unroll 1
-            for (int q = 0; q < 8; ++q) c.constraint(in_blk * (nxt[regs[q]] - loc[regs[q]]));
+            for (int q = 0; q < 11; ++q) c.constraint(in_blk * (nxt[regs[q]] - loc[regs[q]]));
         }
         c.constraint(loc[CAP] - loc[ACT] * fin);
         c.constraint(loc[FA] - first * loc[ACT]);
@@ -377,14 +396,14 @@ struct BlakeAir {
                 c.constraint_x2(h * du * dv - (du + dv));
                 hsum = hsum + h;
             }
-            // ---- bus sends of the next row.  Data root: byte b of its natural message word under the flag E[b], tuple
-            // (leaf, k, byte) with k = position - (size - 32); rows are numbered by the LOCAL row's selectors.
+            // ---- bus sends of the next row: byte b of its natural message word under the flag E[b], tuple (leaf, position in the
+            // root, byte, tree) -- tree 0 = state root, tree 1 = data root; rows are numbered by the LOCAL row's selectors
             {
                 F r8n = sel[0] * F::from(8);
                 for (int r = 1; r < 15; ++r) r8n = r8n + sel[r] * F::from(8 * (r + 1));
                 const F leaf = nxt[NUM] - pub[16], bus_on = pub[19];  // bus_on = 0: a stand-alone proof, nothing on the bus
-                const F pos0 = nxt[T] - nxt[INC] + r8n - nxt[SZ] + F::from(32);
-                const X2<F> base = beta + leaf + g4 * F::from(TAG_BYTE);
+                const F pos0 = nxt[T] - nxt[INC] + r8n - nxt[KOF];
+                const X2<F> base = beta + leaf + g3 * nxt[TR] + g4 * F::from(TAG_BYTE);
                 const F live = nxt[ACT] * bus_on;  // an inactive (padding / junk) message shares its block number with the last real header: it must not send
 #pragma unroll 1
                 for (int pair = 0; pair < 4; ++pair) {
@@ -394,17 +413,6 @@ struct BlakeAir {
                     c.constraint_x2(h * du * dv - dv * (nxt[E0 + b0] * live) - du * (nxt[E0 + b1] * live));
                     hsum = hsum + h;
                 }
-                // state root: big-endian words of bytes 0..3 (rows 5..8 -> words 1, 3, 5, 7) and 4..7 (rows 4..7 -> words 0, 2, 4, 6) of
-                // a first chunk, tuple (tree 0, node id N + leaf, j, word)
-                const F su = sel[4] + sel[5] + sel[6] + sel[7], ju = sel[4] + sel[5] * F::from(3) + sel[6] * F::from(5) + sel[7] * F::from(7);
-                const F sv = sel[3] + sel[4] + sel[5] + sel[6], jv = sel[4] * two + sel[5] * F::from(4) + sel[6] * F::from(6);
-                const F wu = limb4(nxt[MB0 + 3], nxt[MB0 + 2], nxt[MB0 + 1], nxt[MB0 + 0]), wv = limb4(nxt[MB0 + 7], nxt[MB0 + 6], nxt[MB0 + 5], nxt[MB0 + 4]);
-                const X2<F> wbase = beta + gamma * (leaf + pub[18]) + g4 * F::from(TAG_WORD);
-                const X2<F> du = wbase + g2 * ju + g3 * wu, dv = wbase + g2 * jv + g3 * wv;
-                const X2<F> h{nxt[AX(HS, 0)], nxt[AX(HS, 1)]};
-                const F fa = nxt[FA] * bus_on;
-                c.constraint_x2(h * du * dv - dv * (fa * su) - du * (fa * sv));
-                hsum = hsum + h;
             }
             const F ta = per[16], tb_ = per[17], tl = per[18], tt = per[19];
             const X2<F> dt1 = beta + ta + gamma * tb_ + g2 * (tl + tt * F::from(128));

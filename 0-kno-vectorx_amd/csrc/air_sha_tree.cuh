@@ -9,8 +9,8 @@
 // slot 0 a dummy).  Compression rows and column layout are ShaChainAir's (air_sha.cuh, 539 columns); everything positional is a
 // PERIODIC column; the only other witness is the pair of leaf-enable flags ENL / ENR of a bottom-level node (a disabled
 // leaf must be zero and takes nothing from the bus).  Row r < 16 of a DATA block receives message word r:
-//   inner nodes and the bottom level of tree 0:  (tree, child id, r mod 8, word, TAG_WORD)
-//   bottom level of tree 1 (data roots):         (leaf, 4 (r mod 8) + q, byte q of the word, TAG_BYTE), q = 0..3
+//   inner nodes:                 (tree, child id, r mod 8, word, TAG_WORD)                         from the children's PAD blocks
+//   bottom level of both trees:  (leaf, 4 (r mod 8) + q, byte q of the word, tree, TAG_BYTE), q = 0..3   from the header bytes
 // and row 63 of a PAD block sends the node's digest (tree, g, j, word_j), except for the root: its digest is public.
 // Constraint ORDER is protocol: oracle/sha_tree_air.py restates it independently.
 #pragma once
@@ -20,21 +20,21 @@
 #include "air_sha.cuh"
 
 namespace sht {
-constexpr int ENL = shc::DG0, ENR = shc::DG0 + 1, COLS = shc::COLS, AUX = 16, N_PERIODIC = 16;
-enum { P_SEL0, P_SEL63, P_SCHED, P_K, P_DATA, P_TREE, P_PWA, P_PWL, P_PWR, P_PBL, P_PBR, P_CID, P_JJ, P_PS, P_ROOT, P_GID };
+constexpr int ENL = shc::DG0, ENR = shc::DG0 + 1, COLS = shc::COLS, AUX = 16, N_PERIODIC = 14;
+enum { P_SEL0, P_SEL63, P_SCHED, P_K, P_DATA, P_TREE, P_PWA, P_PBL, P_PBR, P_CID, P_JJ, P_PS, P_ROOT, P_GID };
 }  // namespace sht
 
 template <int LOGN, int ID_>
 struct ShaTreeAirT {
     static constexpr int ID = ID_, COLS = sht::COLS, PUB = 16, PERIODIC = sht::N_PERIODIC, PERIOD_LOG = 8 + LOGN, QUOT_ROWS_PER_LANE = 1, AUX = sht::AUX, CHAL = 4, AUXPUB = 1, EXACT_LOG = 1;
     static constexpr int TREE_SIZE = 1 << LOGN;
-    static constexpr int plog(int q) { return q < 4 ? 6 : (q == 4 ? 7 : 8 + LOGN); }
+    static constexpr int plog(int q) { return q < 4 ? 6 : (q == 4 ? 7 : 8 + LOGN); }  // 4 x 64, 128, then 9 full-period columns
 
     // one period of every periodic column, back to back (host)
     static void periodic_values(std::vector<uint64_t>& v) {
         using namespace sht;
         const size_t N = TREE_SIZE, n = 256 * N;
-        v.assign(4 * 64 + 128 + 11 * n, 0);
+        v.assign(4 * 64 + 128 + 9 * n, 0);
         uint64_t* p = v.data();
         p[0] = 1, p[64 + 63] = 1;
         for (int r = 0; r <= 47; ++r) p[128 + r] = 1;
@@ -48,11 +48,9 @@ struct ShaTreeAirT {
             const bool send = blk == 1 && r == 63;
             q[(P_TREE - 5) * n + row] = tree;
             q[(P_PWA - 5) * n + row] = msg && inner;
-            q[(P_PWL - 5) * n + row] = left && bottom && tree == 0;
-            q[(P_PWR - 5) * n + row] = right && bottom && tree == 0;
-            q[(P_PBL - 5) * n + row] = left && bottom && tree == 1;
-            q[(P_PBR - 5) * n + row] = right && bottom && tree == 1;
-            q[(P_CID - 5) * n + row] = msg ? ((bottom && tree == 1) ? 2 * g - N + c : 2 * g + c) : 0;
+            q[(P_PBL - 5) * n + row] = left && bottom;
+            q[(P_PBR - 5) * n + row] = right && bottom;
+            q[(P_CID - 5) * n + row] = msg ? (bottom ? 2 * g - N + c : 2 * g + c) : 0;  // a bottom-level child is a leaf: its index; an inner child: its node id
             q[(P_JJ - 5) * n + row] = msg ? (r & 7) : 0;
             q[(P_PS - 5) * n + row] = send && g >= 2;
             q[(P_ROOT - 5) * n + row] = send && g == 1;
@@ -81,8 +79,8 @@ struct ShaTreeAirT {
 #pragma unroll 1
         for (int j = 0; j < 8; ++j) c.constraint(per[P_ROOT] * (loc[FFV0 + j] - (pub[j] + per[P_TREE] * (pub[8 + j] - pub[j]))));
         const F w0 = val(loc, W0B, 32);
-        c.constraint((per[P_PWL] + per[P_PBL]) * (one - loc[ENL]) * w0);
-        c.constraint((per[P_PWR] + per[P_PBR]) * (one - loc[ENR]) * w0);
+        c.constraint(per[P_PBL] * (one - loc[ENL]) * w0);
+        c.constraint(per[P_PBR] * (one - loc[ENR]) * w0);
         // ---- 9. the bus (logUp): 13 lookups in 7 helper elements of the local row, cyclic running sum
         {
             const X2<F> beta{chal[0], chal[1]}, gamma{chal[2], chal[3]}, g2 = gamma * gamma, g3 = g2 * gamma, g4 = g2 * g2;
@@ -90,13 +88,13 @@ struct ShaTreeAirT {
             const X2<F> tag_w = g4 * F::from(blk::TAG_WORD), tag_b = g4 * F::from(blk::TAG_BYTE);
             // lookup q: 0 = word receive, 1..4 = byte receives, 5..12 = digest sends
             auto mult = [&](int q) -> F {
-                if (q == 0) return zero - (per[P_PWA] + per[P_PWL] * en_l + per[P_PWR] * en_r);
+                if (q == 0) return zero - per[P_PWA];
                 if (q <= 4) return zero - (per[P_PBL] * en_l + per[P_PBR] * en_r);
                 return per[P_PS];
             };
             auto denom = [&](int q) -> X2<F> {
                 if (q == 0) return beta + per[P_TREE] + gamma * per[P_CID] + g2 * per[P_JJ] + g3 * w0 + tag_w;
-                if (q <= 4) return beta + per[P_CID] + gamma * (per[P_JJ] * F::from(4) + F::from((uint64_t)(q - 1))) + g2 * val(loc, W0B + 24 - 8 * (q - 1), 8) + tag_b;
+                if (q <= 4) return beta + per[P_CID] + gamma * (per[P_JJ] * F::from(4) + F::from((uint64_t)(q - 1))) + g2 * val(loc, W0B + 24 - 8 * (q - 1), 8) + g3 * per[P_TREE] + tag_b;
                 return beta + per[P_TREE] + gamma * per[P_GID] + g2 * F::from((uint64_t)(q - 5)) + g3 * loc[FFV0 + q - 5] + tag_w;
             };
             X2<F> hsum{zero, zero};

@@ -19,11 +19,14 @@
 #include "vx_internal.h"
 
 
+// SCALE compact mode of a u32 (decoder.rs:39-92): 1 / 2 / 4 / 5 bytes
+static uint8_t compact_mode(uint32_t v) { return v < (1u << 6) ? 0 : v < (1u << 14) ? 1 : v < (1u << 30) ? 2 : 3; }
+
 struct BlockDesc {
     uint64_t msg_off;  // byte offset of the 128-byte chunk in the headers buffer; ~0 = padding block
     uint32_t t, inc;
     uint32_t D[8];     // digest register before this block
-    uint8_t fin, first, act, pad;
+    uint8_t fin, first, act, mode;  // mode: SCALE compact mode (0..3) of the header's block number
     uint32_t num;      // block number of the header this chunk belongs to
     uint32_t size;     // length of the whole message (< 2^24)
 };
@@ -101,9 +104,10 @@ __global__ __launch_bounds__(64) void k_blake_chain(const uint8_t* msgs, size_t 
 #define VX_HIST_COPIES 8
 #endif
 constexpr int HIST_COPIES = VX_HIST_COPIES;
-constexpr int SW_CAR = 64, SW_MS = 65, SW_MB = 81, SW_HL = 82, SW_D = 90, SW_FLAGS = 94, SW_TN = 95, N_STAGE = 96;
+constexpr int SW_CAR = 64, SW_MS = 65, SW_MB = 81, SW_HL = 82, SW_D = 90, SW_FLAGS = 94, SW_TN = 95, SW_WIN = 96, N_STAGE = 97;
 // SW_CAR: 32 carries x 2 bits; SW_MS: the 16 message words in this row's order; SW_D: 4 words of two limbs;
-// SW_FLAGS: ACT FIN FIRST CAP FA (bits 0..4), INC (8..15), CNT (16..23), MK (24..31), E (32..39), SZ (40..63); SW_TN: T (low half), NUM (high half)
+// SW_FLAGS: ACT FIN FIRST CAP FA MDF0 MDF1 MDF3 (bits 0..7), INC (8..15), CNT (16..23), MK (24..31), E (32..39), SZ (40..63); SW_TN: T (low half),
+// NUM (high half); SW_WIN: KOF (bits 0..23), TR (bit 32)
 struct ExpandEntry {
     uint16_t col;
     uint8_t shift, bits;
@@ -134,11 +138,12 @@ __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const 
             }
             m[k] = w;
         }
-    } else {  // padding block: the 36-byte message D || compact(number)
+    } else {  // padding block: the 40-byte message D || compact(number) || 0..
         for (int k = 0; k < 8; ++k) h[k] = IV[k];
         h[0] ^= 0x01010020ULL;
         for (int k = 0; k < 16; ++k) m[k] = k < 4 ? ((uint64_t)d.D[2 * k] | ((uint64_t)d.D[2 * k + 1] << 32)) : 0;
-        m[4] = 4ULL * d.num + 2;  // bytes 32..36: SCALE compact (4-byte mode) of the last block number
+        // bytes 32..: SCALE compact of the last block number in its own mode (decoder.rs:39-92)
+        m[4] = d.mode == 0 ? 4ULL * d.num : d.mode == 1 ? 4ULL * d.num + 1 : d.mode == 2 ? 4ULL * d.num + 2 : (3ULL | ((uint64_t)d.num << 8));
     }
     auto st = [&](int w) -> uint64_t& { return stage[(size_t)w * n + row]; };
     auto gw = [&](int k, int slot) -> uint64_t& { return st(8 * k + slot); };  // slot 7 = X (L / T)
@@ -218,15 +223,21 @@ __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const 
     uint64_t mk = 0;
     for (int bq = 0; bq < 8; ++bq) mk |= (uint64_t)((uint32_t)(8 * r + bq) < d.inc ? 1 : 0) << bq;
     const uint64_t cnt = d.inc < (uint32_t)(8 * (r + 1)) ? d.inc : (uint32_t)(8 * (r + 1));
-    // E[b]: byte 8r + b of this chunk lies in the last 32 bytes of an active message (the data root, decoder.rs:132-149)
+    // the row's window: rows 4..8 of a first chunk can hold state-root bytes (right behind the compact number, decoder.rs:121-128),
+    // every other row data-root bytes (the last 32 bytes of the message, :132-149).  E[b]: byte 8r + b of this chunk lies in the
+    // window's 32 bytes of an active message
+    const bool srw = d.first && r >= 4 && r <= 8;
+    const uint32_t clen = d.mode == 0 ? 1 : d.mode == 1 ? 2 : d.mode == 2 ? 4 : 5, kof = srw ? 32 + clen : d.size - 32;
     uint64_t eb = 0;
     for (int bq = 0; bq < 8; ++bq) {
         const uint32_t pos = d.t - d.inc + 8 * r + bq;
-        eb |= (uint64_t)((d.act && pos + 32 >= d.size && pos < d.size) ? 1 : 0) << bq;
+        eb |= (uint64_t)((d.act && pos >= kof && pos < kof + 32) ? 1 : 0) << bq;
     }
+    const uint64_t mdf = d.first ? (uint64_t)(d.mode == 0) | ((uint64_t)(d.mode == 1) << 1) | ((uint64_t)(d.mode == 3) << 2) : 0;
     st(SW_FLAGS) = (uint64_t)d.act | ((uint64_t)d.fin << 1) | ((uint64_t)d.first << 2) | ((uint64_t)(cap ? 1 : 0) << 3) | ((uint64_t)((d.first && d.act) ? 1 : 0) << 4) |
-                   ((uint64_t)d.inc << 8) | (cnt << 16) | (mk << 24) | (eb << 32) | ((uint64_t)d.size << 40);
+                   (mdf << 5) | ((uint64_t)d.inc << 8) | (cnt << 16) | (mk << 24) | (eb << 32) | ((uint64_t)d.size << 40);
     st(SW_TN) = (uint64_t)d.t | ((uint64_t)d.num << 32);
+    st(SW_WIN) = (uint64_t)kof | ((uint64_t)(srw ? 0 : 1) << 32);
     __syncthreads();
     rc_part[(size_t)blockIdx.x * 256 + threadIdx.x] = rc_lds[threadIdx.x];
 }
@@ -271,6 +282,8 @@ static void blake_expand_table(std::vector<ExpandEntry>& ent, std::vector<uint32
     add(SW_FLAGS, INC, 8, 8), add(SW_FLAGS, CNT, 16, 8);
     for (int i = 0; i < 8; ++i) add(SW_FLAGS, IB0 + i, 8 + i, 1), add(SW_FLAGS, MK0 + i, 24 + i, 1), add(SW_FLAGS, E0 + i, 32 + i, 1);
     add(SW_FLAGS, SZ, 40, 24);
+    add(SW_FLAGS, MDF0, 5, 1), add(SW_FLAGS, MDF1, 6, 1), add(SW_FLAGS, MDF3, 7, 1);
+    add(SW_WIN, KOF, 0, 24), add(SW_WIN, TR, 32, 1);
     add(SW_TN, T, 0, 32), add(SW_TN, NUM, 32, 32);
     for (int i = 0; i < 32; ++i) add(SW_TN, TB0 + i, i, 1);
     off.assign(1, 0);
@@ -436,13 +449,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_AUX_WAVE
             p[q] = gl2_mul(du, dv), s[q] = gl2_add(du, dv);
         }
         four(p, s, HM0);
-        // bus sends of this row (it is the "next" row of its pair; r = its index in the block).  Data root: byte b under E[b].
+        // bus sends of this row (it is the "next" row of its pair; r = its index in the block): byte b under E[b] as (leaf, position
+        // in the root, byte, tree) -- state root (tree 0) on rows 4..8 of a first chunk, data root (tree 1) elsewhere
         {
             const gl2 g3 = gl2_mul(g2, gamma), g4 = gl2_mul(g2, g2);
             const int r = (int)(i & 15);
             const uint64_t leaf = gl_sub(N(NUM), a.first_number);
-            const uint64_t pos0 = gl_add(gl_sub(gl_add(gl_sub(N(T), N(INC)), (uint64_t)(8 * r)), N(SZ)), 32);
-            const gl2 bbase = gl2_add(beta, gl2_add(gl2{leaf, 0}, gl2_scale(g4, TAG_BYTE)));
+            const uint64_t pos0 = gl_sub(gl_add(gl_sub(N(T), N(INC)), (uint64_t)(8 * r)), N(KOF));
+            const gl2 bbase = gl2_add(beta, gl2_add(gl2{leaf, 0}, gl2_add(gl2_scale(g3, N(TR)), gl2_scale(g4, TAG_BYTE))));
 #pragma unroll 1
             for (int pair = 0; pair < 4; ++pair) {
                 gl2 h{0, 0};
@@ -456,22 +470,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_AUX_WAVE
                 store(HB0 + pair, h);
                 hsum = gl2_add(hsum, h);
             }
-            // state root words: rows 5..8 send bytes 0..3 (words 1, 3, 5, 7), rows 4..7 send bytes 4..7 (words 0, 2, 4, 6) of a first chunk
-            gl2 h{0, 0};
-            const uint64_t fa = a.bus_on ? N(FA) : 0;
-            const bool su = r >= 5 && r <= 8, sv = r >= 4 && r <= 7;
-            if (fa && (su || sv)) {
-                const uint64_t node = gl_add(leaf, a.tree_size);
-                const gl2 wbase = gl2_add(beta, gl2_add(gl2_scale(gamma, node), gl2_scale(g4, TAG_WORD)));
-                const uint64_t wu = (N(MB0) << 24) | (N(MB0 + 1) << 16) | (N(MB0 + 2) << 8) | N(MB0 + 3);
-                const uint64_t wv = (N(MB0 + 4) << 24) | (N(MB0 + 5) << 16) | (N(MB0 + 6) << 8) | N(MB0 + 7);
-                const uint64_t ju = su ? (uint64_t)(2 * (r - 5) + 1) : 0, jv = sv ? (uint64_t)(2 * (r - 4)) : 0;
-                const gl2 du = gl2_add(wbase, gl2_add(gl2_scale(g2, ju), gl2_scale(g3, wu))), dv = gl2_add(wbase, gl2_add(gl2_scale(g2, jv), gl2_scale(g3, wv)));
-                const gl2 num = gl2_add(gl2_scale(dv, su ? fa : 0), gl2_scale(du, sv ? fa : 0));
-                h = gl2_mul(num, gl2_inv(gl2_mul(du, dv)));
-            }
-            store(HS, h);
-            hsum = gl2_add(hsum, h);
         }
         // table helper of this row: ht = M1 / D_t1 + M2 / D_t2
         const uint64_t m1 = N(M1), m2 = N(M2);
@@ -542,14 +540,16 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
     VX_CHECK(stride % 128 == 0 && stride > 0, "blake trace: stride %zu must be a positive multiple of 128", stride);
     VX_CHECK(n_headers >= 1 && n_headers * stride <= headers->n * 8, "blake trace: headers exceed the buffer");
     VX_CHECK(log_n >= blk::TABLE_LOG && log_n <= 24, "blake trace: log_n %d out of range [16, 24] (the trace holds one copy of the 2^16-row lookup tables)", log_n);
-    VX_CHECK(first_block_number >= (1u << 14) && (uint64_t)first_block_number + n_headers <= (1u << 30),
-             "blake trace: block numbers %u.. are outside the 4-byte SCALE compact range [2^14, 2^30) this AIR covers", first_block_number);
+    VX_CHECK((uint64_t)first_block_number + n_headers <= (1ULL << 32), "blake trace: block numbers %u.. overflow 32 bits", first_block_number);
     const size_t n = (size_t)1 << log_n, n_blocks = n >> 4;
     VX_CHECK(trace_out->n >= n * blk::COLS, "blake trace: trace buffer holds %zu < %zu elements", trace_out->n, n * (size_t)blk::COLS);
     std::vector<uint32_t> base(n_headers);
     size_t n_real = 0;
     for (size_t i = 0; i < n_headers; ++i) {
-        VX_CHECK(sizes[i] <= stride && sizes[i] >= 36 && sizes[i] < (1u << 24), "blake trace: header %zu has size %u", i, sizes[i]);
+        const uint32_t clen = (uint32_t[]){1, 2, 4, 5}[compact_mode(first_block_number + (uint32_t)i)];  // parent hash + compact number must fit
+        VX_CHECK(sizes[i] <= stride && sizes[i] >= 32 + clen && sizes[i] < (1u << 24), "blake trace: header %zu has size %u", i, sizes[i]);
+        VX_CHECK(!tree_size || sizes[i] >= 104,
+                 "blake trace: header %zu has size %u (shorter than 104 bytes its state root and data root would share trace rows; no Avail header is)", i, sizes[i]);
         base[i] = (uint32_t)n_real;
         n_real += (sizes[i] + 127) / 128;
     }
@@ -601,6 +601,7 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
             d.t = d.fin ? sizes[i] : 128 * (cidx + 1);
             d.msg_off = i * stride + 128 * (size_t)cidx;
             d.num = first_block_number + (uint32_t)i;
+            d.mode = compact_mode(d.num);
             d.size = sizes[i];
             memcpy(d.D, D, 32);
         }
@@ -611,9 +612,10 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
         memset(&d, 0, sizeof d);
         d.fin = d.first = 1;
         d.act = 0;
-        d.inc = d.t = d.size = 36;
+        d.inc = d.t = d.size = 40;
         d.msg_off = ~0ULL;
         d.num = first_block_number + (uint32_t)n_headers - 1;
+        d.mode = compact_mode(d.num);
         memcpy(d.D, D, 32);
     }
     VX_HIP(hipMemcpyAsync(d_desc, descs.data(), n_blocks * sizeof(BlockDesc), hipMemcpyHostToDevice, ctx->stream));

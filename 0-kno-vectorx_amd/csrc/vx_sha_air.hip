@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void k_sha_tree_aux(const uint64_t* tr, uint64
     const size_t r = row & 63, bk = (row >> 6) & 1, pair = row >> 7, tree = pair / N, g = pair % N;
     const bool msg = bk == 0 && r < 16, bottom = g >= N / 2, inner = g >= 1 && g < N / 2, send = bk == 1 && r == 63 && g >= 2;
     const uint64_t en = msg ? tr[(size_t)(r < 8 ? sht::ENL : sht::ENR) * n + row] : 0;
-    const uint64_t m_word = msg && (inner || (bottom && tree == 0 && en)) ? 1 : 0, m_byte = msg && bottom && tree == 1 && en ? 1 : 0;
+    const uint64_t m_word = msg && inner ? 1 : 0, m_byte = msg && bottom && en ? 1 : 0;  // inner nodes take words, the bottom level of both trees bytes
     auto word = [&](int col0, int nb) -> uint64_t {
         uint64_t v = 0;
         for (int i = 0; i < nb; ++i) v |= tr[(size_t)(col0 + i) * n + row] << i;
@@ -259,14 +259,14 @@ __global__ __launch_bounds__(256) void k_sha_tree_aux(const uint64_t* tr, uint64
         const gl2 g2 = gl2_mul(gamma, gamma), g3 = gl2_mul(g2, gamma), g4 = gl2_mul(g2, g2);
         const gl2 tag_w = gl2_scale(g4, blk::TAG_WORD), tag_b = gl2_scale(g4, blk::TAG_BYTE);
         const uint64_t c = r >= 8 ? 1 : 0, jj = r & 7, w0 = (msg ? word(W0B, 32) : 0);
-        const uint64_t cid = (bottom && tree == 1) ? 2 * g - N + c : 2 * g + c;
+        const uint64_t cid = bottom ? 2 * g - N + c : 2 * g + c;  // a leaf's index / an inner child's node id
         gl2 d[13];
         uint64_t m[13];  // 1 = receive (-1), 2 = send (+1), 0 = inactive
         d[0] = gl2_add(gl2_add(beta, gl2{(uint64_t)tree, 0}), gl2_add(gl2_add(gl2_scale(gamma, cid), gl2_scale(g2, jj)), gl2_add(gl2_scale(g3, w0), tag_w)));
         m[0] = m_word;
         for (int q = 0; q < 4; ++q) {
             const uint64_t byte = (w0 >> (24 - 8 * q)) & 0xFF;
-            d[1 + q] = gl2_add(gl2_add(beta, gl2{cid, 0}), gl2_add(gl2_add(gl2_scale(gamma, 4 * jj + q), gl2_scale(g2, byte)), tag_b));
+            d[1 + q] = gl2_add(gl2_add(beta, gl2{cid, 0}), gl2_add(gl2_add(gl2_scale(gamma, 4 * jj + q), gl2_scale(g2, byte)), gl2_add(gl2_scale(g3, tree), tag_b)));
             m[1 + q] = m_byte;
         }
         for (int j = 0; j < 8; ++j) {

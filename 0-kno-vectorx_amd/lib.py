@@ -31,7 +31,7 @@ SYMBOLS = [
 ]
 
 VX_AIR_FIBONACCI, VX_AIR_MIX, VX_AIR_BLAKE_CHAIN, VX_AIR_LOOKUP = 1, 2, 6, 5
-VX_BLAKE_AIR_COLS, VX_BLAKE_AIR_AUX_COLS = 740, 278
+VX_BLAKE_AIR_COLS, VX_BLAKE_AIR_AUX_COLS = 745, 276
 VX_AIR_SHA_TREE = {256: 7, 512: 8, 16: 9}
 VX_AIR_SHA_CHAIN, VX_SHA_AIR_COLS, VX_SHA_AIR_AUX_COLS, VX_SHA_TREE_AIR_COLS = 4, 414, 4, 412
 VX_AIR_ED25519 = {17: 10, 16: 12}

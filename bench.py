@@ -37,7 +37,7 @@ PROFILE = "P15k"
 # 30,720 compressions x 16 rows -> 2^19 rows, 731 main + 268 auxiliary columns), measured on a 1024-column slab.
 NTT_LOG_N = 19
 NTT_COLS = 1024
-BLAKE_COLS = 740 + 278  # main + auxiliary (logUp) columns
+BLAKE_COLS = 745 + 276  # main + auxiliary (logUp) columns
 
 
 class Workload:
@@ -138,9 +138,9 @@ def ntt_roofline(ctx, iters=10):
 
 def poseidon_roofline(ctx, vx, iters=3):
     """The proof's dominant kernel, k_hash_leaves (Poseidon sponge over the rows of the trace LDE), on the shape of the
-    main-trace commitment of this workload: 2^20 leaves x 740 columns.  Integer-ALU work: priced against the VALU-issue
+    main-trace commitment of this workload: 2^20 leaves x 745 columns.  Integer-ALU work: priced against the VALU-issue
     peak of the permutation code (instruction count x issue cycles, see below), and its HBM fraction beside it."""
-    log_leaves, cols = (20 if N_HEADERS == 256 else 21), 740
+    log_leaves, cols = (20 if N_HEADERS == 256 else 21), 745
     n = 1 << log_leaves
     buf = ctx.alloc(n * cols)
     ctx.fill_random(buf, n * cols, 11)
@@ -411,7 +411,7 @@ def main():
                            "sub-proof structure is replaced by flat tables",
             "config": {
                 "workload": f"header_range_{N_HEADERS}: {N_HEADERS} x 15,360-B synthetic Avail headers (P15k), 300 authorities, one input per GPU; "
-                            f"{120 * N_HEADERS:,} Blake2b compressions -> BlakeChainAir (byte-lookup AIR) trace 2^{19 if N_HEADERS == 256 else 20} rows x (740 main + 278 logUp) columns + ShaTreeAir (SHA-256 Merkle table, 2^{16 if N_HEADERS == 256 else 17} x 428) "
+                            f"{120 * N_HEADERS:,} Blake2b compressions -> BlakeChainAir (byte-lookup AIR) trace 2^{19 if N_HEADERS == 256 else 20} rows x (745 main + 276 logUp) columns + ShaTreeAir (SHA-256 Merkle table, 2^{16 if N_HEADERS == 256 else 17} x 428) "
                             "+ ShaChainAir (2^16 x 418) + EdAir (201 signatures, 2^16 x 1527) + Sha512Air (2^15 x 805) on the same logUp bus",
                 "complete_proof": False,
                 "complete_statement": True,

@@ -198,21 +198,20 @@ int32_t vx_sha256_pairs(vx_ctx* ctx, const uint8_t* pairs64, size_t n, uint8_t* 
 /* ---- K8: BlakeChainAir trace generation (the Blake2b witness behind hash_encoded_header,
  * circuits/builder/header.rs:14-19, and the parent-hash links of
  * circuits/builder/subchain_verification.rs:163-177).  headers as for vx_verify_subchain (stride a
- * multiple of 128).  Writes the column-major MAIN trace (731 columns x 2^log_n rows, 16 rows per
+ * multiple of 128).  Writes the column-major MAIN trace (745 columns x 2^log_n rows, 16 rows per
  * compression, padded with inactive blocks; byte cells + the multiplicities of the two 2^16-row XOR
  * lookup tables, so log_n >= 16) into trace_out, the 20 public inputs (trusted hash, target hash as
  * 32-bit little-endian limbs, first and last block number, tree_size, bus flag) and optionally the digests
  * (host).  tree_size = 16 / 256 / 512: the state roots (decoder.rs:121-128) and data roots (:132-149) of the
  * headers go onto the logUp bus towards a ShaTreeAir of that many leaves (vx_header_range_prove proves both
- * tables under shared challenges); tree_size = 0: a stand-alone hash-chain proof.  The 278
+ * tables under shared challenges); tree_size = 0: a stand-alone hash-chain proof.  The 276
  * auxiliary (logUp) columns are derived inside vx_stark_prove once the lookup challenges exist.
- * KNOWN DEVIATION from decoder.rs:39-92 (which decodes all four SCALE compact modes): the AIR proves
- * that header i carries block number first_block_number + i as a 4-byte (mode 2) compact int, i.e.
- * block numbers in [2^14, 2^30) -- every Avail height since block 16,384; other ranges are refused with
- * VX_ERR_ARG (tests/test_gpu_decoders.py pins the code).  The native path (vx_verify_subchain,
- * vx_decode_header_batch) handles all four modes.
+ * The AIR proves that header i carries block number first_block_number + i as a SCALE compact int in
+ * whichever of the four modes that number takes (decoder.rs:39-92) and reads the state root right behind it.
+ * KNOWN DEVIATION: a header shorter than 104 bytes (whose state root and data root would share trace rows) is
+ * refused with VX_ERR_ARG; parent hash + number + three 32-byte roots already exceed that in every Avail header.
  * Prove it with vx_stark_prove(ctx, VX_AIR_BLAKE_CHAIN, ...). */
-enum { VX_AIR_BLAKE_CHAIN = 6, VX_BLAKE_AIR_COLS = 740, VX_BLAKE_AIR_AUX_COLS = 278 };
+enum { VX_AIR_BLAKE_CHAIN = 6, VX_BLAKE_AIR_COLS = 745, VX_BLAKE_AIR_AUX_COLS = 276 };
 int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_headers,
                              const uint8_t trusted_hash[32], uint32_t first_block_number, uint32_t tree_size, int log_n, vx_buf* trace_out,
                              uint64_t public_inputs_out[20], uint8_t* digests_out);

@@ -41,10 +41,14 @@ ID = 6
 S_A1, S_D1, S_C1, S_B1, S_A2, S_D2, S_C2, S_L, S_T = range(9)
 CAR0, MS0, MB0, HL0, D0 = 576, 608, 640, 648, 664
 ACT, FIN, FIRST, CAP, T, INC, NUM, FA = range(672, 680)
-TB0, IB0, MK0, CNT, M1, M2, SZ, E0, COLS = 680, 712, 720, 728, 729, 730, 731, 732, 740
-# helpers: 128 of the G functions, 4 message-byte range checks, 4 data-root byte sends, 1 state-root word sends, table helper, running sum Z
-N_HELP = 139
-HM0, HB0, HS, HT, ZZ = 128, 132, 136, 137, 138
+TB0, IB0, MK0, CNT, M1, M2, SZ, E0 = 680, 712, 720, 728, 729, 730, 731, 732
+# SCALE compact mode of the block number (one-hot, only on first chunks; mode 2 = FIRST - the other three), and per row
+# the offset the bus positions are counted from and the tree the row's bytes go to
+MDF0, MDF1, MDF3, KOF, TR, COLS = 740, 741, 742, 743, 744, 745
+COMPACT_LEN = (1, 2, 4, 5)
+# helpers: 128 of the G functions, 4 message-byte range checks, 4 root byte sends, table helper, running sum Z
+N_HELP = 138
+HM0, HB0, HT, ZZ = 128, 132, 136, 137
 AUX, CHAL, AUXPUB = 2 * N_HELP, 4, 1
 PUB, PERIODIC, PERIOD_LOG = 20, 20, 16
 # tuples on the bus are (t0, t1, t2, t3, tag): fingerprint t0 + g t1 + g^2 t2 + g^3 t3 + g^4 tag
@@ -182,16 +186,12 @@ def lookups(loc, nxt, sel, pub=None):
     for r in range(1, 15):
         r8n = r8n + sel[r] * (8 * (r + 1))  # 8 * (row index of the next row); sel[15] -> next row is row 0
     leaf = nxt[NUM] - pub[16]
-    pos0 = nxt[T] - nxt[INC] + r8n - nxt[SZ] + 32
+    pos0 = nxt[T] - nxt[INC] + r8n - nxt[KOF]  # position of byte 0 of the next row, counted from the row's window offset
     bus_on = pub[19]  # 0 for a stand-alone proof (nothing on the bus, published total 0), 1 next to the Merkle AIR
     live = nxt[ACT] * bus_on  # an inactive (padding / junk) message shares its block number with the last real header: it must not send
-    out += [(nxt[E0 + b] * live, TAG_BYTE, (leaf, pos0 + b, nxt[MB0 + b])) for b in range(8)]
-    su, ju = sel[4] + sel[5] + sel[6] + sel[7], sel[4] + sel[5] * 3 + sel[6] * 5 + sel[7] * 7   # next row 5..8: words 1, 3, 5, 7 (bytes 0..3)
-    sv, jv = sel[3] + sel[4] + sel[5] + sel[6], sel[4] * 2 + sel[5] * 4 + sel[6] * 6             # next row 4..7: words 0, 2, 4, 6 (bytes 4..7)
-    be = lambda o: ((nxt[MB0 + o] * 256 + nxt[MB0 + o + 1]) * 256 + nxt[MB0 + o + 2]) * 256 + nxt[MB0 + o + 3]  # noqa: E731
-    node = leaf + pub[18]
-    zero = sel[0] * 0
-    out += [(nxt[FA] * su * bus_on, TAG_WORD, (zero, node, ju, be(0))), (nxt[FA] * sv * bus_on, TAG_WORD, (zero, node, jv, be(4)))]
+    # byte b of the next row's natural message word under the flag E[b]: (leaf, position in the root, byte, tree) -- tree 0 = state
+    # root (rows 4..8 of a first chunk, offset 32 + length of the compact block number), tree 1 = data root (offset size - 32)
+    out += [(nxt[E0 + b] * live, TAG_BYTE, (leaf, pos0 + b, nxt[MB0 + b], nxt[TR])) for b in range(8)]
     return out
 
 
@@ -200,7 +200,7 @@ def rotr(x, n):
     return ((x >> n) | (x << (64 - n))) & M64
 
 
-def gen_blocks(messages, n_blocks, trusted_hash, first_number):
+def gen_blocks(messages, n_blocks, trusted_hash, first_number, bus=False):
     """Block descriptors for the given messages (each must start with the previous digest and carry
     its block number as a 4-byte SCALE compact int at bytes 32..36)."""
     import hashlib
@@ -210,7 +210,10 @@ def gen_blocks(messages, n_blocks, trusted_hash, first_number):
     for msg in messages:
         assert msg[:32] == D, "message does not link to the previous digest"
         num += 1
-        assert int.from_bytes(msg[32:36], "little") == 4 * num + 2, "block number is not the 4-byte compact encoding of the expected number"
+        mode = msg[32] & 3
+        got = (msg[32] >> 2, int.from_bytes(msg[32:34], "little") >> 2, int.from_bytes(msg[32:36], "little") >> 2, int.from_bytes(msg[33:37], "little"))[mode]
+        assert got == num and (mode != 3 or msg[32] == 3), "block number is not a SCALE compact encoding of the expected number"
+        assert len(msg) >= (104 if bus else 32 + COMPACT_LEN[mode]), "a header this short would have its state root and its data root in the same rows"
         h = list(IVP)
         nchunks = max(1, (len(msg) + 127) // 128)
         t = 0
@@ -219,14 +222,30 @@ def gen_blocks(messages, n_blocks, trusted_hash, first_number):
             fin = c == nchunks - 1
             inc = len(chunk) if fin else 128
             t += inc
-            blocks.append(dict(m=chunk + bytes(128 - len(chunk)), h=list(h), t=t, inc=inc, fin=fin, first=c == 0, act=1, D=D, num=num))
+            blocks.append(dict(m=chunk + bytes(128 - len(chunk)), h=list(h), t=t, inc=inc, fin=fin, first=c == 0, act=1, D=D, num=num, mode=mode))
             h = compress(h, blocks[-1]["m"], t, fin)[0]
         D = hashlib.blake2b(msg, digest_size=32).digest()
         assert b"".join(x.to_bytes(8, "little") for x in h[:4]) == D
     assert len(blocks) <= n_blocks, f"{len(blocks)} compressions do not fit {n_blocks} blocks"
     while len(blocks) < n_blocks:  # padding: inactive one-chunk messages that still satisfy the link + number rules
-        blocks.append(dict(m=D + (4 * num + 2).to_bytes(4, "little") + bytes(92), h=list(IVP), t=36, inc=36, fin=True, first=True, act=0, D=D, num=num))
+        blocks.append(pad_block(D, num))
     return blocks, D, num
+
+
+def compact_u32(v):
+    """SCALE Compact<u32> (/root/reference circuits/builder/decoder.rs:39-92 is its inverse) and its mode."""
+    if v < 1 << 6:
+        return bytes([v << 2]), 0
+    if v < 1 << 14:
+        return ((v << 2) | 1).to_bytes(2, "little"), 1
+    if v < 1 << 30:
+        return ((v << 2) | 2).to_bytes(4, "little"), 2
+    return b"\x03" + v.to_bytes(4, "little"), 3
+
+
+def pad_block(D, num):
+    enc, mode = compact_u32(num)
+    return dict(m=D + enc + bytes(96 - len(enc)), h=list(IVP), t=40, inc=40, fin=True, first=True, act=0, D=D, num=num, size=40, mode=mode)
 
 
 def compress(h, m_bytes, t, fin):
@@ -324,9 +343,16 @@ def block_rows(blk):
             t[MK0 + b, r] = 1 if 8 * r + b < blk["inc"] else 0
         t[CNT, r] = min(blk["inc"], 8 * (r + 1))
         t[SZ, r] = blk["size"]
+        srw = blk["first"] and 4 <= r <= 8  # the rows that can hold state-root bytes
+        clen = COMPACT_LEN[blk["mode"]]
+        if blk["first"]:
+            for col, m_ in ((MDF0, 0), (MDF1, 1), (MDF3, 3)):
+                t[col, r] = 1 if blk["mode"] == m_ else 0
+        t[KOF, r], t[TR, r] = (32 + clen if srw else blk["size"] - 32), (0 if srw else 1)
         for b in range(8):
             pos = blk["t"] - blk["inc"] + 8 * r + b
-            t[E0 + b, r] = 1 if (blk["act"] and blk["size"] - 32 <= pos < blk["size"]) else 0
+            lo = 32 + clen if srw else blk["size"] - 32
+            t[E0 + b, r] = 1 if (blk["act"] and lo <= pos < lo + 32) else 0
         if r == 0:
             for w in range(16):
                 put_out(r, w, v0[w])
@@ -390,15 +416,16 @@ def gen_trace(messages, log_n, trusted_hash, first_number=None, forge=None, tree
     n = 1 << log_n
     assert log_n >= TABLE_LOG, "the trace must hold one copy of the 2^16-row lookup tables"
     if first_number is None:
-        first_number = (int.from_bytes(messages[0][32:36], "little") - 2) // 4
+        m0 = messages[0]
+        first_number = (m0[32] >> 2, int.from_bytes(m0[32:34], "little") >> 2, int.from_bytes(m0[32:36], "little") >> 2, int.from_bytes(m0[33:37], "little"))[m0[32] & 3]
     # padding blocks are identical: generate each distinct block once
-    real_blocks, target, last_number = gen_blocks(messages, sum(max(1, (len(m) + 127) // 128) for m in messages), trusted_hash, first_number)
+    real_blocks, target, last_number = gen_blocks(messages, sum(max(1, (len(m) + 127) // 128) for m in messages), trusted_hash, first_number, bus=bool(tree_size))
     bi = 0
     for msg in messages:  # the size register: every chunk of a message knows the message's length
         for _ in range(max(1, (len(msg) + 127) // 128)):
             real_blocks[bi]["size"] = len(msg)
             bi += 1
-    pad = dict(m=target + (4 * last_number + 2).to_bytes(4, "little") + bytes(92), h=list(IVP), t=36, inc=36, fin=True, first=True, act=0, D=target, num=last_number, size=36)
+    pad = pad_block(target, last_number)
     blocks = real_blocks + [pad]
     if forge is not None:
         blocks, target, last_number = forge(real_blocks, pad, target, last_number)
@@ -451,8 +478,10 @@ class BlakeChainAir:
         two32 = 1 << 32
 
         # ---- 1. booleans
-        for col in list(range(TB0, TB0 + 32)) + list(range(IB0, IB0 + 8)) + list(range(MK0, MK0 + 8)) + [ACT, FIN, FIRST, CAP, FA]:
+        for col in list(range(TB0, TB0 + 32)) + list(range(IB0, IB0 + 8)) + list(range(MK0, MK0 + 8)) + [ACT, FIN, FIRST, CAP, FA, MDF0, MDF1, MDF3]:
             c.constraint(loc[col] * (loc[col] - 1))
+        mdf2 = loc[FIRST] - loc[MDF0] - loc[MDF1] - loc[MDF3]  # exactly one mode on a first chunk, none elsewhere
+        c.constraint(mdf2 * (mdf2 - 1))
         # ---- 2. carries of the three-operand additions
         for k in range(8):
             for q in range(4):
@@ -555,9 +584,22 @@ class BlakeChainAir:
         for s in range(4):
             for h in range(2):
                 c.constraint(sel[0] * loc[FIRST] * (loc[MS(s, h)] - loc[D0 + 2 * s + h]))
-        c.constraint(sel[0] * loc[FIRST] * (loc[MS(4, 0)] - (4 * loc[NUM] + 2)))  # decoder.rs:64-66, 4-byte compact mode
+        # the block number, bytes 32.. of a first chunk = the natural word of row 4: SCALE compact, all four modes (decoder.rs:39-92)
+        num = loc[NUM]
+        c.constraint(sel[4] * (loc[MDF0] * (mb[0] - num * 4)
+                               + loc[MDF1] * (mb[0] + mb[1] * 256 - num * 4 - 1)
+                               + mdf2 * (mb[0] + mb[1] * 256 + mb[2] * 65536 + mb[3] * (1 << 24) - num * 4 - 2)
+                               + loc[MDF3] * (mb[1] + mb[2] * 256 + mb[3] * 65536 + mb[4] * (1 << 24) - num)))
+        c.constraint(sel[4] * loc[MDF3] * (mb[0] - 3))
+        # the window the row's bus positions are counted from, and its tree: state root on rows 4..8 of a first chunk (right
+        # behind the compact number), data root = the last 32 bytes everywhere else
+        s48 = sel[4] + sel[5] + sel[6] + sel[7] + sel[8]
+        srw = loc[FIRST] * s48
+        clen = loc[MDF0] + loc[MDF1] * 2 + mdf2 * 4 + loc[MDF3] * 5
+        c.constraint(loc[TR] - (1 - srw))
+        c.constraint(loc[KOF] - (s48 * (loc[FIRST] * 32 + clen) + (1 - srw) * (loc[SZ] - 32)))
         # ---- 7. per-block registers
-        for col in (ACT, FIN, FIRST, CAP, T, INC, NUM, FA):
+        for col in (ACT, FIN, FIRST, CAP, T, INC, NUM, FA, MDF0, MDF1, MDF3):
             c.constraint(in_blk * (nxt[col] - loc[col]))
         c.constraint(loc[CAP] - loc[ACT] * loc[FIN])
         c.constraint(loc[FA] - loc[FIRST] * loc[ACT])

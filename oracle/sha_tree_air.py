@@ -14,8 +14,8 @@ bit-decomposed, one round per row, same column layout); everything positional (w
 ids, which tree) is a PERIODIC column, so the only witness besides the SHA rows is the pair of leaf-enable flags
 ENL / ENR of a bottom-level node: a disabled leaf must be zero and takes nothing from the bus.
 Bus (tuples (t0, t1, t2, t3, tag), see blake_air): row r < 16 of a DATA block receives message word r --
-  inner nodes and the bottom level of tree 0:  (tree, child id, r mod 8, word)            [words]
-  bottom level of tree 1 (data roots):         (leaf, 4 (r mod 8) + q, byte q of the word)  q = 0..3  [bytes]
+  inner nodes:                  (tree, child id, r mod 8, word)                          [words, from the children's PAD blocks]
+  bottom level of both trees:   (leaf, 4 (r mod 8) + q, byte q of the word, tree)  q = 0..3  [bytes, from the header bytes]
 and row 63 of a PAD block sends the node's digest (tree, g, j, word_j), j < 8, except for the root, whose digest is
 the public input.  The table's net bus total S is published as S / n.
 """
@@ -35,8 +35,8 @@ COLS = H.COLS
 N_HELP = 8  # 7 helper elements (13 lookups) + running sum
 AUX, CHAL, AUXPUB, PUB = 2 * N_HELP, 4, 1, 16
 # periodic columns
-P_SEL0, P_SEL63, P_SCHED, P_K, P_DATA, P_TREE, P_PWA, P_PWL, P_PWR, P_PBL, P_PBR, P_CID, P_JJ, P_PS, P_ROOT, P_GID = range(16)
-PERIODIC = 16
+P_SEL0, P_SEL63, P_SCHED, P_K, P_DATA, P_TREE, P_PWA, P_PBL, P_PBR, P_CID, P_JJ, P_PS, P_ROOT, P_GID = range(14)
+PERIODIC = 14
 
 
 def make_air(N):
@@ -52,17 +52,15 @@ def make_air(N):
         left, right = msg & (r < 8), msg & (r >= 8)
         bottom, inner = g >= N // 2, (g >= 1) & (g < N // 2)
         c = (r >= 8).astype(np.int64)
-        cid = np.where(bottom & (tree == 1), 2 * g - N + c, 2 * g + c) * msg
+        cid = np.where(bottom, 2 * g - N + c, 2 * g + c) * msg  # a bottom-level child is a leaf: its index; an inner child: its node id
         out = [None] * PERIODIC
         for k, vals in enumerate(H.periodic_values()):
             out[k] = list(vals)
         out[P_DATA] = [1] * 64 + [0] * 64
         out[P_TREE] = tree.tolist()
         out[P_PWA] = (msg & inner).astype(np.int64).tolist()
-        out[P_PWL] = (left & bottom & (tree == 0)).astype(np.int64).tolist()
-        out[P_PWR] = (right & bottom & (tree == 0)).astype(np.int64).tolist()
-        out[P_PBL] = (left & bottom & (tree == 1)).astype(np.int64).tolist()
-        out[P_PBR] = (right & bottom & (tree == 1)).astype(np.int64).tolist()
+        out[P_PBL] = (left & bottom).astype(np.int64).tolist()
+        out[P_PBR] = (right & bottom).astype(np.int64).tolist()
         out[P_CID] = cid.tolist()
         out[P_JJ] = ((r % 8) * msg).tolist()
         send = (blk == 1) & (r == 63)
@@ -73,7 +71,7 @@ def make_air(N):
 
     class ShaTreeAir:
         ID, TREE_SIZE = IDS[N], N
-        PERIOD_LOGS = [6, 6, 6, 6, 7] + [L] * 11
+        PERIOD_LOGS = [6, 6, 6, 6, 7] + [L] * 9
 
         @staticmethod
         def lookups(loc, per):
@@ -87,10 +85,10 @@ def make_air(N):
                     acc = acc + acc + b
                 return acc
 
-            out = [(0 - (per[P_PWA] + per[P_PWL] * en_l + per[P_PWR] * en_r), TAG_WORD, (per[P_TREE], per[P_CID], per[P_JJ], val(w0)))]
+            out = [(0 - per[P_PWA], TAG_WORD, (per[P_TREE], per[P_CID], per[P_JJ], val(w0)))]
             mb = 0 - (per[P_PBL] * en_l + per[P_PBR] * en_r)
             for q in range(4):
-                out.append((mb, TAG_BYTE, (per[P_CID], per[P_JJ] * 4 + q, val(w0[24 - 8 * q: 32 - 8 * q]))))
+                out.append((mb, TAG_BYTE, (per[P_CID], per[P_JJ] * 4 + q, val(w0[24 - 8 * q: 32 - 8 * q]), per[P_TREE])))
             for j in range(8):
                 out.append((per[P_PS], TAG_WORD, (per[P_TREE], per[P_GID], per[P_SEL0] * 0 + j, loc[H.FFV0 + j])))
             return out
@@ -122,8 +120,8 @@ def make_air(N):
             for j in range(8):
                 c.constraint(per[P_ROOT] * (loc[H.FFV0 + j] - (pub[j] + per[P_TREE] * (pub[8 + j] - pub[j]))))
             w0 = val(loc, H.W0B)
-            c.constraint((per[P_PWL] + per[P_PBL]) * (1 - loc[ENL]) * w0)
-            c.constraint((per[P_PWR] + per[P_PBR]) * (1 - loc[ENR]) * w0)
+            c.constraint(per[P_PBL] * (1 - loc[ENL]) * w0)
+            c.constraint(per[P_PBR] * (1 - loc[ENR]) * w0)
             # ---- 9. the bus (logUp): helpers and running sum of the local row
             ds = ShaTreeAir.denominators(loc, per, chal)
             hsum = None

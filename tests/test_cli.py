@@ -71,7 +71,7 @@ def test_build_verb_and_usage(tmp_path):
     r = run("header_range_256", "build", "--build-dir", str(tmp_path / "build"))
     assert r.returncode == 0, r.stderr
     d = json.load(open(tmp_path / "build" / "header_range_256.circuit.json"))
-    assert d["max_headers"] == 256 and d["stark_config"]["num_queries"] == 84 and d["airs"]["blake_chain"] == [6, 740, 278]
+    assert d["max_headers"] == 256 and d["stark_config"]["num_queries"] == 84 and d["airs"]["blake_chain"] == [6, 745, 276]
     assert run("rotate").returncode != 0  # a verb is required
 
 

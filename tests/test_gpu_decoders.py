@@ -101,10 +101,32 @@ def test_mode3_header_with_upper_bits_is_rejected_by_verify_subchain(ctx, vx, or
     assert oracle.verify_subchain(h, ch.sizes, 8, ch.trusted_block, ch.trusted_hash, ch.target_block)[0] != 0
 
 
-def test_blake_chain_air_number_range_is_pinned(ctx, vx):
-    """Known deviation (include/vx.h): the hash-chain AIR covers 4-byte-mode block numbers [2^14, 2^30) only --
-    decoder.rs:39-92 accepts all four modes natively.  The error is an argument error, not a wrong proof."""
-    ch = vx.synth.Chain(8, profile="Ptiny", stride=STRIDE, trusted_block=60)
+@pytest.mark.parametrize("trusted", [60, 16380, (1 << 30) - 4, (1 << 31) + 5])
+def test_header_range_proof_in_every_compact_mode(ctx, vx, trusted):
+    """The hash-chain AIR decodes the block number in all four SCALE compact modes (decoder.rs:39-92) and reads the state root right
+    behind it: chains that straddle 63/64, 16383/16384, 2^30-1/2^30 and one wholly in 5-byte mode are PROVEN (not only checked
+    natively), trace == the oracle's cell by cell, and the blob verifies -- both Merkle roots are what the native mirror computes."""
+    from oracle import blake_air as B
+
+    ch = vx.synth.Chain(8, profile="Ptiny", stride=STRIDE, trusted_block=trusted)
+    hb = ctx.from_host(ch.headers)
+    buf, pub, _ = ctx.blake_chain_trace(hb, STRIDE, ch.sizes, ch.trusted_hash, ch.trusted_block + 1, 16, tree_size=16)
+    msgs = [ch.headers[i, : ch.sizes[i]].tobytes() for i in range(8)]
+    want, wpub, _ = B.gen_trace(msgs, 16, ch.trusted_hash, tree_size=16)
+    bad = np.argwhere(buf.download().reshape(B.COLS, 1 << 16) != want)
+    assert bad.size == 0 and [int(x) for x in pub] == wpub, f"first differing cells (col,row): {bad[:5].tolist()}"
+    cfg = ctx.stark_config(num_queries=8)
+    out96, blob = ctx.header_range_prove(hb, STRIDE, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
+    assert out96 == ch.expected_outputs(16)
+    vx.lib.header_range_verify(blob, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg)
+
+
+def test_blake_chain_air_refuses_headers_shorter_than_104_bytes(ctx, vx):
+    """Known deviation (include/vx.h): a header whose state root and data root would share trace rows cannot be proven (it is
+    still checked natively).  The error is an argument error, not a wrong proof."""
+    ch = vx.synth.Chain(4, profile="Ptiny", stride=STRIDE)
+    sizes = ch.sizes.copy()
+    sizes[2] = 100
     with pytest.raises(vx.VxError) as e:
-        ctx.blake_chain_trace(ctx.from_host(ch.headers), STRIDE, ch.sizes, ch.trusted_hash, ch.trusted_block + 1, 16)
-    assert e.value.code == -1 and "4-byte SCALE compact range" in str(e.value)
+        ctx.blake_chain_trace(ctx.from_host(ch.headers), STRIDE, sizes, ch.trusted_hash, ch.trusted_block + 1, 16, tree_size=16)
+    assert e.value.code == -1 and "104" in str(e.value)

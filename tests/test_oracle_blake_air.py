@@ -37,9 +37,9 @@ def forged_trace(log_n):
     def forge(real, pad, tgt, last):
         junk = tgt + (4 * (last + 1) + 2).to_bytes(4, "little") + bytes(92) + bytes(40)  # 168 bytes = 2 chunks
         h0 = list(B.IVP)
-        b0 = dict(m=junk[:128], h=h0, t=128, inc=128, fin=False, first=True, act=1, D=tgt, num=last + 1, size=168)
+        b0 = dict(m=junk[:128], h=h0, t=128, inc=128, fin=False, first=True, act=1, D=tgt, num=last + 1, size=168, mode=2)
         h1 = B.compress(h0, b0["m"], 128, False)[0]
-        b1 = dict(m=junk[128:] + bytes(88), h=h1, t=168, inc=40, fin=True, first=False, act=0, D=tgt, num=last + 1, size=168)
+        b1 = dict(m=junk[128:] + bytes(88), h=h1, t=168, inc=40, fin=True, first=False, act=0, D=tgt, num=last + 1, size=168, mode=2)
         pad2 = dict(pad, m=tgt + (4 * (last + 1) + 2).to_bytes(4, "little") + bytes(92), num=last + 1)
         return real + [b0, b1, pad2], tgt, last + 1
 
@@ -48,7 +48,7 @@ def forged_trace(log_n):
 
 
 def test_trace_satisfies_constraints_and_detects_corruption(oracle):
-    msgs, trusted, target = make([300, 129, 36])
+    msgs, trusted, target = make([300, 129, 37])
     tr, pub, tgt = B.gen_trace(msgs, 16, trusted)
     assert tgt == target and pub[16:] == [70000, 70002, 0, 0]
     assert int(tr[B.M1].sum()) == 160 * 65536 and int(tr[B.M2].sum()) == 48 * 65536  # lookups per row: 12/16 * 192 + 2/16 * 64 + 8, 12/16 * 64

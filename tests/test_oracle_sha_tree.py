@@ -21,7 +21,8 @@ S.register_air(A)
 def make(lengths, trusted=hashlib.sha256(b"t").digest(), first=70000):
     msgs, d = [], trusted
     for k, n in enumerate(lengths):
-        m = d + (4 * (first + k) + 2).to_bytes(4, "little") + bytes((3 * i + n) & 0xFF for i in range(n - 36))
+        enc = B.compact_u32(first + k)[0]
+        m = d + enc + bytes((3 * i + n) & 0xFF for i in range(n - 32 - len(enc)))
         msgs.append(m)
         d = hashlib.blake2b(m, digest_size=32).digest()
     return msgs, trusted, d
@@ -39,7 +40,7 @@ def balance(apub_a, n_a, apub_b, n_b):
 
 
 def test_tree_constraints_roots_and_bus_balance(oracle):
-    msgs, trusted, _ = make([300, 129, 72, 131, 500])  # 72: state root and data root overlap; leaves 5..15 are zero leaves
+    msgs, trusted, _ = make([300, 129, 104, 131, 500])  # 104: the data root starts in the row after the state root's last; leaves 5..15 are zero leaves
     sr, dr = [m[36:68] for m in msgs], [m[-32:] for m in msgs]
     ttr, tpub = T.gen_trace(sr, dr, N)
     assert tpub == mirror_root(sr, N) + mirror_root(dr, N)
@@ -77,7 +78,7 @@ def test_tree_constraints_roots_and_bus_balance(oracle):
 
 
 def test_tree_prove_verify_under_shared_challenges(oracle):
-    msgs, _, _ = make([200, 90, 300])
+    msgs, _, _ = make([200, 110, 300])
     ttr, tpub = T.gen_trace([m[36:68] for m in msgs], [m[-32:] for m in msgs], N)
     cfg = dict(S.DEFAULT_CFG, num_queries=8)
     seen = {}
@@ -101,7 +102,7 @@ def test_tree_prove_verify_under_shared_challenges(oracle):
 def test_inactive_messages_cannot_send_on_the_bus(oracle):
     """Soundness: a padding / junk message (ACT = 0) carries the block number of the last real header, so its data-root flags
     must not count -- otherwise it could feed the Merkle table bytes of its own in place of that header's data root."""
-    msgs, trusted, _ = make([200, 90])
+    msgs, trusted, _ = make([200, 110])
     tr, pub, _ = B.gen_trace(msgs, 16, trusted, tree_size=N)
     aux, apub = B.BlakeChainAir.gen_aux(tr, CHAL, pub)
     forged = tr.copy()
@@ -110,3 +111,31 @@ def test_inactive_messages_cannot_send_on_the_bus(oracle):
     forged[B.E0:B.E0 + 8, pad_rows] = 1
     aux2, apub2 = B.BlakeChainAir.gen_aux(forged, CHAL, pub)
     assert apub2 == apub and S.check_trace(B.BlakeChainAir, forged, pub, CHAL, aux2, apub2, rows=(30, 80)) is None
+
+
+@pytest.mark.parametrize("first", [62, 16382, (1 << 30) - 2])
+def test_every_compact_mode_of_the_block_number(oracle, first):
+    """Chains whose block numbers cross a SCALE compact mode boundary (1 -> 2, 2 -> 4, 4 -> 5 bytes, decoder.rs:39-92): the state
+    root sits right behind the number, the hash-chain table decodes it in every mode and the bus against the Merkle table balances."""
+    msgs, trusted, _ = make([150, 200, 130, 260], first=first)
+    lens = [len(B.compact_u32(first + k)[0]) for k in range(4)]
+    assert len(set(lens)) == 2
+    sr, dr = [m[32 + l: 64 + l] for m, l in zip(msgs, lens)], [m[-32:] for m in msgs]
+    ttr, tpub = T.gen_trace(sr, dr, N)
+    assert tpub == mirror_root(sr, N) + mirror_root(dr, N)
+    taux, apub_b = A.gen_aux(ttr, CHAL, tpub)
+    tr, pub, _ = B.gen_trace(msgs, 16, trusted, tree_size=N)
+    assert pub[16:18] == [first, first + 3]
+    aux, apub_a = B.BlakeChainAir.gen_aux(tr, CHAL, pub)
+    assert S.check_trace(B.BlakeChainAir, tr, pub, CHAL, aux, apub_a, rows=(0, 16 * 9)) is None
+    assert balance(apub_a, 1 << 16, apub_b, 256 * N) == [0, 0]
+    # claiming the other mode for a header (its state root would be read one or two bytes off) violates the number constraint
+    bad = tr.copy()
+    bad[B.MDF0, 0:16], bad[B.MDF1, 0:16], bad[B.MDF3, 0:16] = 0, 0, 0  # "mode 2" whatever it was
+    if first != (1 << 30) - 2:  # (that chain starts in mode 2 already)
+        assert S.check_trace(B.BlakeChainAir, bad, pub, CHAL, aux, apub_a, rows=(0, 16)) is not None
+
+
+def test_a_header_too_short_for_separate_root_rows_is_refused():
+    with pytest.raises(AssertionError, match="short"):
+        B.gen_trace(make([72])[0], 16, hashlib.sha256(b"t").digest(), tree_size=N)
