@@ -14,9 +14,9 @@
 //   C2 = C1 + D2, (L, T) = (low 7 bits, top bit) of each byte of B1 ^ C2;  byte j of B2 = (B1 ^ C2) >>> 63 is 2 L[j] + T[j-1].
 // Tables (periodic, period 2^16, row i = (a = i & 255, b = i >> 8)): T1 (a, b, a ^ b), T2 (a, b, (a ^ b) & 127, (a ^ b) >> 7).
 // Bus to the SHA-256 Merkle AIR (air_sha_tree.cuh): the running sum also carries what decode_header extracts
-// (decoder.rs:104-157) -- the state root (bytes 36..68, eight big-endian words sent from rows 4..8 of a header's first
-// chunk as (tree 0, node id N + leaf, j, word)) and the data root (the last 32 bytes, sent byte by byte as
-// (leaf, k, byte) under a witness flag E per message byte; k comes from the byte counter and the size register SZ).
+// (decoder.rs:104-157) -- the state root, the 32 bytes right behind the SCALE compact block number (1 / 2 / 4 / 5 bytes by its
+// mode, :39-92; rows 4..8 of a header's first chunk), and the data root (the last 32 bytes): byte by byte as
+// (leaf, k, byte, tree) under a witness flag E per message byte, k = position - KOF with the row's window offset KOF and tree id TR.
 // The table's net bus total is published as S / n (apub) and must cancel against the other table's.
 // Constraint ORDER is protocol: oracle/blake_air.py restates it independently.
 #pragma once

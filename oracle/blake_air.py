@@ -22,11 +22,11 @@ Finalisation reuses the same-row D2 lookups of rows 13 and 14:  U = v_lo ^ v_hi,
 The trace must have at least 2^16 rows (one copy of the tables).
 
 Bus to the SHA-256 Merkle AIR (oracle/sha_tree_air.py): the same running sum also carries what decode_header extracts
-(/root/reference circuits/builder/decoder.rs:104-157) -- the state root, bytes 36..68 of a header whose block number is
-a 4-byte compact int (:121-128), sent as eight big-endian words (tree 0, node id N + leaf, j, word) from the message
-bytes of rows 4..8 of the header's first chunk, and the data root, the last 32 bytes (:132-149), sent byte by byte
-(leaf, k, byte) with a witness flag E per message byte; k = position - (size - 32) is computed from the byte counter and
-a per-message size register SZ.  Whoever receives must take each (leaf, k) exactly once, which pins E.  The net bus
+(/root/reference circuits/builder/decoder.rs:104-157) -- the state root, the 32 bytes right behind the SCALE compact block
+number (1 / 2 / 4 / 5 bytes by its mode, :39-92, :121-128; rows 4..8 of the header's first chunk), and the data root, the last
+32 bytes (:132-149): both byte by byte as (leaf, k, byte, tree) under a witness flag E per message byte; k = position - KOF
+with the row's window offset KOF = 32 + length of the number on those rows and size - 32 elsewhere (size: a per-message
+register SZ), tree = 0 / 1 likewise.  Whoever receives must take each (tree, leaf, k) exactly once, which pins E.  The net bus
 total S of this table is published (as S / n) and must cancel against the other table's.
 """
 import hashlib
@@ -202,7 +202,7 @@ def rotr(x, n):
 
 def gen_blocks(messages, n_blocks, trusted_hash, first_number, bus=False):
     """Block descriptors for the given messages (each must start with the previous digest and carry
-    its block number as a 4-byte SCALE compact int at bytes 32..36)."""
+    its block number as a SCALE compact int at bytes 32..)."""
     import hashlib
 
     blocks, D = [], trusted_hash
