@@ -5,7 +5,7 @@
 // vendored); this is a from-scratch byte-lookup arithmetisation of RFC 7693 in the same spirit: every 64-bit word is
 // 8 byte cells, XORs are lookups into 2^16-row tables through a logUp argument (auxiliary commitment round), additions
 // are 32-bit limb identities, rotations by 32 / 24 / 16 are byte re-indexings and the rotation by 63 is carried by a
-// (low 7 bits, top bit) split of the XOR bytes.  740 main + 278 auxiliary columns (the bit-decomposed AIR it replaces
+// (low 7 bits, top bit) split of the XOR bytes.  745 main + 276 auxiliary columns (the bit-decomposed AIR it replaces
 // had 4337), degree <= 3, 16 rows per compression:
 //   r = 0 INIT (out-state = initial work vector), r = 1..12 ROUND (row r holds round r-1's eight G evaluations),
 //   r = 13 FIN1 (U = v_lo ^ v_hi), r = 14 FIN2 (h_out = U ^ h), r = 15 PAD (H = next h_in, digest register D updated).
