@@ -69,8 +69,9 @@ def test_trace_satisfies_constraints_and_detects_corruption(oracle):
         for col, row, delta in edits:
             bad[col, row] = np.uint64(int(bad[col, row]) + delta)
         aux2, apub2 = A.gen_aux(bad, CHAL, pub)
-        assert S.check_trace(A, bad, pub, CHAL, aux2, apub2) is None and apub2 != [0, 0]
-        assert S.check_trace(A, bad, pub, CHAL, aux2, [0, 0]) is not None  # claiming zero anyway breaks the running sum
+        # (the rows around the edits, the start of the padding region and the wrap-around: the full-trace check above already ran once)
+        assert all(S.check_trace(A, bad, pub, CHAL, aux2, apub2, rows=w) is None for w in ((0, 1024), (65536 - 256, 65536))) and apub2 != [0, 0]
+        assert S.check_trace(A, bad, pub, CHAL, aux2, [0, 0], rows=(0, 64)) is not None  # claiming zero anyway breaks the running sum
     # wrong claimed target / block numbers
     assert S.check_trace(A, tr, pub[:8] + [pub[8] ^ 1] + pub[9:], CHAL, aux, apub, rows=(65530, 65536)) is not None
     assert S.check_trace(A, tr, pub[:16] + [pub[16] + 1] + pub[17:], CHAL, aux, apub, rows=(0, 4)) is not None
