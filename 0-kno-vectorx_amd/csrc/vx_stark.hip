@@ -129,12 +129,16 @@ struct QuotArgs {
 #ifndef VX_Q_WAVES_MAX
 #define VX_Q_WAVES_MAX 8
 #endif
-// one block = a tile of 256 * R consecutive LDE points, lane t holding points t, t + 256, ... of the tile
+#ifndef VX_Q_BLOCK
+#define VX_Q_BLOCK 256
+#endif
+constexpr int QB = VX_Q_BLOCK;
+// one block = a tile of QB * R consecutive LDE points, lane t holding points t, t + QB, ... of the tile
 template <class Air, int R>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_Q_WAVES, VX_Q_WAVES_MAX))) void k_quotient(QuotArgs a) {
+__global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(VX_Q_WAVES, VX_Q_WAVES_MAX))) void k_quotient(QuotArgs a) {
     using F = FpN<R>;
     const size_t N = (size_t)1 << a.log_N;
-    const size_t i0 = blockIdx.x * (size_t)(256 * R) + threadIdx.x;
+    const size_t i0 = blockIdx.x * (size_t)(QB * R) + threadIdx.x;
     const size_t step = (size_t)1 << a.rate_bits;
     Consumer<F> c;
     c.init(a.apow);
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_Q_WAVES,
     uint64_t zinv[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const size_t i = (i0 + 256 * (size_t)j) & (N - 1);  // N >= 256 * R is checked by the launcher
+        const size_t i = (i0 + QB * (size_t)j) & (N - 1);  // N >= QB * R is checked by the launcher
         const uint64_t x = gl_mul(a.shift, root_pow_f(a.tw, i, a.log_N));
         const int k = (int)(i & (step - 1));
         c.z_last.v[j] = gl_sub(x, a.last);
@@ -345,8 +349,8 @@ template <class Air>
 static void launch_q(QuotArgs& a, hipStream_t s) {
     constexpr int R = Air::QUOT_ROWS_PER_LANE;
     const size_t N = (size_t)1 << a.log_N;
-    if (R > 1 && N >= 256 * (size_t)R) hipLaunchKernelGGL((k_quotient<Air, R>), dim3((unsigned)(N / (256 * R))), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_quotient<Air, 1>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, a);
+    if (R > 1 && N >= QB * (size_t)R) hipLaunchKernelGGL((k_quotient<Air, R>), dim3((unsigned)(N / (QB * R))), dim3(QB), 0, s, a);
+    else hipLaunchKernelGGL((k_quotient<Air, 1>), dim3((unsigned)((N + QB - 1) / QB)), dim3(QB), 0, s, a);
 }
 static void no_periodic(std::vector<uint64_t>& v) { v.clear(); }
 static void mix_periodic(std::vector<uint64_t>& v) { v = {0, 0, 0, 1, 3, 5, 7, 11}; }

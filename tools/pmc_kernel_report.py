@@ -11,7 +11,7 @@ from collections import defaultdict
 
 
 def short(k):
-    k = re.sub(r"\(.*", "", k)
+    k = re.sub(r"\(.*", "", k.replace("(anonymous namespace)::", ""))
     return re.sub(r"^void ", "", k).strip()
 
 
