@@ -463,6 +463,9 @@ static inline size_t lds_bytes(int lr, int lT) {
 }
 static bool g_ntt_v1 = getenv("VX_NTT_V1") != nullptr;  // debugging aid: force the LDS-stage kernel
 static int g_ntt_skip = getenv("VX_NTT_SKIP") ? atoi(getenv("VX_NTT_SKIP")) : 0;  // timing experiments (wrong results!)
+// VX_NTT_GROUP=G: run ALL passes of a transform over G columns before moving to the next G (a group of 32 columns of 2^19 is
+// 128 MB: the second pass would find in the 256 MB Infinity Cache what the first just wrote).  0 = every pass over all columns.
+static size_t g_ntt_group = getenv("VX_NTT_GROUP") ? (size_t)atoi(getenv("VX_NTT_GROUP")) : 0;
 template <int MODE>
 static int32_t launch_pass(vx_ctx* ctx, PassArgs& a, int log_n, size_t n_cols, int inverse) {
     size_t tiles = (size_t)1 << (log_n - a.log_rows - a.log_T);
@@ -484,6 +487,11 @@ static int32_t launch_pass(vx_ctx* ctx, PassArgs& a, int log_n, size_t n_cols, i
 // natural -> bit-reversed positions.  src may equal dst.
 static int32_t ntt_dif(vx_ctx* ctx, const uint64_t* src, size_t src_stride, uint64_t* dst, size_t dst_stride, int L,
                        size_t n_cols, int inverse, uint64_t scale) {
+    if (g_ntt_group && n_cols > g_ntt_group && L > 12) {
+        for (size_t c0 = 0; c0 < n_cols; c0 += g_ntt_group)
+            VX_TRY(ntt_dif(ctx, src + c0 * src_stride, src_stride, dst + c0 * dst_stride, dst_stride, L, n_cols - c0 < g_ntt_group ? n_cols - c0 : g_ntt_group, inverse, scale));
+        return VX_OK;
+    }
     std::vector<int> outer;
     int last;
     plan_chunks(L, outer, last);
@@ -520,6 +528,11 @@ static int32_t ntt_dif(vx_ctx* ctx, const uint64_t* src, size_t src_stride, uint
 // coefficients (bit-reversed positions) that are zero-padded to 2^L on the fly.
 static int32_t ntt_dit(vx_ctx* ctx, const uint64_t* src, size_t src_stride, uint64_t* dst, size_t dst_stride, int L,
                        size_t n_cols, int inverse, int expand_bits, const uint64_t* shift_tab) {
+    if (g_ntt_group && n_cols > g_ntt_group && L > 12) {
+        for (size_t c0 = 0; c0 < n_cols; c0 += g_ntt_group)
+            VX_TRY(ntt_dit(ctx, src + c0 * src_stride, src_stride, dst + c0 * dst_stride, dst_stride, L, n_cols - c0 < g_ntt_group ? n_cols - c0 : g_ntt_group, inverse, expand_bits, shift_tab));
+        return VX_OK;
+    }
     std::vector<int> outer;
     int last;
     plan_chunks(L, outer, last);
