@@ -159,6 +159,17 @@ def limb(bytes8, h):
     return acc
 
 
+INV2 = (P + 1) // 2
+
+
+def bus_mode(pub):
+    """Public input 19 selects what the bus carries: 0 nothing (stand-alone proof), 1 the state / data roots of every header
+    (header_range, towards the Merkle table), 2 a WINDOW of message bytes starting at byte pub[18] under tree id 1 (rotate: the
+    ScheduledChange log of the epoch-end header, towards the epoch-end table).  -> (on, window) as polynomials of the constant."""
+    m = pub[19]
+    return m * (3 - m) * INV2, m * (m - 1) * INV2
+
+
 def lookups(loc, nxt, sel, pub=None):
     """The lookups of the row pair in protocol order: (multiplicity, tag, tuple).  Works on any backend (field
     vectors, extension scalars, plain numpy integers).  The 264 table lookups first (pairs share a helper with one common
@@ -187,7 +198,7 @@ def lookups(loc, nxt, sel, pub=None):
         r8n = r8n + sel[r] * (8 * (r + 1))  # 8 * (row index of the next row); sel[15] -> next row is row 0
     leaf = nxt[NUM] - pub[16]
     pos0 = nxt[T] - nxt[INC] + r8n - nxt[KOF]  # position of byte 0 of the next row, counted from the row's window offset
-    bus_on = pub[19]  # 0 for a stand-alone proof (nothing on the bus, published total 0), 1 next to the Merkle AIR
+    bus_on = bus_mode(pub)[0]  # 0 for a stand-alone proof (nothing on the bus, published total 0)
     live = nxt[ACT] * bus_on  # an inactive (padding / junk) message shares its block number with the last real header: it must not send
     # byte b of the next row's natural message word under the flag E[b]: (leaf, position in the root, byte, tree) -- tree 0 = state
     # root (rows 4..8 of a first chunk, offset 32 + length of the compact block number), tree 1 = data root (offset size - 32)
@@ -410,7 +421,7 @@ def multiplicities(tr):
     return m1, m2
 
 
-def gen_trace(messages, log_n, trusted_hash, first_number=None, forge=None, tree_size=0):
+def gen_trace(messages, log_n, trusted_hash, first_number=None, forge=None, tree_size=0, window=None):
     """Full main trace [COLS][n] + public inputs (trusted / target hash limbs, first / last block number, Merkle tree
     size, bus flag).  tree_size = 0: a stand-alone proof, nothing goes on the bus."""
     n = 1 << log_n
@@ -440,6 +451,21 @@ def gen_trace(messages, log_n, trusted_hash, first_number=None, forge=None, tree
     tr[M1, : 1 << TABLE_LOG], tr[M2, : 1 << TABLE_LOG] = m1.astype(np.uint64), m2.astype(np.uint64)
     lt = [int.from_bytes(trusted_hash[4 * j: 4 * j + 4], "little") for j in range(8)]
     lg = [int.from_bytes(target[4 * j: 4 * j + 4], "little") for j in range(8)]
+    if window is not None:  # rotate: bytes [offset, offset + length) of the (single) message go on the bus under tree id 1
+        off, length = window
+        assert len(messages) == 1 and off >= 72 and not tree_size
+        for bi in range(len(real_blocks)):
+            for r in range(16):
+                row = 16 * bi + r
+                if not (real_blocks[bi]["first"] and 4 <= r <= 8):
+                    tr[KOF, row] = off
+                for b in range(8):
+                    pos = real_blocks[bi]["t"] - real_blocks[bi]["inc"] + 8 * r + b
+                    tr[E0 + b, row] = 1 if (off <= pos < off + length and pos < len(messages[0]) and not (real_blocks[bi]["first"] and 4 <= r <= 8)) else 0
+        pad_rows = slice(16 * len(real_blocks), n)
+        sr = np.tile(np.array([1 if 4 <= r <= 8 else 0 for r in range(16)], dtype=np.uint64), (n - 16 * len(real_blocks)) // 16)
+        tr[KOF, pad_rows] = np.where(sr == 1, tr[KOF, pad_rows], np.uint64(off))
+        return tr, lt + lg + [first_number, last_number, off, 2], target
     return tr, lt + lg + [first_number, last_number, tree_size, 1 if tree_size else 0], target
 
 
@@ -597,7 +623,8 @@ class BlakeChainAir:
         srw = loc[FIRST] * s48
         clen = loc[MDF0] + loc[MDF1] * 2 + mdf2 * 4 + loc[MDF3] * 5
         c.constraint(loc[TR] - (1 - srw))
-        c.constraint(loc[KOF] - (s48 * (loc[FIRST] * 32 + clen) + (1 - srw) * (loc[SZ] - 32)))
+        win = bus_mode(pub)[1]
+        c.constraint(loc[KOF] - (s48 * (loc[FIRST] * 32 + clen) + (1 - srw) * ((1 - win) * (loc[SZ] - 32) + win * pub[18])))
         # ---- 7. per-block registers
         for col in (ACT, FIN, FIRST, CAP, T, INC, NUM, FA, MDF0, MDF1, MDF3):
             c.constraint(in_blk * (nxt[col] - loc[col]))

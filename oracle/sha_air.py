@@ -310,7 +310,10 @@ def key_lookup(loc, per, pub):
 
     a0, b0 = limbs(W0B)
     a1, b1 = limbs(W1B)
-    m = loc[SGC] * pub[9] * (per[4] * loc[T_FIRST] + per[5] * loc[T_DATA])
+    mode = pub[9]  # 0: nothing on the bus; 1: SEND the flagged keys (towards EdAir); 2: RECEIVE every key (from the epoch-end table)
+    inv2 = (P + 1) // 2
+    on, rcv = mode * (3 - mode) * inv2, mode * (mode - 1) * inv2
+    m = on * (per[4] * loc[T_FIRST] + per[5] * loc[T_DATA]) * (loc[SGC] * (1 - rcv) - rcv)
     return m, TAG_KEY, ((loc[KC] - 1) * 4 + per[6], a0 + b0 * 65536, a1 + b1 * 65536, 0)
 
 
