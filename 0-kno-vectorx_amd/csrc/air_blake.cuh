@@ -313,7 +313,9 @@ struct BlakeAir {
             const F s48 = sel[4] + sel[5] + sel[6] + sel[7] + sel[8], srw = first * s48;
             const F clen = loc[MDF0] + loc[MDF1] * two + mdf2 * four + loc[MDF3] * F::from(5);
             c.constraint(loc[TR] - (one - srw));
-            c.constraint(loc[KOF] - (s48 * (first * F::from(32) + clen) + (one - srw) * (loc[SZ] - F::from(32))));
+            // public input 19 = bus mode: 0 nothing, 1 the roots of every header, 2 a WINDOW of message bytes from byte pub[18] on (rotate)
+            const F mode = pub[19], win = mode * (mode - one) * F::from(0x7FFFFFFF80000001ULL);  // m (m - 1) / 2
+            c.constraint(loc[KOF] - (s48 * (first * F::from(32) + clen) + (one - srw) * ((one - win) * (loc[SZ] - F::from(32)) + win * pub[18])));
         }
         // ---- 7. per-block registers
         {
@@ -401,7 +403,7 @@ struct BlakeAir {
             {
                 F r8n = sel[0] * F::from(8);
                 for (int r = 1; r < 15; ++r) r8n = r8n + sel[r] * F::from(8 * (r + 1));
-                const F leaf = nxt[NUM] - pub[16], bus_on = pub[19];  // bus_on = 0: a stand-alone proof, nothing on the bus
+                const F leaf = nxt[NUM] - pub[16], bus_on = pub[19] * (F::from(3) - pub[19]) * F::from(0x7FFFFFFF80000001ULL);  // m (3 - m) / 2: 0 = a stand-alone proof
                 const F pos0 = nxt[T] - nxt[INC] + r8n - nxt[KOF];
                 const X2<F> base = beta + leaf + g3 * nxt[TR] + g4 * F::from(TAG_BYTE);
                 const F live = nxt[ACT] * bus_on;  // an inactive (padding / junk) message shares its block number with the last real header: it must not send

@@ -245,7 +245,9 @@ struct ShaAir {
             auto limbs = [&](int col0) -> F {  // bytes b0 b1 b2 b3 of the big-endian word: (b0 + 256 b1) + 2^16 (b2 + 256 b3)
                 return val(loc, col0 + 24, 8) + val(loc, col0 + 16, 8) * k8 + (val(loc, col0 + 8, 8) + val(loc, col0, 8) * k8) * k16;
             };
-            const F m = sgc * pub[9] * (per[4] * loc[T_FIRST] + per[5] * tdata);
+            // public input 9 = bus mode: 0 nothing, 1 SEND the flagged keys (to EdAir), 2 RECEIVE every key (from the epoch-end table)
+            const F mode = pub[9], inv2 = F::from(0x7FFFFFFF80000001ULL), on = mode * (F::from(3) - mode) * inv2, rcv = mode * (mode - one) * inv2;
+            const F m = on * (per[4] * loc[T_FIRST] + per[5] * tdata) * (sgc * (one - rcv) - rcv);
             const X2<F> d = beta + ((kc - one) * F::from(4) + per[6]) + gamma * limbs(W0B) + g2 * limbs(W1B) + g4 * F::from(TAG_KEY);
             const X2<F> h{loc[CHAIN_COLS], loc[CHAIN_COLS + 1]}, z{loc[CHAIN_COLS + 2], loc[CHAIN_COLS + 3]}, zn{nxt[CHAIN_COLS + 2], nxt[CHAIN_COLS + 3]};
             c.constraint_x2(h * d - m);

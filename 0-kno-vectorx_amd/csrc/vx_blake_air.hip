@@ -113,7 +113,8 @@ struct ExpandEntry {
     uint8_t shift, bits;
 };
 __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const BlockDesc* descs, const uint64_t* hchain, size_t n_real,
-                                                     uint64_t* __restrict__ stage, uint32_t* __restrict__ hist, uint32_t* __restrict__ rc_part, size_t n) {
+                                                     uint64_t* __restrict__ stage, uint32_t* __restrict__ hist, uint32_t* __restrict__ rc_part, size_t n,
+                                                     uint32_t win_off, uint32_t win_len) {
     using namespace blk;
     // the (byte, 0) range-check lookups of every row fall on 256 counters = 8 cache lines: as global atomics they
     // serialise in L2 (the kernel took 7.5 ms for 0.4 GB of stores); they are counted per block in LDS instead and
@@ -227,11 +228,13 @@ __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const 
     // every other row data-root bytes (the last 32 bytes of the message, :132-149).  E[b]: byte 8r + b of this chunk lies in the
     // window's 32 bytes of an active message
     const bool srw = d.first && r >= 4 && r <= 8;
-    const uint32_t clen = d.mode == 0 ? 1 : d.mode == 1 ? 2 : d.mode == 2 ? 4 : 5, kof = srw ? 32 + clen : d.size - 32;
+    // win_len > 0 (rotate, bus mode 2): outside those rows the window is bytes [win_off, win_off + win_len) of the message instead
+    const uint32_t clen = d.mode == 0 ? 1 : d.mode == 1 ? 2 : d.mode == 2 ? 4 : 5, kof = srw ? 32 + clen : (win_len ? win_off : d.size - 32);
+    const uint32_t wlen = (win_len && !srw) ? win_len : 32;
     uint64_t eb = 0;
     for (int bq = 0; bq < 8; ++bq) {
         const uint32_t pos = d.t - d.inc + 8 * r + bq;
-        eb |= (uint64_t)((d.act && pos >= kof && pos < kof + 32) ? 1 : 0) << bq;
+        eb |= (uint64_t)((d.act && pos >= kof && pos < kof + wlen && pos < d.size && !(win_len && srw)) ? 1 : 0) << bq;
     }
     const uint64_t mdf = d.first ? (uint64_t)(d.mode == 0) | ((uint64_t)(d.mode == 1) << 1) | ((uint64_t)(d.mode == 3) << 2) : 0;
     st(SW_FLAGS) = (uint64_t)d.act | ((uint64_t)d.fin << 1) | ((uint64_t)d.first << 2) | ((uint64_t)(cap ? 1 : 0) << 3) | ((uint64_t)((d.first && d.act) ? 1 : 0) << 4) |
@@ -534,13 +537,15 @@ int32_t vx_blake_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, cons
 extern "C" {
 
 int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_headers,
-                             const uint8_t trusted_hash[32], uint32_t first_block_number, uint32_t tree_size, int log_n, vx_buf* trace_out,
-                             uint64_t public_inputs_out[20], uint8_t* digests_out) {
+                             const uint8_t trusted_hash[32], uint32_t first_block_number, uint32_t tree_size, uint32_t window_offset, uint32_t window_length,
+                             int log_n, vx_buf* trace_out, uint64_t public_inputs_out[20], uint8_t* digests_out) {
     if (!ctx || !headers || !sizes || !trusted_hash || !trace_out || !public_inputs_out) return VX_ERR_ARG;
     VX_CHECK(stride % 128 == 0 && stride > 0, "blake trace: stride %zu must be a positive multiple of 128", stride);
     VX_CHECK(n_headers >= 1 && n_headers * stride <= headers->n * 8, "blake trace: headers exceed the buffer");
     VX_CHECK(log_n >= blk::TABLE_LOG && log_n <= 24, "blake trace: log_n %d out of range [16, 24] (the trace holds one copy of the 2^16-row lookup tables)", log_n);
     VX_CHECK((uint64_t)first_block_number + n_headers <= (1ULL << 32), "blake trace: block numbers %u.. overflow 32 bits", first_block_number);
+    VX_CHECK(!window_length || (n_headers == 1 && !tree_size && window_offset >= 72 && (uint64_t)window_offset + window_length < (1u << 24)),
+             "blake trace: a byte window (offset %u, length %u) goes with one header, no Merkle tree, and starts behind the state root", window_offset, window_length);
     const size_t n = (size_t)1 << log_n, n_blocks = n >> 4;
     VX_CHECK(trace_out->n >= n * blk::COLS, "blake trace: trace buffer holds %zu < %zu elements", trace_out->n, n * (size_t)blk::COLS);
     std::vector<uint32_t> base(n_headers);
@@ -621,7 +626,7 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
     VX_HIP(hipMemcpyAsync(d_desc, descs.data(), n_blocks * sizeof(BlockDesc), hipMemcpyHostToDevice, ctx->stream));
     VX_HIP(hipMemsetAsync(d_hist, 0, (size_t)HIST_COPIES * 65536 * 8, ctx->stream));
     hipLaunchKernelGGL(k_blake_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t*)headers->d,
-                       (const BlockDesc*)d_desc, (const uint64_t*)d_hc, n_real, d_stage, d_hist, d_hist + (size_t)HIST_COPIES * 131072, n);
+                       (const BlockDesc*)d_desc, (const uint64_t*)d_hc, n_real, d_stage, d_hist, d_hist + (size_t)HIST_COPIES * 131072, n, window_offset, window_length);
     VX_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_blake_expand, dim3((unsigned)((n + 256 * EXP_RPL - 1) / (256 * EXP_RPL)), N_STAGE), dim3(256), 0, ctx->stream,
                        (const uint64_t*)d_stage, trace_out->d, n, (const ExpandEntry*)d_ent, (const uint32_t*)d_eoff);
@@ -638,8 +643,8 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
     }
     public_inputs_out[16] = first_block_number;
     public_inputs_out[17] = first_block_number + (uint64_t)n_headers - 1;
-    public_inputs_out[18] = tree_size;
-    public_inputs_out[19] = tree_size ? 1 : 0;  // bus flag: the state / data roots go to a Merkle AIR of that many leaves
+    public_inputs_out[18] = window_length ? window_offset : tree_size;
+    public_inputs_out[19] = window_length ? 2 : (tree_size ? 1 : 0);  // bus mode: 1 the state / data roots go to a Merkle AIR, 2 a window of message bytes
     if (digests_out) memcpy(digests_out, dig.data(), dig.size());
     return VX_OK;
 }
@@ -888,7 +893,7 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
     size_t len1 = 0;
     if (rc == VX_OK) rc = vx_alloc(ctx, ((size_t)blk::COLS) << log_n, &trace);
     uint64_t pub[20];
-    if (rc == VX_OK) rc = vx_blake_chain_trace(ctx, headers, stride, sizes, n_fetched, trusted_hash, trusted_block + 1, max_headers, log_n, trace, pub, nullptr);
+    if (rc == VX_OK) rc = vx_blake_chain_trace(ctx, headers, stride, sizes, n_fetched, trusted_hash, trusted_block + 1, max_headers, 0, 0, log_n, trace, pub, nullptr);
     if (rc == VX_OK) {
         uint8_t tgt[32];
         for (int q = 0; q < 8; ++q) {

@@ -160,6 +160,9 @@ int32_t vx_ed_trace_dev(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* sigs
 int32_t vx_sha512_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub);
 int32_t vx_sha512_trace_dev(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* sigs, const uint8_t* msg, const uint8_t* flags, size_t n_sigs, int log_n, uint64_t bus_on,
                             uint64_t* trace_d, uint64_t pub_out[15]);
+int32_t vx_epoch_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub);
+int32_t vx_epoch_end_trace_dev(vx_ctx* ctx, const uint8_t* header_d, size_t header_bytes, uint32_t start_position, uint32_t num_authorities, uint64_t bus_on, uint64_t* trace_d,
+                               uint64_t pub_out[10], uint32_t* window_length_out);
 int32_t vx_sha_chain_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub);
 int32_t vx_sha_chain_trace_dev(vx_ctx* ctx, const uint8_t* pubkeys, size_t n_keys, const uint8_t* signed_flags, uint64_t bus_on, int log_n, uint64_t* trace_d,
                                uint64_t public_inputs_out[10], uint8_t commitment_out[32]);

@@ -1,8 +1,10 @@
 // RotateCircuit (circuits/rotate.rs:80-109; builder/rotate.rs:74-323): the epoch-end header is hashed
 // (Blake2b STARK over its compressions), justified by > 2/3 of the CURRENT authority set (Ed25519 batch on
 // the GPU + authority-set commitment STARK), checked to carry the ScheduledChange log that encodes the NEW
-// authority set (k_epoch_end_check, one lane per validator), and the new set's commitment is proved
-// (second SHA-256 chain STARK) and returned as the 32 output bytes.
+// authority set (k_epoch_end_check, one lane per validator, names the failing rule; EpochEndAir proves it), and the
+// new set's commitment is proved (second SHA-256 chain STARK) and returned as the 32 output bytes.  Two logUp buses:
+//   A  current-set commitment -> Ed25519 <-> SHA-512                 (the justification, vx_bus.h)
+//   B  Blake2b header hash -> EpochEndAir -> new-set commitment     (the header bytes of the log ARE the committed keys)
 #include <cstdio>
 #include <cstring>
 #include <thread>
@@ -67,10 +69,10 @@ __global__ __launch_bounds__(64) void k_epoch_end_check(const uint8_t* __restric
     if (t + 1 == num_authorities && (v[40] | v[41] | v[42] | v[43]) != 0) return fail(EE_DELAY, t);  // :267-274
 }
 
-const uint64_t VX_ROT_MAGIC = 0x3254415458525856ULL;  // "VXRXTAT2"
+const uint64_t VX_ROT_MAGIC = 0x3354415458525856ULL;  // "VXRXTAT3"
 // magic, set id, block, n_new, header hash (4), set hash (4), new set hash (4), proof lengths: header hash, current-set commitment,
-// new-set commitment, Ed25519; parent hash (4); SHA-512 proof length, the precommit's round
-constexpr size_t VX_ROT_HDR = 26;
+// new-set commitment, Ed25519; parent hash (4); SHA-512 proof length, the precommit's round, start_position, epoch-end proof length
+constexpr size_t VX_ROT_HDR = 28;
 
 int sha_rows_log(size_t n_keys) {
     int log_n = 6;
@@ -121,11 +123,12 @@ int32_t vx_verify_epoch_end_header(vx_ctx* ctx, const vx_buf* header, uint32_t n
 
 int32_t vx_rotate_proof_bound(const vx_stark_config* cfg, size_t n_chunks, size_t n_cur_authorities, size_t n_new_authorities, size_t* n_words) {
     if (!cfg || !n_words || n_chunks == 0 || n_cur_authorities == 0 || n_new_authorities == 0) return VX_ERR_ARG;
-    size_t w1 = 0, w2 = 0, w3 = 0;
+    size_t w1 = 0, w2 = 0, w3 = 0, w4 = 0;
     int32_t rc = vx_stark_proof_bound(VX_AIR_BLAKE_CHAIN, cfg, blake_rows_log(n_chunks), &w1);
+    if (rc == VX_OK) rc = vx_stark_proof_bound(VX_AIR_EPOCH_END, cfg, VX_EPOCH_END_LOG_ROWS, &w4);
     if (rc == VX_OK) w2 = vx_justification_proof_bound(cfg, n_cur_authorities, &rc);  // commitment of the current set + Ed25519 + SHA-512
     if (rc == VX_OK) rc = vx_stark_proof_bound(VX_AIR_SHA_CHAIN, cfg, sha_rows_log(n_new_authorities), &w3);
-    *n_words = VX_ROT_HDR + w1 + w2 + w3;
+    *n_words = VX_ROT_HDR + w1 + w2 + w3 + w4;
     return rc;
 }
 
@@ -137,47 +140,9 @@ int32_t vx_rotate_prove(vx_ctx* ctx, const vx_buf* header, uint32_t header_size,
     if (header_size > MAX_HEADER_SIZE)  // input/mod.rs:851-856
         return vx_fail(ctx, VX_ERR_STATEMENT, "rotate: header size %u is greater than MAX_HEADER_SIZE %u", header_size, MAX_HEADER_SIZE);
     VX_CHECK(header_size >= 36, "rotate: header of %u bytes cannot hold a parent hash and a block number", header_size);
-    // 0. the justification by the CURRENT set (rotate.rs:297-302) as three tables on one logUp bus -- its commitment (binds the EVM
-    //    input hash; sends the chosen signers' keys), the Ed25519 table and the SHA-512 table (vx_bus.h) -- proven on side contexts
-    //    from host threads meanwhile; they need the precommit, not the header hash
     VX_CHECK(just->num_authorities >= 1 && just->num_authorities <= 512, "rotate: %u authorities (the EdDSA table holds 512)", just->num_authorities);
-    uint8_t commit[2][32];
-    auto prove_set = [&](vx_ctx* c, const uint8_t* keys, size_t nk, uint8_t com[32], uint64_t* dst, size_t cap, size_t* len) -> int32_t {
-        (void)hipSetDevice(c->device);
-        const int sl = sha_rows_log(nk);
-        vx_buf* st = nullptr;
-        int32_t r = vx_alloc(c, ((size_t)VX_SHA_AIR_COLS) << sl, &st);
-        if (r != VX_OK) return r;
-        uint64_t spub[10];
-        r = vx_sha_chain_trace_dev(c, keys, nk, nullptr, 0, sl, st->d, spub, com);  // stand-alone: nothing on the bus
-        if (r == VX_OK) r = vx_stark_prove_impl(c, VX_AIR_SHA_CHAIN, cfg, st->d, st->n, 1, sl, spub, 10, dst, cap, len);
-        (void)vx_free(c, st);
-        return r;
-    };
-    BusMeet rv;
-    rv.n_parties = 3;
-    JustificationTables jt;
-    vx_ctx* side[3];
-    {
-        vx_ctx* c = ctx;
-        for (int t = 0; t < 3; ++t) side[t] = c = c ? vx_side_ctx(c) : nullptr;
-        VX_CHECK(c, "rotate: no side context for every justification table");
-    }
-    struct Joiner {  // every exit path waits for the threads
-        JustificationTables& j;
-        BusMeet& r;
-        ~Joiner() {
-            for (int t = 0; t < 3; ++t)
-                if (j.job[t].th.joinable()) j.job[t].th.join();
-        }
-    } joiner{jt, rv};
-    {
-        const int32_t rs = vx_justification_tables_start(side, just, cfg, &rv, 0, nullptr, nullptr, &jt);
-        if (rs != VX_OK) return vx_fail(ctx, rs, "rotate: no host thread for the justification tables");
-    }
-    // 1. header hash = Blake2b-256 of the first header_size bytes (rotate.rs:293); the trace of its compressions
-    //    is the witness of the hash STARK (one-header chain anchored at the header's own parent hash)
-    uint8_t head[40], header_hash[32];
+    // 0. the header's own rules, natively first (they name the error, and nothing is proven for a header that breaks them)
+    uint8_t head[40], header_hash[32], new_commit[32];
     const uint8_t* parent = head;
     VX_HIP(hipMemcpyAsync(head, header->d, 40, hipMemcpyDeviceToHost, ctx->stream));
     VX_HIP(hipStreamSynchronize(ctx->stream));
@@ -191,50 +156,136 @@ int32_t vx_rotate_prove(vx_ctx* ctx, const vx_buf* header, uint32_t header_size,
         if (got != enc)
             return vx_fail(ctx, VX_ERR_STATEMENT, "rotate: header does not carry block number %u as a 4-byte SCALE compact", epoch_end_block_number);
     }
+    //    the header encodes the new authority set (rotate.rs:306-312)
+    VX_TRY(vx_verify_epoch_end_header(ctx, header, num_authorities, start_position, new_pubkeys, just->max_authorities));
+    // 1. the tables.  Bus A: the justification by the CURRENT set (rotate.rs:297-302) -- its commitment (binds the EVM input hash;
+    //    sends the chosen signers' keys), the Ed25519 table and the SHA-512 table (vx_bus.h).  Bus B: the Blake2b table of the header
+    //    hash (this context) sends the bytes of the ScheduledChange log to the epoch-end table, which sends the keys it reads there to
+    //    the NEW set's commitment table.  Every table but the first is proven on a side context from a host thread.
+    BusMeet rv, rvb;
+    rv.n_parties = rvb.n_parties = 3;
+    BusParty pb[3] = {{&rvb, 0}, {&rvb, 1}, {&rvb, 2}};
+    const vx_chal_hook hb[3] = {{vx_bus_hook, &pb[0]}, {vx_bus_hook, &pb[1]}, {vx_bus_hook, &pb[2]}};
+    JustificationTables jt;
+    TableJob epoch, newset;
+    vx_ctx* side[5];
+    {
+        vx_ctx* c = ctx;
+        for (int t = 0; t < 5; ++t) side[t] = c = c ? vx_side_ctx(c) : nullptr;
+        VX_CHECK(c, "rotate: no side context for every table");
+    }
+    epoch.c = side[3], newset.c = side[4];
+    // the epoch-end trace (512 rows) is written from this thread: its prefix gives the byte window the Blake2b table sends
+    vx_buf* et = nullptr;
+    uint64_t epub[10];
+    uint32_t wlen = 0;
+    VX_TRY(vx_alloc(epoch.c, (size_t)VX_EPOCH_END_AIR_COLS << VX_EPOCH_END_LOG_ROWS, &et));
+    struct FreeEt {
+        vx_ctx* c;
+        vx_buf*& b;
+        ~FreeEt() {
+            if (b) (void)vx_free(c, b);
+        }
+    } free_et{epoch.c, et};
+    {
+        const int32_t r = vx_epoch_end_trace_dev(epoch.c, (const uint8_t*)header->d, header->n * 8, start_position, num_authorities, 1, et->d, epub, &wlen);
+        if (r != VX_OK) return vx_fail(ctx, r, "rotate: %s", vx_last_error(epoch.c));
+    }
+    if (start_position + 1 < 72 || (uint64_t)start_position + 1 + wlen > header_size)  // (the hash covers header_size bytes; 72 = parent hash + number + state root)
+        return vx_fail(ctx, VX_ERR_STATEMENT, "rotate: the log at %u..%llu lies outside the hashed digest bytes of the %u-byte header", start_position + 1,
+                       (unsigned long long)start_position + 1 + wlen, header_size);
+    struct Joiner {  // every exit path waits for the threads
+        JustificationTables& j;
+        TableJob &a, &b;
+        ~Joiner() {
+            for (int t = 0; t < 3; ++t)
+                if (j.job[t].th.joinable()) j.job[t].th.join();
+            if (a.th.joinable()) a.th.join();
+            if (b.th.joinable()) b.th.join();
+        }
+    } joiner{jt, epoch, newset};
+    {
+        const int32_t rs = vx_justification_tables_start(side, just, cfg, &rv, 0, nullptr, nullptr, &jt);
+        if (rs != VX_OK) return vx_fail(ctx, rs, "rotate: no host thread for the justification tables");
+    }
+    auto prove_epoch = [&](vx_ctx* c, TableJob& j) -> int32_t {
+        size_t bound = 0;
+        VX_TRY(vx_stark_proof_bound(VX_AIR_EPOCH_END, cfg, VX_EPOCH_END_LOG_ROWS, &bound));
+        j.proof.resize(bound);
+        return vx_stark_prove_impl(c, VX_AIR_EPOCH_END, cfg, et->d, et->n, /*consume_trace=*/0, VX_EPOCH_END_LOG_ROWS, epub, 10, j.proof.data(), j.proof.size(), &j.len, &hb[1]);
+    };
+    auto prove_newset = [&](vx_ctx* c, TableJob& j) -> int32_t {  // the output (rotate.rs:317-320): receives every key from the epoch-end table
+        const int sl = sha_rows_log(num_authorities);
+        size_t bound = 0;
+        VX_TRY(vx_stark_proof_bound(VX_AIR_SHA_CHAIN, cfg, sl, &bound));
+        j.proof.resize(bound);
+        vx_buf* st = nullptr;
+        VX_TRY(vx_alloc(c, ((size_t)VX_SHA_AIR_COLS) << sl, &st));
+        uint64_t spub[10];
+        int32_t r = vx_sha_chain_trace_dev(c, new_pubkeys, num_authorities, nullptr, 2, sl, st->d, spub, new_commit);
+        if (r == VX_OK) r = vx_stark_prove_impl(c, VX_AIR_SHA_CHAIN, cfg, st->d, st->n, /*consume_trace=*/0, sl, spub, 10, j.proof.data(), j.proof.size(), &j.len, &hb[2]);
+        (void)vx_free(c, st);
+        return r;
+    };
+    int32_t rc = VX_OK;
+    try {
+        epoch.th = std::thread([&] {
+            (void)hipSetDevice(epoch.c->device);
+            epoch.rc = prove_epoch(epoch.c, epoch);
+            if (epoch.rc != VX_OK) rvb.fail();  // do not leave the other provers waiting at their hooks
+        });
+        newset.th = std::thread([&] {
+            (void)hipSetDevice(newset.c->device);
+            newset.rc = prove_newset(newset.c, newset);
+            if (newset.rc != VX_OK) rvb.fail();
+        });
+    } catch (...) {
+        rvb.fail();
+        rc = vx_fail(ctx, VX_ERR_DEVICE, "rotate: no host thread for the epoch-end tables");
+    }
+    // 2. header hash = Blake2b-256 of the first header_size bytes (rotate.rs:293); the trace of its compressions
+    //    is the witness of the hash STARK (one-header chain anchored at the header's own parent hash)
     const size_t chunks = (header_size + 127) / 128;
     const int bl = blake_rows_log(chunks);
     vx_buf* trace = nullptr;
-    VX_TRY(vx_alloc(ctx, ((size_t)VX_BLAKE_AIR_COLS) << bl, &trace));
-    uint64_t pub[20];  // tree_size 0: a stand-alone hash proof, nothing on the bus
-    int32_t rc = vx_blake_chain_trace(ctx, header, MAX_HEADER_SIZE, &header_size, 1, parent, epoch_end_block_number, 0, bl, trace, pub, header_hash);
-    // 2. justification by the current set over (epoch_end_block_number, header hash) (rotate.rs:297-302)
+    if (rc == VX_OK) rc = vx_alloc(ctx, ((size_t)VX_BLAKE_AIR_COLS) << bl, &trace);
+    uint64_t pub[20];
+    if (rc == VX_OK) rc = vx_blake_chain_trace(ctx, header, MAX_HEADER_SIZE, &header_size, 1, parent, epoch_end_block_number, 0, start_position + 1, wlen, bl, trace, pub, header_hash);
+    // 3. justification by the current set over (epoch_end_block_number, header hash) (rotate.rs:297-302), natively
     if (rc == VX_OK)
         rc = vx_verify_simple_justification(ctx, epoch_end_block_number, header_hash, just->authority_set_id, just->authority_set_hash,
                                             just->precommit, just->pubkeys, just->signatures, just->validator_signed, just->num_authorities,
                                             just->max_authorities);
-    // 3. the header encodes the new authority set (rotate.rs:306-312)
-    if (rc == VX_OK) rc = vx_verify_epoch_end_header(ctx, header, num_authorities, start_position, new_pubkeys, just->max_authorities);
     size_t len[3] = {0, 0, 0};
     int32_t rc_room = VX_OK;
     auto room = [&](size_t off) { return rc_room == VX_OK && proof_out && proof_cap > off; };
     if (rc == VX_OK) {
         rc = vx_stark_prove_impl(ctx, VX_AIR_BLAKE_CHAIN, cfg, trace->d, trace->n, 1, bl, pub, 20, room(VX_ROT_HDR) ? proof_out + VX_ROT_HDR : nullptr,
-                                 room(VX_ROT_HDR) ? proof_cap - VX_ROT_HDR : 0, &len[0]);
+                                 room(VX_ROT_HDR) ? proof_cap - VX_ROT_HDR : 0, &len[0], &hb[0]);
         if (rc == VX_ERR_BUFSZ) rc_room = rc, rc = VX_OK;
     }
-    (void)vx_free(ctx, trace);
-    // 4. commitment of the new set (the output, rotate.rs:317-320) on this context; then collect the current set's
-    std::vector<uint64_t> new_proof;
-    if (rc == VX_OK) {
-        size_t bound = 0;
-        rc = vx_stark_proof_bound(VX_AIR_SHA_CHAIN, cfg, sha_rows_log(num_authorities), &bound);
-        new_proof.resize(bound);
-        if (rc == VX_OK) rc = prove_set(ctx, new_pubkeys, num_authorities, commit[1], new_proof.data(), new_proof.size(), &len[2]);
-    }
+    if (rc != VX_OK) rvb.fail();
+    if (trace) (void)vx_free(ctx, trace);
+    // 4. collect the side tables
+    if (epoch.th.joinable()) epoch.th.join();
+    if (newset.th.joinable()) newset.th.join();
     const int32_t rc_just = vx_justification_tables_join(ctx, &jt);
     if (rc == VX_OK && rc_just != VX_OK) rc = rc_just;
-    len[1] = jt.job[0].len;
-    const size_t len_ed = jt.job[1].len, len_h = jt.job[2].len, total = VX_ROT_HDR + len[0] + len[1] + len[2] + len_ed + len_h;
+    for (TableJob* j : {&epoch, &newset})
+        if (rc == VX_OK && j->rc != VX_OK) rc = vx_fail(ctx, j->rc, "rotate: %s", vx_last_error(j->c)[0] ? vx_last_error(j->c) : "an epoch-end table failed");
+    len[1] = jt.job[0].len, len[2] = newset.len;
+    const size_t len_ed = jt.job[1].len, len_h = jt.job[2].len, len_ep = epoch.len, total = VX_ROT_HDR + len[0] + len[1] + len[2] + len_ed + len_h + len_ep;
     if (rc == VX_OK && rc_room == VX_OK && proof_out && proof_cap >= total) {
         size_t off = VX_ROT_HDR + len[0];
         memcpy(proof_out + off, jt.job[0].proof.data(), len[1] * 8), off += len[1];
-        memcpy(proof_out + off, new_proof.data(), len[2] * 8), off += len[2];
+        memcpy(proof_out + off, newset.proof.data(), len[2] * 8), off += len[2];
         memcpy(proof_out + off, jt.job[1].proof.data(), len_ed * 8), off += len_ed;
-        memcpy(proof_out + off, jt.job[2].proof.data(), len_h * 8);
+        memcpy(proof_out + off, jt.job[2].proof.data(), len_h * 8), off += len_h;
+        memcpy(proof_out + off, epoch.proof.data(), len_ep * 8);
     }
     if (rc != VX_OK) return rc;
     *proof_len = total;
-    memcpy(out32, commit[1], 32);
+    memcpy(out32, new_commit, 32);
     if (rc_room != VX_OK || !proof_out || proof_cap < *proof_len)
         return vx_fail(ctx, VX_ERR_BUFSZ, "rotate: proof needs %zu words, buffer has %zu", *proof_len, proof_cap);
     proof_out[0] = VX_ROT_MAGIC;
@@ -243,7 +294,7 @@ int32_t vx_rotate_prove(vx_ctx* ctx, const vx_buf* header, uint32_t header_size,
     proof_out[3] = num_authorities;
     memcpy(proof_out + 4, header_hash, 32);
     memcpy(proof_out + 8, just->authority_set_hash, 32);
-    memcpy(proof_out + 12, commit[1], 32);
+    memcpy(proof_out + 12, new_commit, 32);
     proof_out[16] = len[0];
     proof_out[17] = len[1];
     proof_out[18] = len[2];
@@ -253,6 +304,8 @@ int32_t vx_rotate_prove(vx_ctx* ctx, const vx_buf* header, uint32_t header_size,
     uint64_t round = 0;
     memcpy(&round, just->precommit + 37, 8);  // 0x01 || hash 32 || block 4 || round 8 || set id 8 (decoder.rs:159-200)
     proof_out[25] = round;
+    proof_out[26] = start_position;
+    proof_out[27] = len_ep;
     return VX_OK;
 }
 
@@ -268,24 +321,61 @@ int32_t vx_rotate_verify(const vx_stark_config* cfg, const uint64_t* blob, size_
     if (len <= VX_ROT_HDR || blob[0] != VX_ROT_MAGIC) return bad("bad rotate blob");
     if (blob[1] != authority_set_id || memcmp(blob + 8, authority_set_hash, 32) != 0) return bad("blob is for a different request");
     if (memcmp(blob + 12, out32, 32) != 0) return bad("public output differs from the blob");
-    const size_t l0 = blob[16], l1 = blob[17], l2 = blob[18], l3 = blob[19], l4 = blob[24];
-    if (l0 > len || l1 > len || l2 > len || l3 > len || l4 > len || VX_ROT_HDR + l0 + l1 + l2 + l3 + l4 != len) return bad("blob lengths are inconsistent");
-    if (blob[2] >> 32) return bad("block number out of range");
-    // Blake proof: a chain of exactly one header, numbered epoch_end_block, hashing to the blob's header hash.  The
-    // anchor (first 8 public inputs) is the parent hash the header itself carries -- free in this statement.
+    const size_t l0 = blob[16], l1 = blob[17], l2 = blob[18], l3 = blob[19], l4 = blob[24], l5 = blob[27];
+    if (l0 > len || l1 > len || l2 > len || l3 > len || l4 > len || l5 > len || VX_ROT_HDR + l0 + l1 + l2 + l3 + l4 + l5 != len) return bad("blob lengths are inconsistent");
+    if (blob[2] >> 32 || blob[26] >= MAX_HEADER_SIZE || blob[3] == 0 || blob[3] > 510) return bad("block number, start position or authority count out of range");
     const uint64_t* p0 = blob + VX_ROT_HDR;
-    uint64_t pub[20];
-    for (int j = 0; j < 8; ++j) {
-        uint32_t a, b;
-        memcpy(&a, (const uint8_t*)(blob + 20) + 4 * j, 4);
-        memcpy(&b, (const uint8_t*)(blob + 4) + 4 * j, 4);
-        pub[j] = a;
-        pub[8 + j] = b;
+    int32_t rc;
+    // Bus B: the Blake2b table (a chain of exactly one header, numbered epoch_end_block, hashing to the blob's header hash; the anchor
+    // is the parent hash the header itself carries -- free in this statement) sends the bytes from start_position + 1 on; the
+    // epoch-end table reads the ScheduledChange log of blob[3] authorities there and sends its keys; the new set's commitment table
+    // receives every key and hashes to out32.
+    {
+        const uint64_t* proof[3] = {p0, p0 + l0 + l1 + l2 + l3 + l4, p0 + l0 + l1};
+        const size_t pl[3] = {l0, l5, l2};
+        const int air[3] = {VX_AIR_BLAKE_CHAIN, VX_AIR_EPOCH_END, VX_AIR_SHA_CHAIN};
+        const uint64_t *ppub[3], *pcap[3];
+        size_t npub[3];
+        for (int t = 0; t < 3; ++t)
+            if (!vx_stark_proof_peek(proof[t], pl[t], cfg->cap_height, &ppub[t], &npub[t], &pcap[t])) return bad("epoch-end proofs are too short to hold a trace cap");
+        uint64_t bpub[20], epub[10], spub[10];
+        for (int j = 0; j < 8; ++j) {
+            uint32_t a, b;
+            memcpy(&a, (const uint8_t*)(blob + 20) + 4 * j, 4);
+            memcpy(&b, (const uint8_t*)(blob + 4) + 4 * j, 4);
+            bpub[j] = a;
+            bpub[8 + j] = b;
+        }
+        bpub[16] = bpub[17] = blob[2];
+        bpub[18] = blob[26] + 1, bpub[19] = 2;  // window mode: the bytes behind start_position
+        // the byte lengths of the log's two compact ints are the prover's to state (one-hot); the table's constraints tie them to the bytes
+        if (npub[1] != 10) return bad("epoch-end proof is malformed");
+        epub[0] = blob[3], epub[1] = 1;
+        for (int g = 0; g < 2; ++g) {
+            uint64_t sum = 0;
+            for (int a = 0; a < 4; ++a) {
+                const uint64_t f = ppub[1][2 + 4 * g + a];
+                if (f > 1) return bad("epoch-end proof: length flags are not one-hot");
+                epub[2 + 4 * g + a] = f, sum += f;
+            }
+            if (sum != 1) return bad("epoch-end proof: length flags are not one-hot");
+        }
+        be_limbs(out32, spub);
+        spub[8] = blob[3], spub[9] = 2;  // receives every key
+        uint64_t chal[4];
+        vx_shared_challenges_host(ppub, npub, pcap, 3, (size_t)4 << cfg->cap_height, chal, 4);
+        const uint64_t* want[3] = {bpub, epub, spub};
+        const size_t n_want[3] = {20, 10, 10};
+        uint64_t bus[2] = {0, 0};
+        for (int t = 0; t < 3; ++t) {
+            const uint64_t* apub = nullptr;
+            int L = 0;
+            rc = vx_stark_verify_ext(cfg, proof[t], pl[t], air[t], want[t], n_want[t], chal, &apub, &L, err, errlen);
+            if (rc != VX_OK) return rc;
+            for (int q = 0; q < 2; ++q) bus[q] = glh::add(bus[q], glh::mul(apub[q], ((uint64_t)1 << L) % glh::P));
+        }
+        if (bus[0] || bus[1]) return bad("the lookup bus between the header hash, the epoch-end table and the new set does not balance");
     }
-    pub[16] = pub[17] = blob[2];
-    pub[18] = pub[19] = 0;
-    int32_t rc = vx_stark_verify(cfg, p0, l0, VX_AIR_BLAKE_CHAIN, pub, 20, err, errlen);
-    if (rc != VX_OK) return rc;
     // the justification by the current set: commitment, Ed25519 and SHA-512 tables under shared lookup challenges; the signed
     // message is the precommit for (the proven header hash, the block number, the round, the request's set id)
     {
@@ -314,16 +404,7 @@ int32_t vx_rotate_verify(const vx_stark_config* cfg, const uint64_t* blob, size_
         }
         if (bus[0] || bus[1]) return bad("the lookup bus between the justification tables does not balance");
     }
-    // the new set's commitment (stand-alone): the hash, the number of keys (bound by the hash; taken from the proof), bus off
-    {
-        uint64_t spub[10];
-        be_limbs(out32, spub);
-        const uint64_t *ppub, *pcap;
-        size_t n_ppub;
-        if (!vx_stark_proof_peek(p0 + l0 + l1, l2, cfg->cap_height, &ppub, &n_ppub, &pcap) || n_ppub != 10) return bad("authority-set commitment proof is malformed");
-        spub[8] = ppub[8], spub[9] = 0;
-        return vx_stark_verify(cfg, p0 + l0 + l1, l2, VX_AIR_SHA_CHAIN, spub, 10, err, errlen);
-    }
+    return VX_OK;
 }
 
 }  // extern "C"

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void k_sha_chain_aux(const uint64_t* tr, uint6
     if (row >= n) return;
     const int r = (int)(row & 63);
     gl2 h{0, 0};
-    if (bus_on && r < 16 && !(r & 1) && tr[(size_t)SGC * n + row] && tr[(size_t)(r < 8 ? T_FIRST : T_DATA) * n + row]) {
+    // bus mode 1: the flagged keys are sent; mode 2: every key is received
+    if (bus_on && r < 16 && !(r & 1) && (bus_on == 2 || tr[(size_t)SGC * n + row]) && tr[(size_t)(r < 8 ? T_FIRST : T_DATA) * n + row]) {
         auto limbs = [&](int col0) -> uint64_t {
             uint32_t w = 0;
             for (int i = 0; i < 32; ++i) w |= (uint32_t)tr[(size_t)(col0 + i) * n + row] << i;
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256) void k_sha_chain_aux(const uint64_t* tr, uint6
         gl2 d = gl2_add(beta, gl2_add(gl2_scale(gamma, limbs(W0B)), gl2_add(gl2_scale(g2, limbs(W1B)), gl2_scale(g4, TAG_KEY))));
         d.a = gl_add(d.a, 4 * (tr[(size_t)KC * n + row] - 1) + ((r & 7) >> 1));
         h = gl2_inv(d);
+        if (bus_on == 2) h = gl2{gl_neg(h.a), gl_neg(h.b)};
     }
     aux[row] = h.a, aux[n + row] = h.b;
     aux[2 * n + row] = h.a, aux[3 * n + row] = h.b;  // increments; the scan makes them the running sum
@@ -186,7 +188,8 @@ extern "C" int32_t vx_sha_chain_trace(vx_ctx* ctx, const uint8_t* pubkeys, size_
                                       uint64_t public_inputs_out[10], uint8_t commitment_out[32]) {
     if (!ctx || !pubkeys || !trace_out || !public_inputs_out) return VX_ERR_ARG;
     VX_CHECK(log_n >= 6 && log_n <= 24 && trace_out->n >= ((size_t)shc::CHAIN_COLS << log_n), "sha trace: trace buffer too small");
-    return vx_sha_chain_trace_dev(ctx, pubkeys, n_keys, signed_flags, bus_on ? 1 : 0, log_n, trace_out->d, public_inputs_out, commitment_out);
+    VX_CHECK(bus_on <= 2, "sha trace: bus mode %u (0 off, 1 send the flagged keys, 2 receive every key)", bus_on);
+    return vx_sha_chain_trace_dev(ctx, pubkeys, n_keys, signed_flags, bus_on, log_n, trace_out->d, public_inputs_out, commitment_out);
 }
 
 // ---- ShaTreeAir: the two SHA-256 Merkle trees over state roots and data roots ------------------------------------------

@@ -19,6 +19,7 @@
 #include "air_blake.cuh"
 #include "air_sha.cuh"
 #include "air_ed.cuh"
+#include "air_epoch.cuh"
 #include "air_sha512.cuh"
 #include "air_sha_tree.cuh"
 #include "poseidon_constants.h"
@@ -377,6 +378,7 @@ static const AirDesc AIRS[] = {
     desc<ShaTreeAir16>(ShaTreeAir16::periodic_values, vx_sha_tree_gen_aux_16),
     desc<EdAir17>(EdAir17::periodic_values, vx_ed_air_gen_aux), desc<EdAir16>(EdAir16::periodic_values, vx_ed_air_gen_aux),
     desc<Sha512Air16>(Sha512Air16::periodic_values, vx_sha512_air_gen_aux), desc<Sha512Air10>(Sha512Air10::periodic_values, vx_sha512_air_gen_aux), desc<Sha512Air15>(Sha512Air15::periodic_values, vx_sha512_air_gen_aux),
+    desc<EpochEndAir>(EpochEndAir::periodic_values, vx_epoch_air_gen_aux),
 };
 static const AirDesc* find_air(int id) {
     for (const AirDesc& d : AIRS)

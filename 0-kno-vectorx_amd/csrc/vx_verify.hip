@@ -12,6 +12,7 @@
 #include "air_blake.cuh"
 #include "air_sha.cuh"
 #include "air_ed.cuh"
+#include "air_epoch.cuh"
 #include "air_sha512.cuh"
 #include "air_sha_tree.cuh"
 #include "poseidon_constants.h"
@@ -172,7 +173,7 @@ void v_lookup_periodic(std::vector<uint64_t>& v) {
 const AirV V_AIRS[] = {
     vdesc<ShaAir>(ShaAir::periodic_values), vdesc<FibAir>(v_no_periodic), vdesc<MixAir>(v_mix_periodic), vdesc<BlakeAir>(v_blake_periodic),
     vdesc<LookupAir>(v_lookup_periodic), vdesc<ShaTreeAir256>(ShaTreeAir256::periodic_values), vdesc<ShaTreeAir512>(ShaTreeAir512::periodic_values),
-    vdesc<ShaTreeAir16>(ShaTreeAir16::periodic_values), vdesc<EdAir17>(EdAir17::periodic_values), vdesc<EdAir16>(EdAir16::periodic_values), vdesc<Sha512Air16>(Sha512Air16::periodic_values), vdesc<Sha512Air10>(Sha512Air10::periodic_values), vdesc<Sha512Air15>(Sha512Air15::periodic_values),
+    vdesc<ShaTreeAir16>(ShaTreeAir16::periodic_values), vdesc<EdAir17>(EdAir17::periodic_values), vdesc<EdAir16>(EdAir16::periodic_values), vdesc<Sha512Air16>(Sha512Air16::periodic_values), vdesc<Sha512Air10>(Sha512Air10::periodic_values), vdesc<Sha512Air15>(Sha512Air15::periodic_values), vdesc<EpochEndAir>(EpochEndAir::periodic_values),
 };
 size_t brev(size_t x, int bits) {
     size_t r = 0;

@@ -27,7 +27,7 @@ SYMBOLS = [
     "vx_ed25519_verify_batch", "vx_verify_simple_justification", "vx_sha_chain_trace",
     "vx_verify_epoch_end_header", "vx_rotate_proof_bound", "vx_rotate_prove", "vx_rotate_verify",
     "vx_gather_proofs", "vx_quotient_eval", "vx_decode_header_batch", "vx_decode_precommit_batch", "vx_stark_aux_trace",
-    "vx_ed_trace", "vx_sha512_trace",
+    "vx_ed_trace", "vx_sha512_trace", "vx_epoch_end_trace",
 ]
 
 VX_AIR_FIBONACCI, VX_AIR_MIX, VX_AIR_BLAKE_CHAIN, VX_AIR_LOOKUP = 1, 2, 6, 5
@@ -38,6 +38,7 @@ VX_AIR_ED25519 = {17: 10, 16: 12}
 VX_ED_AIR_COLS, VX_ED_AIR_AUX_COLS = 839, 688
 VX_AIR_SHA512 = {16: 11, 15: 14, 10: 13}
 VX_SHA512_AIR_COLS, VX_SHA512_AIR_AUX_COLS = 801, 4
+VX_AIR_EPOCH_END, VX_EPOCH_END_AIR_COLS, VX_EPOCH_END_AIR_AUX_COLS = 15, 52, 46
 
 
 class JustificationStruct(C.Structure):
@@ -119,11 +120,12 @@ def load_library():
         "vx_stark_prove": [vp, C.c_int, C.POINTER(StarkConfig), vp, C.c_int, vp, sz, vp, sz, C.POINTER(sz)],
         "vx_blake2b_256_batch": [vp, vp, sz, vp, sz, vp], "vx_sha256_pairs": [vp, vp, sz, vp],
         "vx_verify_subchain": [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp],
-        "vx_blake_chain_trace": [vp, vp, sz, vp, sz, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp],
+        "vx_blake_chain_trace": [vp, vp, sz, vp, sz, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp],
         "vx_ed25519_verify_batch": [vp, vp, vp, vp, C.c_uint32, vp, sz, vp],
         "vx_sha_chain_trace": [vp, vp, sz, vp, C.c_uint32, C.c_int, vp, vp, vp],
         "vx_ed_trace": [vp, vp, vp, vp, C.c_uint32, vp, sz, C.c_int, C.c_uint32, vp, vp],
         "vx_sha512_trace": [vp, vp, vp, vp, C.c_uint32, vp, sz, C.c_int, C.c_uint32, vp, vp],
+        "vx_epoch_end_trace": [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp],
         "vx_verify_simple_justification": [vp, C.c_uint32, vp, u64, vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32],
         "vx_verify_epoch_end_header": [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32],
         "vx_rotate_proof_bound": [C.POINTER(StarkConfig), sz, sz, sz, C.POINTER(sz)],
@@ -211,14 +213,14 @@ def rotate_verify(blob, authority_set_id, authority_set_hash, out32, cfg=None):
         raise VxError(rc, err.value.decode())
 
 
-ROT_HDR = 26  # words before the first proof in a rotate blob
+ROT_HDR = 28  # words before the first proof in a rotate blob
 
 
 def split_rotate_blob(blob):
-    """-> (header-hash proof, current-set commitment proof, new-set commitment proof, Ed25519 proof, SHA-512 proof) of a
-    vx_rotate_prove blob."""
+    """-> (header-hash proof, current-set commitment proof, new-set commitment proof, Ed25519 proof, SHA-512 proof, epoch-end
+    proof) of a vx_rotate_prove blob."""
     out, off = [], ROT_HDR
-    for ln in (int(blob[16]), int(blob[17]), int(blob[18]), int(blob[19]), int(blob[24])):
+    for ln in (int(blob[16]), int(blob[17]), int(blob[18]), int(blob[19]), int(blob[24]), int(blob[27])):
         out.append(blob[off: off + ln])
         off += ln
     return tuple(out)
@@ -477,13 +479,14 @@ class Context:
         self._ck(self.L.vx_sha256_pairs(self.h, _ptr(p), p.shape[0], _ptr(out)))
         return out
 
-    def blake_chain_trace(self, headers_buf, stride, sizes, trusted_hash, first_block_number, log_n, trace_buf=None, tree_size=0):
+    def blake_chain_trace(self, headers_buf, stride, sizes, trusted_hash, first_block_number, log_n, trace_buf=None, tree_size=0, window=(0, 0)):
         sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
         th = np.frombuffer(bytes(trusted_hash), dtype=np.uint8).copy()
         trace_buf = trace_buf or self.alloc(VX_BLAKE_AIR_COLS << log_n)
         pub = np.zeros(20, dtype=np.uint64)
         dig = np.zeros((sizes.size, 32), dtype=np.uint8)
-        self._ck(self.L.vx_blake_chain_trace(self.h, headers_buf.h, stride, _ptr(sizes), sizes.size, _ptr(th), first_block_number, tree_size, log_n, trace_buf.h, _ptr(pub), _ptr(dig)))
+        self._ck(self.L.vx_blake_chain_trace(self.h, headers_buf.h, stride, _ptr(sizes), sizes.size, _ptr(th), first_block_number, tree_size, window[0], window[1], log_n,
+                                             trace_buf.h, _ptr(pub), _ptr(dig)))
         return trace_buf, pub, dig
 
     def sha_chain_trace(self, pubkeys, log_n, trace_buf=None, signed=None, bus_on=0):
@@ -520,6 +523,14 @@ class Context:
         pub = np.zeros(15, dtype=np.uint64)
         self._ck(self.L.vx_sha512_trace(self.h, _ptr(pk) if n else None, _ptr(sg) if n else None, _ptr(m), m.size, _ptr(en) if n else None, n, log_n, bus_on, trace_buf.h, _ptr(pub)))
         return trace_buf, pub
+
+    def epoch_end_trace(self, header_buf, start_position, num_authorities, bus_on=0, trace_buf=None):
+        """EpochEndAir trace of the ScheduledChange log behind start_position -> (Buffer [52][512], public inputs, window length)."""
+        trace_buf = trace_buf or self.alloc(VX_EPOCH_END_AIR_COLS << 9)
+        pub = np.zeros(10, dtype=np.uint64)
+        wlen = C.c_uint32(0)
+        self._ck(self.L.vx_epoch_end_trace(self.h, header_buf.h, start_position, num_authorities, bus_on, trace_buf.h, _ptr(pub), C.byref(wlen)))
+        return trace_buf, pub, wlen.value
 
     def ed25519_verify_batch(self, pubkeys, sigs, msg, enabled=None):
         pk = np.ascontiguousarray(np.frombuffer(b"".join(pubkeys), dtype=np.uint8))

@@ -204,7 +204,9 @@ int32_t vx_sha256_pairs(vx_ctx* ctx, const uint8_t* pairs64, size_t n, uint8_t* 
  * 32-bit little-endian limbs, first and last block number, tree_size, bus flag) and optionally the digests
  * (host).  tree_size = 16 / 256 / 512: the state roots (decoder.rs:121-128) and data roots (:132-149) of the
  * headers go onto the logUp bus towards a ShaTreeAir of that many leaves (vx_header_range_prove proves both
- * tables under shared challenges); tree_size = 0: a stand-alone hash-chain proof.  The 276
+ * tables under shared challenges); tree_size = 0: a stand-alone hash-chain proof.  window_length > 0 (one header, tree_size 0;
+ * rotate): bytes [window_offset, window_offset + window_length) of the header go onto the bus instead, towards the
+ * epoch-end table (vx_epoch_end_trace); public input 19 is the bus mode (0 / 1 / 2), 18 the tree size or the offset.  The 276
  * auxiliary (logUp) columns are derived inside vx_stark_prove once the lookup challenges exist.
  * The AIR proves that header i carries block number first_block_number + i as a SCALE compact int in
  * whichever of the four modes that number takes (decoder.rs:39-92) and reads the state root right behind it.
@@ -213,8 +215,8 @@ int32_t vx_sha256_pairs(vx_ctx* ctx, const uint8_t* pairs64, size_t n, uint8_t* 
  * Prove it with vx_stark_prove(ctx, VX_AIR_BLAKE_CHAIN, ...). */
 enum { VX_AIR_BLAKE_CHAIN = 6, VX_BLAKE_AIR_COLS = 745, VX_BLAKE_AIR_AUX_COLS = 276 };
 int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_headers,
-                             const uint8_t trusted_hash[32], uint32_t first_block_number, uint32_t tree_size, int log_n, vx_buf* trace_out,
-                             uint64_t public_inputs_out[20], uint8_t* digests_out);
+                             const uint8_t trusted_hash[32], uint32_t first_block_number, uint32_t tree_size, uint32_t window_offset, uint32_t window_length,
+                             int log_n, vx_buf* trace_out, uint64_t public_inputs_out[20], uint8_t* digests_out);
 
 /* ---- K8: ShaChainAir trace generation (compute_authority_set_commitment, justification.rs:127-162):
  * the chained SHA-256 commitment h_0 = SHA256(pk_0), h_i = SHA256(h_{i-1} || pk_i) over n_keys 32-byte
@@ -245,6 +247,20 @@ int32_t vx_ed_trace(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* signatur
 enum { VX_AIR_SHA512 = 11, VX_AIR_SHA512_10 = 13, VX_AIR_SHA512_15 = 14, VX_SHA512_AIR_COLS = 801, VX_SHA512_AIR_AUX_COLS = 4 };
 int32_t vx_sha512_trace(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* signatures, const uint8_t* message, uint32_t message_len, const uint8_t* signed_flags,
                         size_t n_signatures, int log_n, uint32_t bus_on, vx_buf* trace_out, uint64_t public_inputs_out[15]);
+
+/* ---- K9: EpochEndAir trace generation (verify_epoch_end_header in-proof, circuits/builder/rotate.rs:74-276): the
+ * ScheduledChange log of the epoch-end header -- consensus flag 4, "FRNK", a SCALE compact length, flag 1, the compact
+ * number of new authorities, num_authorities records (32-byte key, weight 1 as u64 LE), a zero u32 delay -- starting at byte
+ * start_position + 1 of `header` (resident in HBM), one row per record in a 512-row table.  The table RECEIVES those bytes
+ * over the logUp bus from the Blake2b table that hashes the header (vx_blake_chain_trace with window_offset =
+ * start_position + 1, window_length = *window_length_out) and SENDS the keys to the new set's ShaChainAir (vx_sha_chain_trace
+ * with bus_on = 2), so the new authority-set commitment is the commitment of exactly those header bytes.  Writes the 52-column
+ * trace and the 10 public inputs (num_authorities, bus_on, one-hot byte lengths 1/2/4/5 of the two compact ints).
+ * VX_ERR_STATEMENT when the prefix is not the log's; the records themselves are checked by the proof (and named by
+ * vx_verify_epoch_end_header).  Prove with vx_stark_prove(ctx, VX_AIR_EPOCH_END, ..., log_n = 9). */
+enum { VX_AIR_EPOCH_END = 15, VX_EPOCH_END_AIR_COLS = 52, VX_EPOCH_END_AIR_AUX_COLS = 46, VX_EPOCH_END_LOG_ROWS = 9 };
+int32_t vx_epoch_end_trace(vx_ctx* ctx, const vx_buf* header, uint32_t start_position, uint32_t num_authorities, uint32_t bus_on, vx_buf* trace_out,
+                           uint64_t public_inputs_out[10], uint32_t* window_length_out);
 
 /* ---- statement level: verify_subchain (circuits/builder/subchain_verification.rs:56-303)
  * headers: n_fetched encoded headers (blocks trusted+1 .. target) resident in HBM at `stride`

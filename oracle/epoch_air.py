@@ -28,13 +28,13 @@ NB = 44
 V, DL, Q0, COLS = 44, 45, 46, 52
 N_HELP = 23  # 20 pairs of byte receives, 2 pairs of key sends, the running sum
 AUX, CHAL, AUXPUB, PUB = 2 * N_HELP, 4, 1, 10
-PERIODIC = 2  # R0 (row 0), I (row index)
+PERIODIC = 2  # R0 (row 0), J (record index: 0 on row 0, i - 1 on row i -- one column, so that byte positions stay of degree 1)
 LENS = (1, 2, 4, 5)
 
 
 def periodic_values():
     n = 1 << LOG_N
-    return [[1] + [0] * (n - 1), list(range(n))]
+    return [[1] + [0] * (n - 1), [0] + list(range(n - 1))]
 
 
 def compact(v):
@@ -56,10 +56,10 @@ def prefix_len(pub):
 
 def lookups(loc, per, pub):
     """(multiplicity, tag, tuple) of the 44 lookups of the local row: 40 byte receives, 4 key sends."""
-    r0, idx = per[0], per[1]
+    r0, rec = per[0], per[1]
     on = pub[1]
     plen = prefix_len(pub)
-    kbase = (1 - r0) * (plen + (idx - 1) * 40)
+    kbase = (1 - r0) * plen + rec * 40
     out = []
     for j in range(40):
         pm = 0  # [j < P] for the prefix row
@@ -73,13 +73,13 @@ def lookups(loc, per, pub):
         out.append((0 - m * on, TAG_BYTE, (r0 * 0, kbase + j, loc[j], r0 * 0 + 1)))
     for q in range(4):
         l = [loc[8 * q + 2 * t] + loc[8 * q + 2 * t + 1] * 256 for t in range(4)]
-        out.append((loc[V] * on, TAG_KEY, ((idx - 1) * 4 + q, l[0] + l[1] * 65536, l[2] + l[3] * 65536, r0 * 0)))
+        out.append((loc[V] * on, TAG_KEY, (rec * 4 + q, l[0] + l[1] * 65536, l[2] + l[3] * 65536, r0 * 0)))
     return out
 
 
 def eval(loc, nxt, per, pub, c, chal, aux_pub):  # noqa: A001
     X2 = S.X2
-    r0, idx = per[0], per[1]
+    r0, rec = per[0], per[1]
     n_auth = pub[0]
     # ---- 1. row flags
     for col in [V, DL] + list(range(Q0, Q0 + 6)):
@@ -89,7 +89,7 @@ def eval(loc, nxt, per, pub, c, chal, aux_pub):  # noqa: A001
     c.constraint(r0 * (nxt[V] - 1))                          # row 1 is a validator
     c.constraint(nxt[DL] - loc[V] * (1 - nxt[V]))           # the delay row follows the last validator
     c.constraint((1 - r0) * nxt[V] * (1 - loc[V]))          # validators are rows 1..n
-    c.constraint(loc[DL] * (idx - n_auth - 1))              # ... and n is the public count
+    c.constraint(loc[DL] * (rec - n_auth))                  # ... and n is the public count
     # ---- 2. validator and delay rows
     c.constraint(loc[V] * (loc[32] - 1))
     for j in range(33, 40):

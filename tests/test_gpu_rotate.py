@@ -1,11 +1,12 @@
 """RotateCircuit on the GPU: vx_verify_epoch_end_header agrees with the oracle's restatement of
 builder/rotate.rs:74-276 on accepts and on every rejection class; vx_rotate_prove returns the oracle's new
-authority-set hash, its three STARKs are accepted by the python reference verifier and by the product's host
-verifier, and a wrong statement never reaches the prover."""
+authority-set hash, its six STARKs (two logUp buses) are accepted by the python reference verifier and by the
+product's host verifier, and a wrong statement never reaches the prover."""
 import numpy as np
 import pytest
 
 from oracle import blake_air as B
+from oracle import epoch_air as EP
 from oracle import rotate_ref as R
 from oracle import sha_air as A
 from oracle import stark_ref as S
@@ -13,6 +14,7 @@ from oracle import stark_ref as S
 pytestmark = pytest.mark.gpu
 S.register_air(B.BlakeChainAir)
 S.register_air(A.ShaChainAir)
+S.register_air(EP.EpochEndAir)
 
 
 def gpu_reason(ctx, vx, hb, n, pos, keys):
@@ -76,12 +78,19 @@ def test_rotate_prove_small(ctx, vx):
     why, want = R.rotate(e.padded.tobytes(), e.size, 140000, 5, e.start_position, e.new_pubkeys, 3, sj.authority_set_hash, sj, max_authorities=12)
     assert why is None and out32 == want == e.new_authority_set_hash
     assert blob[4:8].tobytes() == e.hash and blob[8:12].tobytes() == sj.authority_set_hash and blob[12:16].tobytes() == out32
-    p0, p1, p2, p_ed, p_h = vx.lib.split_rotate_blob(blob)
+    p0, p1, p2, p_ed, p_h, p_ep = vx.lib.split_rotate_blob(blob)
     limbs = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "little") for j in range(8)]  # noqa: E731
-    info = S.verify(p0, pcfg, expect_air=B.ID)
-    assert info["public_inputs"] == limbs(e.bytes[:32]) + limbs(e.hash) + [140000, 140000, 0, 0]  # stand-alone: nothing on the bus
     be = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "big") for j in range(8)]  # noqa: E731
-    assert S.verify(p2, pcfg, expect_air=A.ID)["public_inputs"] == be(out32) + [5, 0]  # the new set: 5 keys, stand-alone
+    # bus B (reference verifier): the header hash sends the bytes behind start_position, the epoch-end table reads the log there
+    # and sends its keys, the new set's commitment receives every key
+    tables = [(p0, B.ID), (p_ep, EP.ID), (p2, A.ID)]
+    chal = S.shared_challenges_n([S.proof_peek(p, 4) for p, _ in tables], 4)
+    infos = [S.verify(p, pcfg, expect_air=air, ext_chal=chal) for p, air in tables]
+    assert infos[0]["public_inputs"] == limbs(e.bytes[:32]) + limbs(e.hash) + [140000, 140000, e.start_position + 1, 2]
+    assert infos[1]["public_inputs"] == EP.gen_trace(e.bytes, e.start_position, 5)[1] and infos[1]["public_inputs"][:2] == [5, 1]
+    assert infos[2]["public_inputs"] == be(out32) + [5, 2]
+    assert all(sum(i["aux_public"][q] * (1 << i["degree_bits"]) for i in infos) % B.P == 0 for q in range(2)), "bus B does not balance"
+    assert any(i["aux_public"][0] for i in infos)
     # the justification by the current set: commitment, Ed25519 and SHA-512 tables on one bus (reference verifier)
     from oracle import ed_air as E
     from oracle import sha512_air as H5
@@ -98,7 +107,7 @@ def test_rotate_prove_small(ctx, vx):
     for args in ((4, sj.authority_set_hash, out32), (3, bytes(32), out32), (3, sj.authority_set_hash, bytes(32))):
         with pytest.raises(vx.VxError):
             vx.lib.rotate_verify(blob, *args, cfg)
-    for word in (5, 21, 25, 26 + int(blob[16]) // 2, 26 + int(blob[16]) + 40, len(blob) - 7):  # (25: the precommit's round)
+    for word in (3, 5, 21, 25, 26, 28 + int(blob[16]) // 2, 28 + int(blob[16]) + 40, len(blob) - 7):  # (25: the precommit's round, 26: start_position)
         bad = blob.copy()
         bad[word] ^= np.uint64(1)
         with pytest.raises(vx.VxError):

@@ -65,6 +65,21 @@ def test_epoch_end_table_and_its_two_buses(vx, n_new, logs_before):
     assert ((s_e + s_b + s_c).a, (s_e + s_b + s_c).b) == (0, 0)
 
 
+def test_epoch_end_prove_verify(vx):
+    """Every constraint has degree <= 3 (the quotient identity holds at zeta), stand-alone and under external challenges."""
+    e = vx.synth.EpochEndHeader(140000, 3)
+    cfg = dict(S.DEFAULT_CFG, num_queries=8)
+    for bus_on in (0, 1):
+        tr, pub, _, _ = EP.gen_trace(e.bytes, e.start_position, 3, bus_on=bus_on)
+        proof = S.prove(EP.EpochEndAir, tr, pub, cfg, chal_hook=(lambda pub_, cap: CHAL) if bus_on else None)
+        info = S.verify(proof, cfg, expect_air=EP.ID, expect_public=pub, ext_chal=CHAL if bus_on else None)
+        assert (info["aux_public"][:2] != [0, 0]) == bool(bus_on)
+    bad = proof.copy()
+    bad[len(bad) // 2] ^= np.uint64(1)
+    with pytest.raises(S.VerifyError):
+        S.verify(bad, cfg, expect_air=EP.ID, ext_chal=CHAL)
+
+
 def test_epoch_end_forgeries():
     import vx_import
 
