@@ -346,8 +346,11 @@ int32_t vx_verify_epoch_end_header(vx_ctx* ctx, const vx_buf* header, uint32_t n
                                    const uint8_t* new_pubkeys, uint32_t max_authorities);
 int32_t vx_rotate_proof_bound(const vx_stark_config* cfg, size_t n_chunks, size_t n_cur_authorities, size_t n_new_authorities,
                               size_t* n_words);
-/* RotateMethods::rotate (builder/rotate.rs:278-323) + Circuit::prove: header hash STARK, justification by the
- * current set (`just`, required), epoch-end header checks, both authority-set commitment STARKs.
+/* RotateMethods::rotate (builder/rotate.rs:278-323) + Circuit::prove.  Six STARKs on two logUp buses: (A) the justification
+ * by the current set (`just`, required): its commitment, the Ed25519 and the SHA-512 tables; (B) the Blake2b header hash, which
+ * sends the bytes behind start_position to the epoch-end table (verify_epoch_end_header in-proof), which sends the keys it
+ * reads there to the new set's commitment -- out32.  Every rule is also checked natively first and named in the error.
+ * The log must lie inside the first header_size bytes (the hashed ones) and behind byte 72.
  * VX_ERR_STATEMENT where the reference circuit's assertions (or the hint's panics) would fail. */
 int32_t vx_rotate_prove(vx_ctx* ctx, const vx_buf* header, uint32_t header_size, uint32_t epoch_end_block_number,
                         uint32_t num_authorities, uint32_t start_position, const uint8_t* new_pubkeys,
