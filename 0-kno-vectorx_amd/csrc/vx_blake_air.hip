@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k_blake_trace(const uint8_t* msgs, const 
     uint64_t eb = 0;
     for (int bq = 0; bq < 8; ++bq) {
         const uint32_t pos = d.t - d.inc + 8 * r + bq;
-        eb |= (uint64_t)((d.act && pos >= kof && pos < kof + wlen && pos < d.size && !(win_len && srw)) ? 1 : 0) << bq;
+        eb |= (uint64_t)((d.act && pos >= kof && pos < kof + wlen && (!win_len || (pos < d.size && !srw))) ? 1 : 0) << bq;
     }
     const uint64_t mdf = d.first ? (uint64_t)(d.mode == 0) | ((uint64_t)(d.mode == 1) << 1) | ((uint64_t)(d.mode == 3) << 2) : 0;
     st(SW_FLAGS) = (uint64_t)d.act | ((uint64_t)d.fin << 1) | ((uint64_t)d.first << 2) | ((uint64_t)(cap ? 1 : 0) << 3) | ((uint64_t)((d.first && d.act) ? 1 : 0) << 4) |
