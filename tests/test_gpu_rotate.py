@@ -130,6 +130,30 @@ def test_rotate_prove_small(ctx, vx):
     hb.free()
 
 
+@pytest.mark.parametrize("n_new,size,logs_before", [(1, None, 0), (70, 35840, 2)])
+def test_rotate_edges(ctx, vx, n_new, size, logs_before):
+    """One new authority (1-byte compact count, the log right behind the fixed fields) and a header of exactly MAX_HEADER_SIZE
+    bytes with a 2-byte compact count; a log that ends outside the hashed bytes is refused before anything is proven."""
+    cfg = ctx.stark_config(num_queries=8)
+    e = vx.synth.EpochEndHeader(150000 + n_new, n_new, size=size, logs_before=logs_before)
+    sj = vx.synth.Justification(e.number, e.hash, n_auth=4, n_signed=3, set_id=9)
+    just = vx.lib.PackedJustification(sj, max(8, n_new))  # (one MAX_AUTHORITY_SET_SIZE bounds both sets)
+    hb = ctx.from_host(e.padded)
+    out32, blob = ctx.rotate_prove(hb, e.size, e.number, n_new, e.start_position, e.new_pubkeys, just, cfg)
+    assert out32 == e.new_authority_set_hash and int(blob[26]) == e.start_position and int(blob[3]) == n_new
+    vx.lib.rotate_verify(blob, 9, sj.authority_set_hash, out32, cfg)
+    with pytest.raises(vx.VxError):
+        vx.lib.rotate_verify(blob, 9, sj.authority_set_hash, bytes(32), cfg)
+    # the same bytes hashed only up to the middle of the log: the native parser (which reads the padded array, as the
+    # reference's does) accepts, the prover refuses -- the hash would not cover what the epoch-end table reads
+    cut = e.start_position + 20
+    short = vx.synth.Justification(e.number, __import__("hashlib").blake2b(e.bytes[:cut], digest_size=32).digest(), n_auth=4, n_signed=3, set_id=9)
+    with pytest.raises(vx.VxError) as ei:
+        ctx.rotate_prove(hb, cut, e.number, n_new, e.start_position, e.new_pubkeys, vx.lib.PackedJustification(short, max(8, n_new)), cfg)
+    assert ei.value.code == -5 and "outside the hashed" in str(ei.value)
+    hb.free()
+
+
 def test_rotate_full_size(ctx, vx):
     """BASELINE configs[3]-shaped case: MAX_AUTHORITY_SET_SIZE = 300 current and 300 new authorities, 201 signers
     (201*3 > 300*2), a 15,360-byte epoch-end header; default StarkConfig.  Determinism: two runs, same bytes."""
