@@ -67,10 +67,12 @@ class RcclComm:
 
         rank, world = dist.get_rank(), dist.get_world_size()
         u = Uid()
-        if rank == 0 and self._lib.ncclGetUniqueId(C.byref(u)) != 0:
-            raise OSError("ncclGetUniqueId failed")
-        box = [bytes(u) if rank == 0 else None]
+        # rank 0 always broadcasts (None on failure): the other ranks must not be left waiting in the collective
+        got_id = rank != 0 or self._lib.ncclGetUniqueId(C.byref(u)) == 0
+        box = [(bytes(u) if got_id else None) if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            raise OSError("ncclGetUniqueId failed on rank 0")
         C.memmove(C.byref(u), box[0], 128)
         torch.cuda.set_device(device)
         comm = C.c_void_p()
