@@ -1,11 +1,19 @@
 // Context lifecycle, HBM buffers, K1 batch field arithmetic.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 
 #include "gl.cuh"
 #include <dlfcn.h>
 
 #include "vx_internal.h"
+
+// The provers keep 5-6 streams busy per proof and hosts run several proofs at once; the HIP runtime multiplexes all streams of a
+// process onto GPU_MAX_HW_QUEUES hardware queues, 4 by default, which serialises them (header_range_256: 7.26 -> 7.86 proofs/s with
+// 16; profiles/README.md).  The runtime reads the variable when it initialises (the first HIP call of the process), so it is set
+// when the library is loaded, unless the host has chosen a value itself.  A host that touches HIP before loading the library
+// exports it on its own.
+__attribute__((constructor)) static void vx_runtime_env() { setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0); }
 
 int32_t vx_fail(vx_ctx* ctx, int32_t code, const char* fmt, ...) {
     char buf[512];

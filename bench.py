@@ -8,8 +8,8 @@ resident in HBM (a 256-header P15k chain + its STARK trace): see `config.stages`
 line for exactly which stages are inside the timed region -- `config.complete_proof` says
 whether they add up to a full proof yet.  Independent inputs shard one per rank (weak
 scaling, no data-path collective); the only collective is the final RCCL gather of the
-fixed-size result blobs, outside the per-step work but inside the timed region.  By default three
-proofs are in flight per GPU (`--inflight`): K steps are K complete proofs, handed to three worker
+fixed-size result blobs, outside the per-step work but inside the timed region.  By default four
+proofs are in flight per GPU (`--inflight`): K steps are K complete proofs, handed to four worker
 contexts from one queue, so one proof's small-kernel tail overlaps another's bulk kernels.
 
 The JSON line carries `roofline` (NTT kernel: algorithmic bytes 16*n*c per transform over
@@ -261,15 +261,18 @@ def dry_launch(args):
 
 
 def main():
+    # before anything can initialise the HIP runtime (torch.cuda.set_device in the multi-rank path does, ahead of the library's own
+    # constructor): more hardware queues than the runtime's default 4, see vx_core.hip
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headers", type=int, default=256, choices=(256, 512),
                     help="256 = BASELINE.json configs[1] (the headline metric, default); 512 = configs[2]/[5]")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="proofs in flight per GPU (contexts + host threads; steps are handed out from one queue). Default: 2")
+                    help="proofs in flight per GPU (contexts + host threads; steps are handed out from one queue). Default: 4")
     ap.add_argument("--circuit", default="header_range", choices=("header_range", "rotate"),
                     help="header_range = the headline metric (default); rotate = BASELINE.json configs[3]")
     ap.add_argument("--dry-launch", action="store_true", help="rehearse the multi-rank launch on CPU (gloo), no GPU work")
@@ -305,7 +308,9 @@ def main():
             dist_mod.init_process_group(backend)
         dist = dist_mod
     vx = vx_import.load()
-    inflight = args.inflight or 3  # measured: 6.88 proofs/s with 3 in flight, 6.56 with 2, 6.30 with 1 (every proof already runs its five tables on five streams)
+    # measured with GPU_MAX_HW_QUEUES=16 (set by the library): 7.76 / 7.86 / 7.93 / 7.92 proofs/s with 3 / 4 / 5 / 6 in flight (every proof already
+    # runs its five tables on five streams); with the runtime's default of 4 hardware queues 7.26 / 7.22 with 3 / 4
+    inflight = args.inflight or 4
     inflight = max(1, min(inflight, args.steps))
     # `inflight` proofs are proven concurrently on this GPU: each worker thread owns a context (stream, pool) and an
     # input resident in HBM and takes the next step from a shared counter, so the tail of one proof (FRI layers, host
