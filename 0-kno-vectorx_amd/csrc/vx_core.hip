@@ -151,6 +151,16 @@ int32_t vx_ctx_create(int device, vx_ctx** out) {
     ctx->scratch_n = 0;
     ctx->pinned = nullptr;
     ctx->pinned_n = 0;
+    {
+        // A proof's host threads (one per table, several proofs in flight) mostly wait in hipStreamSynchronize.  The runtime's default
+        // spins: 35.6 s of CPU for a 10 s bench run, 9.3 s with blocking waits, at the same 7.95 proofs/s (profiles/README.md) -- and
+        // eight ranks share the cores of one node.  VX_SYNC_MODE = s (spin) / y (yield) / b (blocking, the default) overrides.
+        const char* sm = getenv("VX_SYNC_MODE");
+        const char m = sm ? sm[0] : 'b';
+        (void)hipSetDevice(device);
+        (void)hipSetDeviceFlags(m == 's' ? hipDeviceScheduleSpin : m == 'y' ? hipDeviceScheduleYield : hipDeviceScheduleBlockingSync);
+        (void)hipGetLastError();  // (a host that has fixed the flags already keeps them)
+    }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx;
