@@ -58,3 +58,19 @@ def test_integration_md_rust_block_is_generated_from_the_header():
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for name in declared_symbols():
         assert f"pub fn {name}(" in text, name
+
+
+def test_loading_the_library_raises_the_hardware_queue_limit():
+    """The provers run 5-6 streams per proof; the HIP runtime's default of 4 hardware queues serialised them (profiles/README.md).
+    Binding and library both set GPU_MAX_HW_QUEUES (without overriding a host's own choice) before the first HIP call."""
+    import subprocess
+    import sys
+
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('GPU_MAX_HW_QUEUES', None); os.environ['VX_NO_PY_ENV'] = '1'; "
+            "import ctypes, vx_import; vx = vx_import.load(); ctypes.CDLL(vx.lib.LIB_PATH); "
+            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; print(libc.getenv(b'GPU_MAX_HW_QUEUES'))") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout
+    assert out.strip() == "b'16'", out  # set by the library's constructor alone
+    code2 = code.replace("os.environ.pop('GPU_MAX_HW_QUEUES', None)", "os.environ['GPU_MAX_HW_QUEUES'] = '7'")
+    out = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, check=True).stdout
+    assert out.strip() == "b'7'", out  # a host's own value is kept
