@@ -43,6 +43,16 @@ def test_evm_packing(cli, vx):
     # the reference's own vector (dummy_header_range.rs test: first 80 input bytes) decodes field by field
     rot = bytes.fromhex("0000000000000075f2da06eb7ec36f683d2908648c431a1b3f968fa5212b72cc7e8eddce8b80958d")
     assert cli.unpack_rotate_input(rot) == {"authority_set_id": 0x75, "authority_set_hash": rot[8:40]}
+    # ... and the header_range literal of dummy_header_range.rs:66 (80 bytes: blocks 246150 -> 246330 under set 0x75), whose
+    # expected output (:73) is three 32-byte words: target hash, state-root Merkle root, data-root Merkle root
+    hr = bytes.fromhex("0003c18695f303b01e4834da35e5fdc3971fe297d1b48feb0c3f330491639136a6ada5980000000000000075"
+                       "f2da06eb7ec36f683d2908648c431a1b3f968fa5212b72cc7e8eddce8b80958d0003c23a")
+    got = cli.unpack_header_range_input(hr)
+    assert (got["trusted_block"], got["authority_set_id"], got["target_block"]) == (0x3C186, 0x75, 0x3C23A) and got["target_block"] - got["trusted_block"] == 180
+    assert got["authority_set_hash"] == rot[8:40] and vx.synth.pack_input(got["trusted_block"], got["trusted_hash"], got["authority_set_id"], got["authority_set_hash"], got["target_block"]) == hr
+    out = bytes.fromhex("3aaa82535ce715acb251047c280d5492d1330c41fe24c9841db508ba961dce464cb5c2a82cc64e401ac01ba85c471fe1dab4fe4baf7a96c306d4e94dcb428f47"
+                        "ead156d58c77adfa928845f048b50fd92e871776dfa76ed2f98c6ef823aa7a2d")
+    assert len(out) == 96  # (the headers behind it live on the Avail chain: the VALUES cannot be reproduced offline)
     with pytest.raises(cli.CliError):
         cli.unpack_header_range_input(raw[:79])
     with pytest.raises(cli.CliError):
