@@ -227,8 +227,14 @@ __global__ __launch_bounds__(256) void k_pow_brev_weights(PowBrevArgs a, uint64_
 // columns: the two ext weights of an index (32 bytes) are loaded once and used for BARY_CPB values (8 bytes each) --
 // with one column per block the weight stream, served by L2 / Infinity Cache, was 4x the data stream.
 constexpr int BARY_CPB = 2;  // measured per proof: 1 -> 9.3 ms, 4 -> 12.7 ms
+// gridDim.y = BARY_SPLIT blocks share a column pair (interleaved index ranges; partial sums to out + blockIdx.y * split_stride, added
+// on the host with the openings it downloads anyway): 1021 columns / 2 gave 511 blocks = two waves per SIMD, a latency-bound loop.
+#ifndef VX_BARY_SPLIT
+#define VX_BARY_SPLIT 4
+#endif
+constexpr int BARY_SPLIT = VX_BARY_SPLIT;
 __global__ __launch_bounds__(256) void k_bary_dot(const uint64_t* vals, size_t col_stride, int log_step, size_t n, size_t n_cols,
-                                                  const uint64_t* w0, const uint64_t* w1, uint64_t* out) {
+                                                  const uint64_t* w0, const uint64_t* w1, uint64_t* out, size_t split_stride) {
     __shared__ uint64_t red[256 * 4];
     const uint64_t* col[BARY_CPB];
     gl_acc acc[BARY_CPB][4];  // lazy sums (160-bit integers), reduced once per lane
@@ -239,7 +245,8 @@ __global__ __launch_bounds__(256) void k_bary_dot(const uint64_t* vals, size_t c
 #pragma unroll
         for (int e = 0; e < 4; ++e) gl_acc_zero(acc[q][e]);
     }
-    for (size_t i = threadIdx.x; i < n; i += 256) {
+    out += blockIdx.y * split_stride;
+    for (size_t i = blockIdx.y * (size_t)256 + threadIdx.x; i < n; i += (size_t)256 * gridDim.y) {
         const uint64_t a0 = w0[2 * i], b0 = w0[2 * i + 1], a1 = w1[2 * i], b1 = w1[2 * i + 1];
 #pragma unroll
         for (int q = 0; q < BARY_CPB; ++q) {
@@ -761,12 +768,13 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
     // coset points g * w_n^i (every 2^r-th LDE point) -- neither the trace values nor coefficients are needed
     uint64_t* w0 = mem.alloc(2 * n);
     uint64_t* w1 = mem.alloc(2 * n);
-    uint64_t* d_open = mem.alloc(4 * (c + nq));
+    const size_t open_words = 4 * (c + nq);
+    uint64_t* d_open = mem.alloc(BARY_SPLIT * open_words);
     VX_CHECK(w0 && w1 && d_open, "stark prove: out of device memory (openings)");
     hipLaunchKernelGGL(k_bary_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, L, g, gl2{zeta.a, zeta.b},
                        gl2{zeta_next.a, zeta_next.b}, (const uint64_t*)ctx->tw_fwd.d, w0, w1);
-    hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)((nq + BARY_CPB - 1) / BARY_CPB)), dim3(256), 0, ctx->stream, (const uint64_t*)quot_lde, N, r, n, (size_t)nq, (const uint64_t*)w0,
-                       (const uint64_t*)w1, d_open + 4 * c);
+    hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)((nq + BARY_CPB - 1) / BARY_CPB), BARY_SPLIT), dim3(256), 0, ctx->stream, (const uint64_t*)quot_lde, N, r, n, (size_t)nq, (const uint64_t*)w0,
+                       (const uint64_t*)w1, d_open + 4 * c, open_words);
     if (coef_main) {
         // the coefficients are at hand (bit-reversed positions): plain evaluation, no barycentric factor
         PowBrevArgs pa{};
@@ -779,19 +787,21 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
             z1 = e_mul(z1, z1);
         }
         hipLaunchKernelGGL(k_pow_brev_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, pa, w0, w1);
-        hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)((cm + BARY_CPB - 1) / BARY_CPB)), dim3(256), 0, ctx->stream, (const uint64_t*)coef_main, n, 0, n, cm, (const uint64_t*)w0,
-                           (const uint64_t*)w1, d_open);
+        hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)((cm + BARY_CPB - 1) / BARY_CPB), BARY_SPLIT), dim3(256), 0, ctx->stream, (const uint64_t*)coef_main, n, 0, n, cm, (const uint64_t*)w0,
+                           (const uint64_t*)w1, d_open, open_words);
         if (ca)
-            hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)((ca + BARY_CPB - 1) / BARY_CPB)), dim3(256), 0, ctx->stream, (const uint64_t*)aux_d, n, 0, n, ca, (const uint64_t*)w0,
-                               (const uint64_t*)w1, d_open + 4 * cm);
+            hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)((ca + BARY_CPB - 1) / BARY_CPB), BARY_SPLIT), dim3(256), 0, ctx->stream, (const uint64_t*)aux_d, n, 0, n, ca, (const uint64_t*)w0,
+                               (const uint64_t*)w1, d_open + 4 * cm, open_words);
     } else {
-        hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)((c + BARY_CPB - 1) / BARY_CPB)), dim3(256), 0, ctx->stream, (const uint64_t*)trace_lde, N, r, n, c, (const uint64_t*)w0,
-                           (const uint64_t*)w1, d_open);
+        hipLaunchKernelGGL(k_bary_dot, dim3((unsigned)((c + BARY_CPB - 1) / BARY_CPB), BARY_SPLIT), dim3(256), 0, ctx->stream, (const uint64_t*)trace_lde, N, r, n, c, (const uint64_t*)w0,
+                           (const uint64_t*)w1, d_open, open_words);
     }
     VX_HIP(hipGetLastError());
-    std::vector<uint64_t> h_open(4 * (c + nq));
+    std::vector<uint64_t> h_open(BARY_SPLIT * open_words);
     VX_HIP(hipMemcpyAsync(h_open.data(), d_open, h_open.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     VX_HIP(hipStreamSynchronize(ctx->stream));
+    for (int sp = 1; sp < BARY_SPLIT; ++sp)  // the partial sums of the split blocks
+        for (size_t j = 0; j < open_words; ++j) h_open[j] = glh::add(h_open[j], h_open[sp * open_words + j]);
     const uint64_t gn_ = glh::pow(g, n), fsc = glh::inv(glh::mul(n % glh::P, gn_));
     const Ext f0 = e_scale(e_sub(e_pow(zeta, n), Ext{gn_, 0}), fsc);       // (zeta^n - g^n) / (n g^n)
     const Ext f1 = e_scale(e_sub(e_pow(zeta_next, n), Ext{gn_, 0}), fsc);  // ((w zeta)^n - g^n) / (n g^n)
