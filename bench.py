@@ -109,10 +109,13 @@ def ntt_roofline(ctx, iters=10):
     for _ in range(2):
         ctx.ntt(buf, NTT_LOG_N, NTT_COLS, order=1)
     ctx.sync()
-    ctx.timer_start()
-    for _ in range(iters):
-        ctx.ntt(buf, NTT_LOG_N, NTT_COLS, order=1)
-    ms = ctx.timer_stop() / iters
+    groups = []
+    for _ in range(3):  # three groups of `iters` transforms, the best group counts (the proofs before it leave the clocks where they were)
+        ctx.timer_start()
+        for _ in range(iters):
+            ctx.ntt(buf, NTT_LOG_N, NTT_COLS, order=1)
+        groups.append(ctx.timer_stop() / iters)
+    ms = min(groups)
     buf.free()
     launches = 1 + (NTT_LOG_N > 12) + (NTT_LOG_N > 20)
     alg_bytes = 16.0 * n * NTT_COLS
@@ -132,7 +135,7 @@ def ntt_roofline(ctx, iters=10):
         "bound": "hbm", "kernel": "k_ntt_tile", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "per": f"one forward NTT of 2^{NTT_LOG_N} x {NTT_COLS} columns = {launches} launches, {alg_bytes / 1e9:.3f} GB algorithmic (16*n*c)",
-        "ms_per_transform": round(ms, 4), "ms_per_launch": round(ms / launches, 4),
+        "ms_per_transform": round(ms, 4), "ms_per_launch": round(ms / launches, 4), "ms_per_transform_groups": [round(g, 4) for g in groups],
     }
 
 
