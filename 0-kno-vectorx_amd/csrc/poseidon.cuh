@@ -10,6 +10,7 @@
 // 32-bit ops for the high part), and the two sums are recombined with
 // 2^64 = 2^32 - 1 (mod p).
 #pragma once
+#include <utility>
 #include "gl.cuh"
 #include "poseidon_constants.h"
 
@@ -198,9 +199,74 @@ __device__ __forceinline__ uint64_t poseidon_mds_coop(uint64_t s, int l, uint64_
     const uint64_t y = ((uint64_t)yhi << 32) | (uint32_t)w;
     return y + (carry ? (uint64_t)GL_EPS : 0);
 }
+// ---- the same layer with wavefront shuffles instead of LDS (north_star's "wavefront shuffles for the Poseidon MDS"): the
+// 15 other lanes of the 16-lane row come in through DPP row rotations (v_mov_b32 ... row_ror:n, two per 64-bit element).
+// Each lane multiplies what rotation n brings by a coefficient fixed for the kernel: C[(q - l) mod 12] when the source lane
+// q holds a state element, 0 when it is one of the four idle lanes -- found by rotating the lane numbers themselves, so the
+// code does not depend on the direction row_ror turns.  Default since the A/B in profiles/README.md (3-9 % on small trees, caps
+// identical); -DVX_POSEIDON_COOP_DPP=0 brings the LDS exchange back.
+#ifndef VX_POSEIDON_COOP_DPP
+#define VX_POSEIDON_COOP_DPP 1
+#endif
+template <int N>
+__device__ __forceinline__ uint32_t dpp_ror(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x120 + N, 0xf, 0xf, false);
+}
+struct CoopCoef {
+    uint32_t c[16];
+};
+static __device__ const uint32_t POSEIDON_MDS_CIRC_DEV[12] = VX_POSEIDON_MDS_CIRC_INIT;
+template <int N>
+__device__ __forceinline__ void coop_coef_one(CoopCoef& k, int l) {
+    const int q = (int)dpp_ror<N>((uint32_t)l);
+    int d = q - l;
+    if (d < 0) d += 12;
+    k.c[N] = (q < 12 && l < 12) ? POSEIDON_MDS_CIRC_DEV[d < 12 ? d : 0] : 0;
+}
+template <int... Ns>
+__device__ __forceinline__ void coop_coef_all(CoopCoef& k, int l, std::integer_sequence<int, Ns...>) {
+    (coop_coef_one<Ns + 1>(k, l), ...);
+}
+template <int N>
+__device__ __forceinline__ void coop_mac_one(const CoopCoef& k, uint64_t s, uint64_t& al, uint64_t& ah) {
+    const uint32_t lo = dpp_ror<N>((uint32_t)s), hi = dpp_ror<N>((uint32_t)(s >> 32));
+    al += (uint64_t)lo * k.c[N];
+    ah += (uint64_t)hi * k.c[N];
+}
+template <int... Ns>
+__device__ __forceinline__ void coop_mac_all(const CoopCoef& k, uint64_t s, uint64_t& al, uint64_t& ah, std::integer_sequence<int, Ns...>) {
+    (coop_mac_one<Ns + 1>(k, s, al, ah), ...);
+}
+__device__ __forceinline__ uint64_t poseidon_mds_coop_dpp(uint64_t s, int l, const CoopCoef& k) {
+    uint64_t al = (uint64_t)(uint32_t)s * k.c[0], ah = (s >> 32) * k.c[0];
+    coop_mac_all(k, s, al, ah, std::make_integer_sequence<int, 15>{});
+    if (l == 0) {
+        al += (uint64_t)(uint32_t)s * VX_POSEIDON_MDS_DIAG0;
+        ah += (s >> 32) * VX_POSEIDON_MDS_DIAG0;
+    }
+    const uint64_t w = (ah >> 32) * GL_EPS + al;
+    uint32_t yhi;
+    const bool carry = __builtin_add_overflow((uint32_t)(w >> 32), (uint32_t)ah, &yhi);
+    const uint64_t y = ((uint64_t)yhi << 32) | (uint32_t)w;
+    return y + (carry ? (uint64_t)GL_EPS : 0);
+}
 // s = this lane's state element (l < 12); returns the permuted element, canonical
 __device__ __forceinline__ uint64_t poseidon_permute_coop(uint64_t s, int l, uint64_t* g) {
     const int lc = l < 12 ? l : 0;
+#if VX_POSEIDON_COOP_DPP
+    CoopCoef k;
+    k.c[0] = l < 12 ? POSEIDON_MDS_CIRC_DEV[0] : 0;
+    coop_coef_all(k, l, std::make_integer_sequence<int, 15>{});
+    if (l >= 12) s = 0;
+#pragma unroll 1
+    for (int r = 0; r < 30; ++r) {
+        s = gl_add_nc(s, POSEIDON_RC[12 * r + lc]);
+        const bool full = r < 4 || r >= 26;
+        if (full || l == 0) s = poseidon_sbox(s);
+        s = poseidon_mds_coop_dpp(s, l, k);
+    }
+    return gl_canon(s);
+#endif
 #pragma unroll 1
     for (int r = 0; r < 30; ++r) {
         s = gl_add_nc(s, POSEIDON_RC[12 * r + lc]);  // folded table: partial rounds carry a constant for element 0 only
