@@ -131,8 +131,19 @@ def ntt_roofline(ctx, iters=10):
             traffic_src = (f"profiles/{tag}_ntt_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/ntt_pmc.py), calibrated on known "
                            "8-B/lane streams; GB per transform")
             break
+    # why the fraction is what it is: the kernel is integer-VALU bound, not bandwidth bound (the committed rocprofv3 --pmc SQ pass of one proof)
+    alu = None
+    ppath = os.path.join(ROOT, "profiles", "r02_pmc_valu_by_kernel.json")
+    if os.path.exists(ppath):
+        k = json.load(open(ppath)).get("k_ntt_tile<1, 0>")
+        if k:
+            alu = {"valu_active_per_wave_cycle": k["SQ_ACTIVE_INST_VALU/WAVE_CYCLES"], "waves_per_simd": 3,
+                   "valu_issue_utilisation_per_simd": round(3 * k["SQ_ACTIVE_INST_VALU/WAVE_CYCLES"], 2),
+                   "note": "three waves per SIMD each issue a VALU instruction in 0.31 of their cycles: the SIMD's VALU port is busy ~0.93 of the time; "
+                           "HBM traffic is 2.0x algorithmic with no re-reads, so fewer instructions per butterfly, not fewer bytes, would raise the fraction",
+                   "source": "profiles/r02_pmc_valu_by_kernel.json (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, rocprofv3 --pmc)"}
     return {
-        "bound": "hbm", "kernel": "k_ntt_tile", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "bound": "hbm", "alu_bound_evidence": alu, "kernel": "k_ntt_tile", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "per": f"one forward NTT of 2^{NTT_LOG_N} x {NTT_COLS} columns = {launches} launches, {alg_bytes / 1e9:.3f} GB algorithmic (16*n*c)",
         "ms_per_transform": round(ms, 4), "ms_per_launch": round(ms / launches, 4), "ms_per_transform_groups": [round(g, 4) for g in groups],
