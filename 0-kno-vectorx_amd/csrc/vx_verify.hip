@@ -35,7 +35,7 @@ void v_poseidon(uint64_t* s) {
             unsigned __int128 acc = 0;
             for (int i = 0; i < 12; ++i) acc += (unsigned __int128)s[(i + row) % 12] * V_MDS[i];
             if (row == 0) acc += (unsigned __int128)s[0] * VX_POSEIDON_MDS_DIAG0;
-            o[row] = (uint64_t)(acc % glh::P);
+            o[row] = glh::reduce128(acc);
         }
         memcpy(s, o, sizeof o);
     }
