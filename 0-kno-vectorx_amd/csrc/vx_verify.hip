@@ -228,6 +228,8 @@ int32_t vx_stark_verify_ext(const vx_stark_config* cfg, const uint64_t* pr, size
     auto have = [&](size_t k) { return pos + k <= len; };
     NEED(have(10), "proof truncated (header)");
     NEED(pr[0] == 0x314b524154535856ULL, "bad magic");
+    // (every narrow header field is compared as the 64-bit word it is: a proof has ONE encoding)
+    NEED(((pr[1] | pr[2] | pr[5] | pr[6] | pr[7] | pr[8]) >> 31) == 0, "header word out of range");
     const int air_id = (int)pr[1], L = (int)pr[2];
     const size_t nq = pr[4];
     const int r = (int)pr[5], cap_h = (int)pr[6];
@@ -252,7 +254,7 @@ int32_t vx_stark_verify_ext(const vx_stark_config* cfg, const uint64_t* pr, size
         }
     }
     NEED(have(n_layers + 2) && n_layers == arities.size(), "FRI plan mismatch");
-    for (size_t i = 0; i < n_layers; ++i) NEED((int)pr[pos + i] == arities[i], "FRI plan mismatch");
+    for (size_t i = 0; i < n_layers; ++i) NEED(pr[pos + i] == (uint64_t)arities[i], "FRI plan mismatch");
     pos += n_layers;
     const size_t final_len = pr[pos], n_pub = pr[pos + 1];
     pos += 2;

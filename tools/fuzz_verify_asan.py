@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Mutation fuzzing of the HOST verifier under AddressSanitizer + UBSan (CPU only; the verifier takes untrusted proofs).
+
+Builds vx_verify.hip host-only with -fsanitize=address,undefined, loads it in a child interpreter started with the sanitizer runtime
+preloaded, and feeds vx_stark_verify / vx_header_range_verify mutated proofs: seeds are real proofs of the small AIRs made by the CPU
+reference prover (oracle/stark_ref.py -- test infrastructure, used here to make inputs only).  Mutations: word flips, random words,
+truncation, extension, the degree-bits / length fields set to every small value, header words of a range blob set to extremes.
+Any sanitizer report aborts the child: the script fails.  Every mutated proof must also be REJECTED (a flipped word that is accepted
+would be a soundness bug) unless it is byte-identical to its seed.
+
+usage: fuzz_verify_asan.py [iterations per seed]      (default 3000; about a minute)"""
+import ctypes as C
+import glob
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = "/tmp/libvxverify_asan.so"
+SRC = os.path.join(ROOT, "0-kno-vectorx_amd", "csrc", "vx_verify.hip")
+
+
+def build():
+    if os.path.exists(SO) and os.path.getmtime(SO) > os.path.getmtime(SRC):
+        return
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--cuda-host-only", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-fno-omit-frame-pointer", "-fPIC", "-fvisibility=hidden", "-shared", "-o", SO, SRC], cwd=os.path.dirname(SRC))
+
+
+def child(iters):
+    import numpy as np
+
+    sys.path.insert(0, ROOT)
+    from oracle import stark_ref as S
+
+    L = C.CDLL(SO)
+
+    import vx_import
+
+    vx = vx_import.load()
+    StarkConfig = vx.lib.StarkConfig
+    cfg = StarkConfig()
+    for k, v in dict(S.DEFAULT_CFG, num_queries=8).items():
+        setattr(cfg, k, v)
+    ocfg = dict(S.DEFAULT_CFG, num_queries=8)
+    vp, sz = C.c_void_p, C.c_size_t
+    L.vx_stark_verify.argtypes = [C.POINTER(StarkConfig), vp, sz, C.c_int, vp, sz, C.c_char_p, sz]
+    L.vx_header_range_verify.restype = C.c_int32
+    L.vx_stark_verify.restype = C.c_int32
+    err = C.create_string_buffer(256)
+
+    def verify(words, air):
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        return L.vx_stark_verify(C.byref(cfg), w.ctypes.data_as(vp), w.size, air, None, 0, err, 256)
+
+    rng = np.random.default_rng(2026)
+    total = rejected = 0
+    for air, log_n in ((S.FibAir, 5), (S.MixAir, 6), (S.LookupAir, 8), (S.FibAir, 9)):
+        tr, pub = air.trace(log_n)
+        seed = S.prove(air, tr, pub, ocfg)
+        assert verify(seed, air.ID) == 0, err.value
+        n = seed.size
+        for it in range(iters):
+            p = seed.copy()
+            kind = it % 8
+            if kind == 0:
+                p[rng.integers(n)] ^= np.uint64(1) << np.uint64(rng.integers(64))
+            elif kind == 1:
+                p[rng.integers(n)] = np.uint64(rng.integers(0, 2**63)) * np.uint64(2) + np.uint64(rng.integers(2))
+            elif kind == 2:
+                p = p[: rng.integers(0, n)]
+            elif kind == 3:
+                p = np.concatenate([p, rng.integers(0, 2**63, size=rng.integers(1, 40), dtype=np.uint64)])
+            elif kind == 4:  # the header words (air id, degree bits, counts ...) set to small and extreme values
+                p[rng.integers(0, min(16, n))] = np.uint64([0, 1, 2, 3, 26, 27, 63, 64, 2**32 - 1, 2**32, 2**63, 2**64 - 1][rng.integers(12)])
+            elif kind == 5:
+                k = rng.integers(1, 6)
+                for _ in range(k):
+                    p[rng.integers(n)] = np.uint64(2**64 - 1)
+            elif kind == 6:
+                a, b = sorted(rng.integers(0, n, size=2))
+                p[a:b] = 0
+            else:
+                p = rng.integers(0, 2**63, size=rng.integers(0, 2 * n), dtype=np.uint64)
+            rc = verify(p, air.ID)
+            total += 1
+            if p.size == n and (p == seed).all():
+                continue
+            assert rc != 0, f"mutation kind {kind} of a {air.__name__} proof was ACCEPTED"
+            rejected += 1
+    # range blobs: garbage behind a valid magic, extreme lengths
+    L.vx_header_range_verify.argtypes = [C.POINTER(StarkConfig), vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, C.c_uint32, vp, C.c_char_p, sz]
+    magic = int(vx.lib.HR_MAGIC)
+    out96 = (C.c_uint8 * 96)()
+    h32 = (C.c_uint8 * 32)()
+    for it in range(iters):
+        m = int(rng.integers(0, 4000))
+        b = rng.integers(0, 2**63, size=m, dtype=np.uint64)
+        if m > 22:
+            b[0] = np.uint64(magic)
+            b[1], b[2], b[3] = np.uint64(256), np.uint64(100), np.uint64(356)
+            for q in range(16, 21):
+                b[q] = np.uint64([0, 1, m, m - 22, (m - 22) // 5, 2**64 - 1, 2**63][rng.integers(7)])
+        rc = L.vx_header_range_verify(C.byref(cfg), b.ctypes.data_as(vp), b.size, 256, 100, h32, 0, h32, 356, out96, err, 256)
+        assert rc != 0
+        total += 1
+    print(f"fuzz: {total} inputs, {rejected} mutated proofs rejected, no sanitizer report")
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--child":
+        child(int(sys.argv[2]))
+    else:
+        build()
+        rt = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")[0]
+        env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+        iters = sys.argv[1] if len(sys.argv) > 1 else "3000"
+        sys.exit(subprocess.call([sys.executable, os.path.abspath(__file__), "--child", iters], env=env))
