@@ -123,3 +123,47 @@ def test_a_proof_has_one_encoding(vx):
             if accepted(p):
                 bad.append((w, "x + p"))
     assert not bad, f"accepted mutations (word, bit): {bad[:20]}"
+
+
+def _blobs():
+    import os
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "circuit_blobs.npz"), allow_pickle=False)
+
+
+def test_circuit_verifiers_on_gpu_made_blobs(vx):
+    """tests/golden/circuit_blobs.npz (tools/make_blob_fixtures.py, made on an MI355X): a header_range blob (five tables, one bus)
+    and a rotate blob (six tables, two buses) go through the host verifiers here, on the CPU tier: accepted for their requests,
+    rejected for any other request, any other claimed output, and after tampering anywhere."""
+    z = _blobs()
+    cfg = vx.lib.default_stark_config(num_queries=2)
+    hr, out96, th, sh = z["hr_blob"], z["hr_out96"].tobytes(), z["hr_trusted_hash"].tobytes(), z["hr_set_hash"].tobytes()
+    tb, tg, sid = int(z["hr_trusted_block"]), int(z["hr_target_block"]), int(z["hr_set_id"])
+    ok = lambda blob=hr, mh=16, a=tb, h=th, g=tg, o=out96, s=sh, i=sid: vx.lib.header_range_verify(blob, mh, a, h, g, o, cfg, authority_set_hash=s, authority_set_id=i)  # noqa: E731
+    ok()
+    flip = lambda b, k=0: bytes([b[k] ^ 1]) + b[1:] if k == 0 else b[:k] + bytes([b[k] ^ 1]) + b[k + 1:]  # noqa: E731
+    for kw in (dict(mh=256), dict(a=tb + 1), dict(h=flip(th)), dict(g=tg - 1), dict(o=flip(out96)), dict(o=flip(out96, 40)), dict(o=flip(out96, 95)), dict(s=flip(sh)), dict(i=sid + 1)):
+        with pytest.raises(vx.VxError):
+            ok(**kw)
+    rng = np.random.default_rng(5)
+    for w in list(range(22)) + [int(x) for x in rng.integers(22, hr.size, size=60)]:
+        bad = hr.copy()
+        bad[w] ^= np.uint64(1) << np.uint64(rng.integers(64))
+        with pytest.raises(vx.VxError):
+            ok(blob=bad)
+    for cut in (0, 5, 22, hr.size // 2, hr.size - 1):
+        with pytest.raises(vx.VxError):
+            ok(blob=hr[:cut])
+    rot, out32, rsh, rid = z["rot_blob"], z["rot_out32"].tobytes(), z["rot_set_hash"].tobytes(), int(z["rot_set_id"])
+    vx.lib.rotate_verify(rot, rid, rsh, out32, cfg)
+    for args in ((rid + 1, rsh, out32), (rid, flip(rsh), out32), (rid, rsh, flip(out32, 31))):
+        with pytest.raises(vx.VxError):
+            vx.lib.rotate_verify(rot, *args, cfg)
+    for w in list(range(28)) + [int(x) for x in rng.integers(28, rot.size, size=60)]:
+        bad = rot.copy()
+        bad[w] ^= np.uint64(1) << np.uint64(rng.integers(64))
+        with pytest.raises(vx.VxError):
+            vx.lib.rotate_verify(bad, rid, rsh, out32, cfg)
+    for cut in (0, 27, 28, rot.size // 3, rot.size - 1):
+        with pytest.raises(vx.VxError):
+            vx.lib.rotate_verify(rot[:cut], rid, rsh, out32, cfg)

@@ -104,6 +104,45 @@ def child(iters):
         rc = L.vx_header_range_verify(C.byref(cfg), b.ctypes.data_as(vp), b.size, 256, 100, h32, 0, h32, 356, out96, err, 256)
         assert rc != 0
         total += 1
+    # a real blob (tests/golden/circuit_blobs.npz, made on the GPU): five proofs behind a 22-word header
+    z = np.load(os.path.join(ROOT, "tests", "golden", "circuit_blobs.npz"), allow_pickle=False)
+    cfg2 = StarkConfig()
+    for k, v in dict(S.DEFAULT_CFG, num_queries=2).items():
+        setattr(cfg2, k, v)
+    hr = np.ascontiguousarray(z["hr_blob"], dtype=np.uint64)
+    o96, th, sh = (np.ascontiguousarray(z[k]) for k in ("hr_out96", "hr_trusted_hash", "hr_set_hash"))
+    tb, tg, sid = int(z["hr_trusted_block"]), int(z["hr_target_block"]), int(z["hr_set_id"])
+
+    def hr_verify(b):
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        return L.vx_header_range_verify(C.byref(cfg2), b.ctypes.data_as(vp), b.size, 16, tb, th.ctypes.data_as(vp), sid, sh.ctypes.data_as(vp), tg, o96.ctypes.data_as(vp), err, 256)
+
+    assert hr_verify(hr) == 0, err.value
+    n = hr.size
+    for it in range(max(iters // 4, 50)):
+        p = hr.copy()
+        kind = it % 6
+        if kind == 0:
+            p[rng.integers(n)] ^= np.uint64(1) << np.uint64(rng.integers(64))
+        elif kind == 1:
+            p[rng.integers(0, 22)] = np.uint64([0, 1, 21, 22, n, n - 22, 2**32, 2**63, 2**64 - 1][rng.integers(9)])
+        elif kind == 2:
+            p = p[: rng.integers(0, n)]
+        elif kind == 3:
+            a = int(rng.integers(22, n))
+            p[a: a + int(rng.integers(1, 64))] = np.uint64(2**64 - 1)
+        elif kind == 4:  # move a word between two length fields: the sum stays, the cut points move
+            q = 16 + int(rng.integers(0, 4))
+            d = np.uint64(rng.integers(1, 50))
+            p[q], p[q + 1] = p[q] - d, p[q + 1] + d
+        else:
+            a, b_ = sorted(int(x) for x in rng.integers(22, n, size=2))
+            p[a:b_] = rng.integers(0, 2**63, size=b_ - a, dtype=np.uint64)
+        if p.size == n and (p == hr).all():
+            continue
+        assert hr_verify(p) != 0, f"mutation kind {kind} of the header_range blob was ACCEPTED"
+        total += 1
+        rejected += 1
     print(f"fuzz: {total} inputs, {rejected} mutated proofs rejected, no sanitizer report")
 
 
