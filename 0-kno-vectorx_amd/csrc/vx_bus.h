@@ -58,3 +58,15 @@ int32_t vx_justification_expect(const uint64_t* ppub_chain, size_t n_chain, cons
                                 uint64_t authority_set_id, const uint8_t block_hash[32], uint32_t block_number, uint64_t round, uint64_t spub[10], uint64_t epub[2],
                                 uint64_t hpub[15], int air[3], char* err, size_t errlen);
 void vx_shared_challenges_host(const uint64_t* const* pubs, const size_t* n_pubs, const uint64_t* const* caps, size_t k, size_t cap_words, uint64_t* out, size_t n_out);
+
+// ---- rotate blob (written by vx_rotate_prove in vx_rotate.hip, read by vx_rotate_verify in vx_verify.hip)
+static const uint64_t VX_ROT_MAGIC = 0x3354415458525856ULL;  // "VXRXTAT3"
+// magic, set id, block, n_new, header hash (4), set hash (4), new set hash (4), proof lengths: header hash, current-set commitment,
+// new-set commitment, Ed25519; parent hash (4); SHA-512 proof length, the precommit's round, start_position, epoch-end proof length
+static constexpr size_t VX_ROT_HDR = 28;
+
+static constexpr uint32_t VX_MAX_HEADER_SIZE = 35840;  // consts.rs:16
+static inline void be_limbs(const uint8_t h[32], uint64_t out[8]) {
+    for (int j = 0; j < 8; ++j)
+        out[j] = ((uint64_t)h[4 * j] << 24) | ((uint64_t)h[4 * j + 1] << 16) | ((uint64_t)h[4 * j + 2] << 8) | h[4 * j + 3];
+}

@@ -69,11 +69,6 @@ __global__ __launch_bounds__(64) void k_epoch_end_check(const uint8_t* __restric
     if (t + 1 == num_authorities && (v[40] | v[41] | v[42] | v[43]) != 0) return fail(EE_DELAY, t);  // :267-274
 }
 
-const uint64_t VX_ROT_MAGIC = 0x3354415458525856ULL;  // "VXRXTAT3"
-// magic, set id, block, n_new, header hash (4), set hash (4), new set hash (4), proof lengths: header hash, current-set commitment,
-// new-set commitment, Ed25519; parent hash (4); SHA-512 proof length, the precommit's round, start_position, epoch-end proof length
-constexpr size_t VX_ROT_HDR = 28;
-
 int sha_rows_log(size_t n_keys) {
     int log_n = 6;
     while (((size_t)1 << log_n) < 64 * (2 * n_keys - 1)) ++log_n;
@@ -85,10 +80,6 @@ int blake_rows_log(size_t chunks) {
     return log_n;
 }
 
-void be_limbs(const uint8_t h[32], uint64_t out[8]) {
-    for (int j = 0; j < 8; ++j)
-        out[j] = ((uint64_t)h[4 * j] << 24) | ((uint64_t)h[4 * j + 1] << 16) | ((uint64_t)h[4 * j + 2] << 8) | h[4 * j + 3];
-}
 
 }  // namespace
 
@@ -306,104 +297,6 @@ int32_t vx_rotate_prove(vx_ctx* ctx, const vx_buf* header, uint32_t header_size,
     proof_out[25] = round;
     proof_out[26] = start_position;
     proof_out[27] = len_ep;
-    return VX_OK;
-}
-
-// RotateCircuit verify: the blob must be for this (authority_set_id, authority_set_hash) request and claim out32;
-// then the three STARKs are verified against the public inputs those values imply.
-int32_t vx_rotate_verify(const vx_stark_config* cfg, const uint64_t* blob, size_t len, uint64_t authority_set_id,
-                         const uint8_t authority_set_hash[32], const uint8_t out32[32], char* err, size_t errlen) {
-    if (!cfg || !blob || !authority_set_hash || !out32) return VX_ERR_ARG;
-    auto bad = [&](const char* why) {
-        if (err && errlen) snprintf(err, errlen, "%s", why);
-        return (int32_t)VX_ERR_STATEMENT;
-    };
-    if (len <= VX_ROT_HDR || blob[0] != VX_ROT_MAGIC) return bad("bad rotate blob");
-    if (blob[1] != authority_set_id || memcmp(blob + 8, authority_set_hash, 32) != 0) return bad("blob is for a different request");
-    if (memcmp(blob + 12, out32, 32) != 0) return bad("public output differs from the blob");
-    const size_t l0 = blob[16], l1 = blob[17], l2 = blob[18], l3 = blob[19], l4 = blob[24], l5 = blob[27];
-    if (l0 > len || l1 > len || l2 > len || l3 > len || l4 > len || l5 > len || VX_ROT_HDR + l0 + l1 + l2 + l3 + l4 + l5 != len) return bad("blob lengths are inconsistent");
-    if (blob[2] >> 32 || blob[26] >= MAX_HEADER_SIZE || blob[3] == 0 || blob[3] > 510) return bad("block number, start position or authority count out of range");
-    const uint64_t* p0 = blob + VX_ROT_HDR;
-    int32_t rc;
-    // Bus B: the Blake2b table (a chain of exactly one header, numbered epoch_end_block, hashing to the blob's header hash; the anchor
-    // is the parent hash the header itself carries -- free in this statement) sends the bytes from start_position + 1 on; the
-    // epoch-end table reads the ScheduledChange log of blob[3] authorities there and sends its keys; the new set's commitment table
-    // receives every key and hashes to out32.
-    {
-        const uint64_t* proof[3] = {p0, p0 + l0 + l1 + l2 + l3 + l4, p0 + l0 + l1};
-        const size_t pl[3] = {l0, l5, l2};
-        const int air[3] = {VX_AIR_BLAKE_CHAIN, VX_AIR_EPOCH_END, VX_AIR_SHA_CHAIN};
-        const uint64_t *ppub[3], *pcap[3];
-        size_t npub[3];
-        for (int t = 0; t < 3; ++t)
-            if (!vx_stark_proof_peek(proof[t], pl[t], cfg->cap_height, &ppub[t], &npub[t], &pcap[t])) return bad("epoch-end proofs are too short to hold a trace cap");
-        uint64_t bpub[20], epub[10], spub[10];
-        for (int j = 0; j < 8; ++j) {
-            uint32_t a, b;
-            memcpy(&a, (const uint8_t*)(blob + 20) + 4 * j, 4);
-            memcpy(&b, (const uint8_t*)(blob + 4) + 4 * j, 4);
-            bpub[j] = a;
-            bpub[8 + j] = b;
-        }
-        bpub[16] = bpub[17] = blob[2];
-        bpub[18] = blob[26] + 1, bpub[19] = 2;  // window mode: the bytes behind start_position
-        // the byte lengths of the log's two compact ints are the prover's to state (one-hot); the table's constraints tie them to the bytes
-        if (npub[1] != 10) return bad("epoch-end proof is malformed");
-        epub[0] = blob[3], epub[1] = 1;
-        for (int g = 0; g < 2; ++g) {
-            uint64_t sum = 0;
-            for (int a = 0; a < 4; ++a) {
-                const uint64_t f = ppub[1][2 + 4 * g + a];
-                if (f > 1) return bad("epoch-end proof: length flags are not one-hot");
-                epub[2 + 4 * g + a] = f, sum += f;
-            }
-            if (sum != 1) return bad("epoch-end proof: length flags are not one-hot");
-        }
-        be_limbs(out32, spub);
-        spub[8] = blob[3], spub[9] = 2;  // receives every key
-        uint64_t chal[4];
-        vx_shared_challenges_host(ppub, npub, pcap, 3, (size_t)4 << cfg->cap_height, chal, 4);
-        const uint64_t* want[3] = {bpub, epub, spub};
-        const size_t n_want[3] = {20, 10, 10};
-        uint64_t bus[2] = {0, 0};
-        for (int t = 0; t < 3; ++t) {
-            const uint64_t* apub = nullptr;
-            int L = 0;
-            rc = vx_stark_verify_ext(cfg, proof[t], pl[t], air[t], want[t], n_want[t], chal, &apub, &L, err, errlen);
-            if (rc != VX_OK) return rc;
-            for (int q = 0; q < 2; ++q) bus[q] = glh::add(bus[q], glh::mul(apub[q], ((uint64_t)1 << L) % glh::P));
-        }
-        if (bus[0] || bus[1]) return bad("the lookup bus between the header hash, the epoch-end table and the new set does not balance");
-    }
-    // the justification by the current set: commitment, Ed25519 and SHA-512 tables under shared lookup challenges; the signed
-    // message is the precommit for (the proven header hash, the block number, the round, the request's set id)
-    {
-        const uint64_t* proof[3] = {p0 + l0, p0 + l0 + l1 + l2, p0 + l0 + l1 + l2 + l3};
-        const size_t pl[3] = {l1, l3, l4};
-        const uint64_t *ppub[3], *pcap[3];
-        size_t npub[3];
-        for (int t = 0; t < 3; ++t)
-            if (!vx_stark_proof_peek(proof[t], pl[t], cfg->cap_height, &ppub[t], &npub[t], &pcap[t])) return bad("justification proofs are too short to hold a trace cap");
-        uint64_t spub[10], epub[2], hpub[15];
-        int air[3];
-        rc = vx_justification_expect(ppub[0], npub[0], ppub[1], npub[1], npub[2], authority_set_hash, authority_set_id, (const uint8_t*)(blob + 4), (uint32_t)blob[2], blob[25],
-                                     spub, epub, hpub, air, err, errlen);
-        if (rc != VX_OK) return rc;
-        uint64_t chal[4];
-        vx_shared_challenges_host(ppub, npub, pcap, 3, (size_t)4 << cfg->cap_height, chal, 4);
-        const uint64_t* want[3] = {spub, epub, hpub};
-        const size_t n_want[3] = {10, 2, 15};
-        uint64_t bus[2] = {0, 0};
-        for (int t = 0; t < 3; ++t) {
-            const uint64_t* apub = nullptr;
-            int L = 0;
-            rc = vx_stark_verify_ext(cfg, proof[t], pl[t], air[t], want[t], n_want[t], chal, &apub, &L, err, errlen);
-            if (rc != VX_OK) return rc;
-            for (int q = 0; q < 2; ++q) bus[q] = glh::add(bus[q], glh::mul(apub[q], ((uint64_t)1 << L) % glh::P));
-        }
-        if (bus[0] || bus[1]) return bad("the lookup bus between the justification tables does not balance");
-    }
     return VX_OK;
 }
 

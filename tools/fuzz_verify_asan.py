@@ -2,7 +2,7 @@
 """Mutation fuzzing of the HOST verifier under AddressSanitizer + UBSan (CPU only; the verifier takes untrusted proofs).
 
 Builds vx_verify.hip host-only with -fsanitize=address,undefined, loads it in a child interpreter started with the sanitizer runtime
-preloaded, and feeds vx_stark_verify / vx_header_range_verify mutated proofs: seeds are real proofs of the small AIRs made by the CPU
+preloaded, and feeds vx_stark_verify / vx_header_range_verify / vx_rotate_verify mutated proofs: seeds are real proofs of the small AIRs made by the CPU
 reference prover (oracle/stark_ref.py -- test infrastructure, used here to make inputs only).  Mutations: word flips, random words,
 truncation, extension, the degree-bits / length fields set to every small value, header words of a range blob set to extremes.
 Any sanitizer report aborts the child: the script fails.  Every mutated proof must also be REJECTED (a flipped word that is accepted
@@ -17,7 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = "/tmp/libvxverify_asan.so"
-SRC = os.path.join(ROOT, "0-kno-vectorx_amd", "csrc", "vx_verify.hip")
+SRC = os.path.join(ROOT, "0-kno-vectorx_amd", "csrc", "vx_verify.hip")  # every host verifier, no GPU code
 
 
 def build():
@@ -141,6 +141,41 @@ def child(iters):
         if p.size == n and (p == hr).all():
             continue
         assert hr_verify(p) != 0, f"mutation kind {kind} of the header_range blob was ACCEPTED"
+        total += 1
+        rejected += 1
+    # ... and the rotate blob (six proofs, two buses) through vx_rotate_verify
+    L.vx_rotate_verify.argtypes = [C.POINTER(StarkConfig), vp, sz, C.c_uint64, vp, vp, C.c_char_p, sz]
+    L.vx_rotate_verify.restype = C.c_int32
+    rot = np.ascontiguousarray(z["rot_blob"], dtype=np.uint64)
+    o32, rsh, rid = np.ascontiguousarray(z["rot_out32"]), np.ascontiguousarray(z["rot_set_hash"]), int(z["rot_set_id"])
+
+    def rot_verify(b):
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        return L.vx_rotate_verify(C.byref(cfg2), b.ctypes.data_as(vp), b.size, rid, rsh.ctypes.data_as(vp), o32.ctypes.data_as(vp), err, 256)
+
+    assert rot_verify(rot) == 0, err.value
+    n = rot.size
+    for it in range(max(iters // 4, 50)):
+        p = rot.copy()
+        kind = it % 5
+        if kind == 0:
+            p[rng.integers(n)] ^= np.uint64(1) << np.uint64(rng.integers(64))
+        elif kind == 1:
+            p[rng.integers(0, 28)] = np.uint64([0, 1, 27, 28, n, n - 28, 510, 511, 35840, 2**32, 2**63, 2**64 - 1][rng.integers(12)])
+        elif kind == 2:
+            p = p[: rng.integers(0, n)]
+        elif kind == 3:
+            q = [16, 17, 18, 19, 24, 27][int(rng.integers(0, 6))]
+            q2 = [16, 17, 18, 19, 24, 27][int(rng.integers(0, 6))]
+            d = np.uint64(rng.integers(1, 50))
+            if q != q2:
+                p[q], p[q2] = p[q] - d, p[q2] + d
+        else:
+            a, b_ = sorted(int(x) for x in rng.integers(28, n, size=2))
+            p[a:b_] = rng.integers(0, 2**63, size=b_ - a, dtype=np.uint64)
+        if p.size == n and (p == rot).all():
+            continue
+        assert rot_verify(p) != 0, f"mutation kind {kind} of the rotate blob was ACCEPTED"
         total += 1
         rejected += 1
     print(f"fuzz: {total} inputs, {rejected} mutated proofs rejected, no sanitizer report")
