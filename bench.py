@@ -143,7 +143,7 @@ def ntt_roofline(ctx, iters=10):
                            "HBM traffic is 2.0x algorithmic with no re-reads, so fewer instructions per butterfly, not fewer bytes, would raise the fraction",
                    "source": "profiles/r02_pmc_valu_by_kernel.json (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, rocprofv3 --pmc)"}
     return {
-        "bound": "hbm", "alu_bound_evidence": alu, "kernel": "k_ntt_tile", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "bound": "hbm", "alu_bound_evidence": alu, "kernel": "k_ntt_tile<0, 0>", "rocprof_stats": "profiles/r02_ntt_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this shape: 3.10 ms average per launch)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "per": f"one forward NTT of 2^{NTT_LOG_N} x {NTT_COLS} columns = {launches} launches, {alg_bytes / 1e9:.3f} GB algorithmic (16*n*c)",
         "ms_per_transform": round(ms, 4), "ms_per_launch": round(ms / launches, 4), "ms_per_transform_groups": [round(g, 4) for g in groups],
