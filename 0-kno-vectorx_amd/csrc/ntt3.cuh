@@ -1,0 +1,284 @@
+// k_ntt3<MODE, INV, LR>: the tile pass of vx_ntt.hip with the tile SHAPE fixed at compile time.
+//
+// A pass works on 4096-element tiles of 2^LR rows x 2^(12-LR) contiguous columns (rows strided by m = 2^log_m elements),
+// 16 elements per lane of a 256-thread block, radix-16 rounds in registers, padded LDS exchanges in between -- as
+// k_ntt_tile (the run-time-shape kernel it replaces for LR in {4..8, 12}).  What is new:
+//   * every address is  (uniform scalar base, per element) + (per-lane offset, computed ONCE per block): the element index
+//     of register e in layout F is  lane_part(tid) | e << F  with disjoint bit fields, so row / column / padded LDS slot /
+//     bit-reversed row are all sums of a lane term and a compile-time element term.  The run-time-shape kernel spent
+//     ~8 VALU instructions of 64-bit index arithmetic per element and access (40 % of its instruction stream);
+//   * the round twiddle index of register e is  R(tid) * bitrev4(e)  with R fixed per lane;
+//   * the table of w_(2^LR) has 2^(LR-1) entries (64 for the 7-stage pass), which leaves LDS room to stage the two-level
+//     table of the between-pass twiddle (w_S^(c * bitrev(r)), S = 2^log_sub) instead of gathering it from L2;
+//   * round arithmetic stays in [0, 2^64) + a carry word between reductions (gl96 below).
+// Layout names: F = 8 / 4 / 0 is the bit position of the 4-bit register window inside the 12-bit tile index.
+#pragma once
+#include <utility>
+
+#include "gl.cuh"
+
+namespace n3 {
+
+template <int F>
+__device__ __forceinline__ int lane_part(int tid) {
+    return (tid & ((1 << F) - 1)) | ((tid >> F) << (F + 4));
+}
+__host__ __device__ constexpr int pad(int i) { return i + (i >> 4); }
+__host__ __device__ constexpr int brev_c(int x, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+template <int LR>
+struct Shape {
+    static_assert(LR >= 4 && LR <= 12, "k_ntt3 needs 4 <= log_rows <= 12");
+    static constexpr int LT = 12 - LR, T = 1 << LT;
+    static constexpr int NR = (LR + 3) / 4;
+    static constexpr int QA = 4, QB = LR > 4 ? (LR - 4 < 4 ? LR - 4 : 4) : 0, QC = LR > 8 ? LR - 8 : 0;
+    static constexpr int WN = LR >= 5 ? 1 << (LR - 1) : 0;  // entries of the staged w_(2^LR) half table
+    // layout the DIF pass ends in / the DIT pass starts from when there is no closing exchange
+    static constexpr int F_EDGE = NR == 1 ? 8 : (NR == 2 ? 4 : 8);
+};
+
+// ---- global addressing: element e of layout F sits at  base + e_off<F>(e) + lane_off<F>(tid)
+template <int F, int LT>
+__device__ __forceinline__ uint32_t lane_off(int tid, int log_m) {  // in BYTES (a column is below 4 GB: log_n <= 28)
+    const int lp = lane_part<F>(tid);
+    return (((uint32_t)(lp >> LT) << log_m) + (uint32_t)(lp & ((1 << LT) - 1))) << 3;
+}
+__device__ __forceinline__ uint64_t ld_at(const uint64_t* p, uint32_t byte_off) { return *(const uint64_t*)((const char*)p + byte_off); }
+__device__ __forceinline__ void st_at(uint64_t* p, uint32_t byte_off, uint64_t v) { *(uint64_t*)((char*)p + byte_off) = v; }
+template <int F, int LT>
+__device__ __forceinline__ size_t e_off(int e, int log_m) {  // uniform
+    const int ep = e << F;
+    return ((size_t)(ep >> LT) << log_m) + (size_t)(ep & ((1 << LT) - 1));
+}
+
+}  // namespace n3
+
+// ---------------------------------------------------------------------------------------------------------------
+// The kernel.  Included by vx_ntt.hip after PassArgs and tab3_pow.
+#include "gl96.h"
+
+#ifndef VX_NTT3_TPB
+#define VX_NTT3_TPB 4
+#endif
+
+namespace n3 {
+
+template <int F>
+__device__ __forceinline__ void exch_write(const uint64_t* y, uint64_t* lds, int slot) {  // slot = pad(lane_part<F>(tid))
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lds[slot + pad(e << F)] = y[e];
+}
+template <int F>
+__device__ __forceinline__ void exch_read(uint64_t* y, const uint64_t* lds, int slot) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) y[e] = lds[slot + pad(e << F)];
+}
+__device__ __forceinline__ void widen(gl96::X* x, const uint64_t* y) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = gl96::from64(y[e]);
+}
+// 16 lazy values -> 64-bit representatives in [0, 2^64).  The fast form (two 32-bit additions per value) is exact unless a
+// half of some value sits within FOLD_K of a wrap point; the whole wave then takes the exact form (test vectors of all
+// p - 1 / 2^32 - 1 words do that on purpose).
+__device__ __forceinline__ void fold16(uint64_t* y, const gl96::X* x) {
+    uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) m = gl96::fold_margin(m, x[e]);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!gl96::fold_ok(m)) != 0, 0)) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) y[e] = gl96::fold_exact(x[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) y[e] = gl96::fold_fast(x[e]);
+    }
+}
+// representatives in [0, 2^64) -> canonical: a value >= p has an all-ones high word (probability 2^-32 on random data)
+__device__ __forceinline__ void canon16(uint64_t* y) {
+    uint32_t mx = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const uint32_t h = (uint32_t)(y[e] >> 32);
+        mx = mx > h ? mx : h;
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx == 0xFFFFFFFFu) != 0, 0)) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) y[e] = gl_canon(y[e]);
+    }
+}
+// y[e] *= w[e - 1]  (e >= 1); any representatives in, [0, 2^64) out
+__device__ __forceinline__ void mul15(uint64_t* y, const uint64_t* w) {
+#pragma unroll
+    for (int e = 1; e < 16; ++e) y[e] = gl_mul_nc(y[e], w[e - 1]);
+}
+
+}  // namespace n3
+
+template <int MODE, int INV, int LR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_ntt3(PassArgs a) {
+    using S = n3::Shape<LR>;
+    constexpr int LT = S::LT, NR = S::NR;
+    constexpr int T2N = LR <= 8 ? 2048 : 0;            // staged two-level table of the between-pass twiddle
+    constexpr int WBN = LR > 8 ? 256 : 0;               // staged w_256^j (all of them: no sign fix-up) for the second round twiddle
+    constexpr int FE = S::F_EDGE;                       // layout of the strided side: DIF stores from it, DIT loads into it
+    __shared__ __attribute__((aligned(16))) uint64_t lds[4096 + 256 + (WBN ? WBN : 1) + (T2N ? T2N : 1)];
+    uint64_t* const wsB = lds + 4096 + 256;
+    uint64_t* const t2s = wsB + (WBN ? WBN : 1);
+    const int tid = threadIdx.x;
+    const int log_m = a.log_sub - LR;
+    const bool strided = log_m > 0;                     // m > 1: this pass carries the between-pass twiddle
+    const bool t2_lds = T2N && strided && a.tw2_total <= (unsigned)T2N;
+    if (WBN) wsB[tid] = tid < 128 ? a.w12[tid << 4] : GL_P - a.w12[(tid - 128) << 4];
+    if (T2N && t2_lds)
+        for (unsigned j = tid; j < a.tw2_total; j += 256) t2s[j] = a.tw2_lo[j];
+
+    // round-A twiddles of this lane, w_(2^LR)^(R bitrev4(e)) with R = rho mod 2^(LR-4) = tid >> LT in layout 8: the same for
+    // every tile, so they live in registers (the sign of the upper half circle is folded in here, once)
+    uint64_t wA[15];
+    if (LR > 4) {
+        const int RA = tid >> LT;
+#pragma unroll
+        for (int e = 1; e < 16; ++e) {
+            const int idx = (RA * n3::brev_c(e, 4)) << (12 - LR);   // exponent of w_4096, below 4096
+            const uint64_t w = a.w12[idx & 2047];
+            wA[e - 1] = (idx & 2048) ? GL_P - w : w;
+        }
+    }
+    if (WBN || T2N) __syncthreads();
+
+    const uint64_t* src = a.src + blockIdx.y * a.src_col_stride;
+    uint64_t* dst = a.dst + blockIdx.y * a.dst_col_stride;
+    const int log_tps = a.log_sub - 12;                 // tiles per sub-array
+    const size_t tile0 = (size_t)blockIdx.x * VX_NTT3_TPB;
+    const int n_here = (int)(a.n_tiles - tile0 < (size_t)VX_NTT3_TPB ? a.n_tiles - tile0 : (size_t)VX_NTT3_TPB);
+
+    // per-lane terms, fixed for the block
+    const int s8 = n3::pad(n3::lane_part<8>(tid)), s4 = n3::pad(n3::lane_part<4>(tid)), s0 = n3::pad(n3::lane_part<0>(tid));
+    const uint32_t off8 = n3::lane_off<8, LT>(tid, log_m), offE = n3::lane_off<FE, LT>(tid, log_m);
+    const int RB = LR > 8 ? ((tid & 15) >> LT) : 0;     // rho mod 2^(LR-8) in layout 4; exponent of w_256 is RB * bitrev4(e) << (12 - LR)
+    auto twiddle_b = [&](uint64_t* y) {
+#pragma unroll
+        for (int e = 1; e < 16; ++e) y[e] = gl_mul_nc(y[e], wsB[((RB * n3::brev_c(e, 4)) << (LR > 8 ? 12 - LR : 0)) & 255]);
+    };
+    // between-pass twiddle on the strided side (layout FE): exponent (col0 + tau) * bitrev_LR(rho), both sums of a lane and an element term
+    const int lpE = n3::lane_part<FE>(tid);
+    const uint32_t tauE = lpE & ((1 << LT) - 1), brE = __brev((unsigned)(lpE >> LT)) >> (32 - LR);
+    const uint32_t t2_mask = ((uint32_t)1 << a.tw2_bits) - 1;
+    auto ip_twiddle = [&](uint32_t col0, int e) -> uint64_t {
+        const int ep = e << FE;
+        const uint32_t ex = (col0 + tauE + (uint32_t)(ep & ((1 << LT) - 1))) * (brE + (uint32_t)n3::brev_c(ep >> LT, LR));
+        if (T2N && t2_lds) return gl_mul_nc(t2s[(t2_mask + 1) + (ex >> a.tw2_bits)], t2s[ex & t2_mask]);
+        return gl_mul_nc(a.tw2_hi[ex >> a.tw2_bits], a.tw2_lo[ex & t2_mask]);
+    };
+
+    gl96::X x[16];
+    uint64_t y[16];
+#pragma unroll 1
+    for (int t = 0; t < n_here; ++t) {
+        const size_t tile = tile0 + t;
+        const size_t sub = tile >> log_tps;
+        const uint32_t col0 = (uint32_t)(tile - (sub << log_tps)) << LT;
+        const size_t base = (sub << a.log_sub) + col0;
+        if (MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x[e] = gl96::from64(n3::ld_at(src + base + n3::e_off<8, LT>(e, log_m), off8));
+            gl96::dif_round<4, INV>(x);
+            n3::fold16(y, x);
+            if (LR > 4) n3::mul15(y, wA);
+            if (NR >= 2) {
+                __syncthreads();
+                n3::exch_write<8>(y, lds, s8);
+                __syncthreads();
+                n3::exch_read<4>(y, lds, s4);
+                n3::widen(x, y);
+                gl96::dif_round<S::QB ? S::QB : 1, INV>(x);
+                n3::fold16(y, x);
+                if (LR > 8) twiddle_b(y);
+            }
+            if (NR == 3) {
+                __syncthreads();
+                n3::exch_write<4>(y, lds, s4);
+                __syncthreads();
+                n3::exch_read<0>(y, lds, s0);
+                n3::widen(x, y);
+                gl96::dif_round<S::QC ? S::QC : 1, INV>(x);
+                n3::fold16(y, x);
+                __syncthreads();
+                n3::exch_write<0>(y, lds, s0);
+                __syncthreads();
+                n3::exch_read<8>(y, lds, s8);
+            }
+            if (strided) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) y[e] = gl_mul_nc(y[e], ip_twiddle(col0, e));
+            }
+            if (a.scale > 1) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) y[e] = gl_mul_nc(y[e], a.scale);
+            }
+            n3::canon16(y);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) n3::st_at(dst + base + n3::e_off<FE, LT>(e, log_m), offE, y[e]);
+        } else {
+            if (a.expand_bits) {  // first pass of an LDE (contiguous tile): zero padding + coset scaling on the fly
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const size_t g = base + (size_t)(n3::lane_part<FE>(tid) | (e << FE));
+                    uint64_t v = 0;
+                    if ((g & (((size_t)1 << a.expand_bits) - 1)) == 0) {
+                        v = src[g >> a.expand_bits];
+                        if (a.shift_tab) v = gl_mul_nc(v, tab3_pow(a.shift_tab, brev32((uint32_t)(g >> a.expand_bits), a.log_coeff)));
+                    }
+                    y[e] = v;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) y[e] = n3::ld_at(src + base + n3::e_off<FE, LT>(e, log_m), offE);
+                if (a.shift_tab && !strided) {  // plain coset transform, first pass: c_k *= shift^k
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const size_t g = base + (size_t)(n3::lane_part<FE>(tid) | (e << FE));
+                        y[e] = gl_mul_nc(y[e], tab3_pow(a.shift_tab, brev32((uint32_t)g, a.log_coeff)));
+                    }
+                }
+                if (strided) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) y[e] = gl_mul_nc(y[e], ip_twiddle(col0, e));
+                }
+            }
+            if (NR == 3) {
+                __syncthreads();
+                n3::exch_write<8>(y, lds, s8);
+                __syncthreads();
+                n3::exch_read<0>(y, lds, s0);
+                n3::widen(x, y);
+                gl96::dit_round<S::QC ? S::QC : 1, INV>(x);
+                n3::fold16(y, x);
+                __syncthreads();
+                n3::exch_write<0>(y, lds, s0);
+                __syncthreads();
+                n3::exch_read<4>(y, lds, s4);
+            }
+            if (NR >= 2) {
+                if (LR > 8) twiddle_b(y);
+                n3::widen(x, y);
+                gl96::dit_round<S::QB ? S::QB : 1, INV>(x);
+                n3::fold16(y, x);
+                __syncthreads();
+                n3::exch_write<4>(y, lds, s4);
+                __syncthreads();
+                n3::exch_read<8>(y, lds, s8);
+            }
+            if (LR > 4) n3::mul15(y, wA);
+            n3::widen(x, y);
+            gl96::dit_round<4, INV>(x);
+            n3::fold16(y, x);
+            n3::canon16(y);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) n3::st_at(dst + base + n3::e_off<8, LT>(e, log_m), off8, y[e]);
+        }
+    }
+}

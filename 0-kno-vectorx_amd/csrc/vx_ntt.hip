@@ -39,6 +39,7 @@ struct PassArgs {
     const uint64_t* tw2_lo;     // two-level table of w_{2^log_sub}: lo[j] = w^j, hi[j] = w^(j << tw2_bits)
     const uint64_t* tw2_hi;
     int tw2_bits;
+    unsigned tw2_total;  // entries of lo | hi back to back (k_ntt3 stages them in LDS when they fit)
     size_t n_tiles;  // tiles per column in this pass (a block takes NTT_TPB consecutive ones)
     int dbg_skip;  // timing experiments only (VX_NTT_SKIP bit mask): 1 = tile twiddles, 2 = inter-pass twiddle, 4 = butterflies
 };
@@ -419,6 +420,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     }
 }
 
+#include "ntt3.cuh"
+
 // out[i] = in[bitrev(i)] (per column); in != out
 __global__ void k_bitrev_copy(const uint64_t* in, uint64_t* out, int log_n, size_t in_stride, size_t out_stride) {
     size_t n = (size_t)1 << log_n;
@@ -462,6 +465,12 @@ static inline size_t lds_bytes(int lr, int lT) {
     return ((size_t)1 << lr) * (T > 1 ? T + 1 : 1) * 8;
 }
 static bool g_ntt_v1 = getenv("VX_NTT_V1") != nullptr;  // debugging aid: force the LDS-stage kernel
+static bool g_ntt_v2 = getenv("VX_NTT_V2") != nullptr;  // A/B aid: the run-time-shape tile kernel instead of k_ntt3
+template <int MODE, int LR>
+static void launch_ntt3(vx_ctx* ctx, const PassArgs& a, unsigned gx, size_t n_cols, int inverse) {
+    if (inverse) hipLaunchKernelGGL((k_ntt3<MODE, 1, LR>), dim3(gx, (unsigned)n_cols), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_ntt3<MODE, 0, LR>), dim3(gx, (unsigned)n_cols), dim3(256), 0, ctx->stream, a);
+}
 static int g_ntt_skip = getenv("VX_NTT_SKIP") ? atoi(getenv("VX_NTT_SKIP")) : 0;  // timing experiments (wrong results!)
 // VX_NTT_GROUP=G: run ALL passes of a transform over G columns before moving to the next G (a group of 32 columns of 2^19 is
 // 128 MB: the second pass would find in the 256 MB Infinity Cache what the first just wrote).  0 = every pass over all columns.
@@ -470,6 +479,20 @@ template <int MODE>
 static int32_t launch_pass(vx_ctx* ctx, PassArgs& a, int log_n, size_t n_cols, int inverse) {
     size_t tiles = (size_t)1 << (log_n - a.log_rows - a.log_T);
     a.dbg_skip = g_ntt_skip;
+    if (a.log_rows + a.log_T == 12 && !g_ntt_v1 && !g_ntt_v2 && (a.log_rows == 12 || (a.log_rows >= 4 && a.log_rows <= 8))) {
+        a.n_tiles = tiles;
+        const unsigned gx = (unsigned)((tiles + VX_NTT3_TPB - 1) / VX_NTT3_TPB);
+        switch (a.log_rows) {
+        case 4: launch_ntt3<MODE, 4>(ctx, a, gx, n_cols, inverse); break;
+        case 5: launch_ntt3<MODE, 5>(ctx, a, gx, n_cols, inverse); break;
+        case 6: launch_ntt3<MODE, 6>(ctx, a, gx, n_cols, inverse); break;
+        case 7: launch_ntt3<MODE, 7>(ctx, a, gx, n_cols, inverse); break;
+        case 8: launch_ntt3<MODE, 8>(ctx, a, gx, n_cols, inverse); break;
+        default: launch_ntt3<MODE, 12>(ctx, a, gx, n_cols, inverse); break;
+        }
+        VX_HIP(hipGetLastError());
+        return VX_OK;
+    }
     if (a.log_rows + a.log_T == 12 && !g_ntt_v1) {
         a.n_tiles = tiles;
         const unsigned gx = (unsigned)((tiles + NTT_TPB - 1) / NTT_TPB);
@@ -511,7 +534,7 @@ static int32_t ntt_dif(vx_ctx* ctx, const uint64_t* src, size_t src_stride, uint
         {
             Tw2 t2;
             VX_TRY(vx_get_tw2(ctx, ls, inverse, &t2));
-            a.tw2_lo = t2.lo, a.tw2_hi = t2.hi, a.tw2_bits = t2.lo_bits;
+            a.tw2_lo = t2.lo, a.tw2_hi = t2.hi, a.tw2_bits = t2.lo_bits, a.tw2_total = ((unsigned)1 << t2.lo_bits) + ((unsigned)1 << (ls - t2.lo_bits));
         }
         VX_TRY(launch_pass<0>(ctx, a, L, n_cols, inverse));
         a.src = dst;
@@ -563,7 +586,7 @@ static int32_t ntt_dit(vx_ctx* ctx, const uint64_t* src, size_t src_stride, uint
         {
             Tw2 t2;
             VX_TRY(vx_get_tw2(ctx, ls, inverse, &t2));
-            a.tw2_lo = t2.lo, a.tw2_hi = t2.hi, a.tw2_bits = t2.lo_bits;
+            a.tw2_lo = t2.lo, a.tw2_hi = t2.hi, a.tw2_bits = t2.lo_bits, a.tw2_total = ((unsigned)1 << t2.lo_bits) + ((unsigned)1 << (ls - t2.lo_bits));
         }
         VX_TRY(launch_pass<1>(ctx, a, L, n_cols, inverse));
     }

@@ -163,3 +163,59 @@ def test_large_ntt_properties(ctx, rng):
         tot = (tot + int(np.sum(chunk.astype(object)))) % P
     ctx.ntt(a, log_n, cols)
     assert int(a.download(1)[0]) == tot
+
+
+def _special_columns(rng, n):
+    """Columns that drive the lazy butterfly arithmetic to its corners: all p-1, alternating extremes, a delta at every
+    power-of-two stride, words whose halves are all ones, and a random draw from a set of special values."""
+    S = np.array([0, 1, 2, P - 1, P - 2, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, P - (1 << 32), P - (1 << 32) + 1, 1 << 63, (1 << 63) - 1,
+                  0xFFFFFFFF00000000, 0xFFFFFFFE00000002, 0x00000001FFFFFFFF, 0x8000000080000000, 0x7FFFFFFF7FFFFFFF, 0xFFFFFFFEFFFFFFFF], dtype=np.uint64)
+    cols = [np.full(n, P - 1, dtype=np.uint64)]
+    alt = np.full(n, P - 1, dtype=np.uint64)
+    alt[1::2] = 0
+    cols.append(alt)
+    alt2 = np.full(n, 0xFFFFFFFF00000000, dtype=np.uint64)
+    alt2[::3] = P - (1 << 32) + 1
+    cols.append(alt2)
+    d = np.zeros(n, dtype=np.uint64)
+    d[[0] + [1 << k for k in range(n.bit_length() - 1)]] = P - 1
+    cols.append(d)
+    cols.append(S[rng.integers(0, S.size, size=n)])
+    cols.append(rand_field(rng, n))
+    return np.stack(cols)
+
+
+# every tile shape the planner produces: log_n = 12 + rows of the strided pass (k_ntt3 for 4..8 rows bits, the run-time-shape
+# kernel below that), 21 / 22 = three passes
+@pytest.mark.parametrize("log_n", [12, 13, 15, 16, 17, 18, 19, 20, 21, 22])
+def test_ntt_tile_shapes_special_values(ctx, oracle, rng, log_n):
+    n = 1 << log_n
+    x = _special_columns(rng, n)
+    cols = x.shape[0]
+    want = oracle.ntt(x)
+    perm = bitrev_perm(log_n)
+    buf = ctx.from_host(x)
+    ctx.ntt(buf, log_n, cols, order=1)  # DIF plan, bit-reversed output
+    got = buf.download().reshape(cols, n)
+    assert (got < np.uint64(P)).all()
+    assert (got[:, perm] == want).all()
+    ctx.ntt(buf, log_n, cols, inverse=True, order=1)  # DIT plan back
+    assert (buf.download().reshape(cols, n) == x).all()
+    buf = ctx.from_host(x)
+    ctx.ntt(buf, log_n, cols)  # natural -> natural (DIT plan, forward)
+    assert (buf.download().reshape(cols, n) == want).all()
+    ctx.ntt(buf, log_n, cols, inverse=True)  # DIF plan, inverse, with the 1/n scale
+    assert (buf.download().reshape(cols, n) == x).all()
+
+
+@pytest.mark.parametrize("log_n,rate_bits", [(15, 1), (16, 1), (18, 1), (19, 1), (17, 3)])
+def test_lde_tile_shapes_special_values(ctx, oracle, rng, log_n, rate_bits):
+    n, N = 1 << log_n, 1 << (log_n + rate_bits)
+    vals = _special_columns(rng, n)[[0, 2, 4, 5]]
+    cols = vals.shape[0]
+    leaves, coeffs = oracle.lde_from_values(vals, rate_bits, 7)
+    src, dst, co = ctx.from_host(vals), ctx.alloc(N * cols), ctx.alloc(n * cols)
+    ctx.lde(src, log_n, cols, rate_bits, dst, shift=7, coeffs_out=co)
+    got = dst.download().reshape(cols, N)
+    assert (got[:, bitrev_perm(log_n + rate_bits)].T == leaves).all()
+    assert (co.download().reshape(cols, n) == coeffs).all()
