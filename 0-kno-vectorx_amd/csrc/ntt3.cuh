@@ -64,6 +64,14 @@ __device__ __forceinline__ size_t e_off(int e, int log_m) {  // uniform
 #ifndef VX_NTT3_TPB
 #define VX_NTT3_TPB 4
 #endif
+// waves per SIMD the register allocation aims at: the contiguous 12-stage pass needs 37 KB of LDS per block (4 blocks per CU),
+// the strided passes stage the between-pass table as well (52 KB: 3 blocks per CU)
+#ifndef VX_NTT3_DIRECT0
+#define VX_NTT3_DIRECT0 0
+#endif
+#ifndef VX_NTT3_WAVES
+#define VX_NTT3_WAVES(LR, MODE) ((LR) == 12 && (MODE) == 0 ? 4 : 3)
+#endif
 
 namespace n3 {
 
@@ -117,13 +125,25 @@ __device__ __forceinline__ void mul15(uint64_t* y, const uint64_t* w) {
 
 }  // namespace n3
 
-template <int MODE, int INV, int LR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_ntt3(PassArgs a) {
+// EB > 0: the first pass of an LDE (MODE 1, LR 12, contiguous tile).  The source holds the 2^log_coeff coefficients in
+// bit-reversed positions; position g of the 2^EB times larger transform is coefficient g >> EB when g is a multiple of
+// 2^EB and zero otherwise, scaled by shift^bitrev(g >> EB).  The tile is loaded straight into layout 0 (16 consecutive
+// positions per lane): a lane reads its 16 >> EB coefficients as one contiguous run, the zeros are compile-time constants
+// (the first EB butterfly stages fold away), and the scale factor is split along the bit fields of the index,
+//   shift^bitrev(q) = A(tile) * B(lane) * C(element),
+// so that a coefficient costs two multiplications instead of three table look-ups and up to three multiplications on
+// every lane of the tile, zero or not.
+template <int MODE, int INV, int LR, int EB = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_NTT3_WAVES(LR, MODE), 4))) void k_ntt3(PassArgs a) {
+    static_assert(EB == 0 || (MODE == 1 && LR == 12 && EB <= 3), "zero-padded loads exist for the contiguous DIT pass only");
     using S = n3::Shape<LR>;
     constexpr int LT = S::LT, NR = S::NR;
     constexpr int T2N = LR <= 8 ? 2048 : 0;            // staged two-level table of the between-pass twiddle
     constexpr int WBN = LR > 8 ? 256 : 0;               // staged w_256^j (all of them: no sign fix-up) for the second round twiddle
-    constexpr int FE = S::F_EDGE;                       // layout of the strided side: DIF stores from it, DIT loads into it
+    // layout of the pass's outer edge: DIF stores from it, DIT loads into it.  A three-round pass ends (starts) in layout 0, 16
+    // consecutive elements per lane: with VX_NTT3_DIRECT0 it stores (loads) them from there -- 128 contiguous bytes per lane as
+    // 16-byte accesses -- instead of paying one more LDS exchange for 512-byte wave rows
+    constexpr int FE = (NR == 3 && (EB > 0 || (VX_NTT3_DIRECT0 && MODE == 1))) ? 0 : S::F_EDGE;
     __shared__ __attribute__((aligned(16))) uint64_t lds[4096 + 256 + (WBN ? WBN : 1) + (T2N ? T2N : 1)];
     uint64_t* const wsB = lds + 4096 + 256;
     uint64_t* const t2s = wsB + (WBN ? WBN : 1);
@@ -174,6 +194,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         return gl_mul_nc(a.tw2_hi[ex >> a.tw2_bits], a.tw2_lo[ex & t2_mask]);
     };
 
+    // coset scale factors of the zero-padded load (EB > 0): per lane and per element, fixed for the launch
+    uint64_t sB = 1, sC[EB > 0 ? (16 >> EB) : 1];
+    if (EB > 0 && a.shift_tab) {
+        sB = tab3_pow(a.shift_tab, (uint64_t)(__brev((unsigned)tid) >> 24) << (a.log_coeff - 12 + EB));
+#pragma unroll
+        for (int j = 0; j < (16 >> EB); ++j) sC[j] = tab3_pow(a.shift_tab, (uint64_t)n3::brev_c(j, 4 - EB) << (a.log_coeff - 4 + EB));
+    }
+
     gl96::X x[16];
     uint64_t y[16];
 #pragma unroll 1
@@ -206,10 +234,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
                 n3::widen(x, y);
                 gl96::dif_round<S::QC ? S::QC : 1, INV>(x);
                 n3::fold16(y, x);
-                __syncthreads();
-                n3::exch_write<0>(y, lds, s0);
-                __syncthreads();
-                n3::exch_read<8>(y, lds, s8);
+                if (FE != 0) {
+                    __syncthreads();
+                    n3::exch_write<0>(y, lds, s0);
+                    __syncthreads();
+                    n3::exch_read<8>(y, lds, s8);
+                }
             }
             if (strided) {
 #pragma unroll
@@ -223,16 +253,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
 #pragma unroll
             for (int e = 0; e < 16; ++e) n3::st_at(dst + base + n3::e_off<FE, LT>(e, log_m), offE, y[e]);
         } else {
-            if (a.expand_bits) {  // first pass of an LDE (contiguous tile): zero padding + coset scaling on the fly
+            if (EB > 0) {
+                constexpr int J = 16 >> EB;                       // coefficients per lane
+                const uint64_t* sp = src + (base >> EB) + (size_t)tid * J;
+                uint64_t ab = 0;
+                if (a.shift_tab) ab = gl_mul_nc(tab3_pow(a.shift_tab, brev32((uint32_t)(tile), a.log_coeff - 12 + EB)), sB);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const size_t g = base + (size_t)(n3::lane_part<FE>(tid) | (e << FE));
-                    uint64_t v = 0;
-                    if ((g & (((size_t)1 << a.expand_bits) - 1)) == 0) {
-                        v = src[g >> a.expand_bits];
-                        if (a.shift_tab) v = gl_mul_nc(v, tab3_pow(a.shift_tab, brev32((uint32_t)(g >> a.expand_bits), a.log_coeff)));
+                    if (e & ((1 << EB) - 1)) y[e] = 0;
+                    else {
+                        uint64_t v = sp[e >> EB];
+                        if (a.shift_tab) v = gl_mul_nc(gl_mul_nc(v, ab), sC[e >> EB]);
+                        y[e] = v;
                     }
-                    y[e] = v;
                 }
             } else {
 #pragma unroll
@@ -250,10 +283,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
                 }
             }
             if (NR == 3) {
-                __syncthreads();
-                n3::exch_write<8>(y, lds, s8);
-                __syncthreads();
-                n3::exch_read<0>(y, lds, s0);
+                if (FE != 0) {
+                    __syncthreads();
+                    n3::exch_write<8>(y, lds, s8);
+                    __syncthreads();
+                    n3::exch_read<0>(y, lds, s0);
+                }
                 n3::widen(x, y);
                 gl96::dit_round<S::QC ? S::QC : 1, INV>(x);
                 n3::fold16(y, x);

@@ -468,8 +468,14 @@ static bool g_ntt_v1 = getenv("VX_NTT_V1") != nullptr;  // debugging aid: force 
 static bool g_ntt_v2 = getenv("VX_NTT_V2") != nullptr;  // A/B aid: the run-time-shape tile kernel instead of k_ntt3
 template <int MODE, int LR>
 static void launch_ntt3(vx_ctx* ctx, const PassArgs& a, unsigned gx, size_t n_cols, int inverse) {
-    if (inverse) hipLaunchKernelGGL((k_ntt3<MODE, 1, LR>), dim3(gx, (unsigned)n_cols), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((k_ntt3<MODE, 0, LR>), dim3(gx, (unsigned)n_cols), dim3(256), 0, ctx->stream, a);
+    const dim3 grid(gx, (unsigned)n_cols), block(256);
+    if constexpr (MODE == 1 && LR == 12) {  // the zero-padding first pass of an LDE (forward only: the callers never expand an inverse)
+        if (a.expand_bits == 1) { hipLaunchKernelGGL((k_ntt3<1, 0, 12, 1>), grid, block, 0, ctx->stream, a); return; }
+        if (a.expand_bits == 2) { hipLaunchKernelGGL((k_ntt3<1, 0, 12, 2>), grid, block, 0, ctx->stream, a); return; }
+        if (a.expand_bits == 3) { hipLaunchKernelGGL((k_ntt3<1, 0, 12, 3>), grid, block, 0, ctx->stream, a); return; }
+    }
+    if (inverse) hipLaunchKernelGGL((k_ntt3<MODE, 1, LR>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_ntt3<MODE, 0, LR>), grid, block, 0, ctx->stream, a);
 }
 static int g_ntt_skip = getenv("VX_NTT_SKIP") ? atoi(getenv("VX_NTT_SKIP")) : 0;  // timing experiments (wrong results!)
 // VX_NTT_GROUP=G: run ALL passes of a transform over G columns before moving to the next G (a group of 32 columns of 2^19 is
@@ -479,7 +485,8 @@ template <int MODE>
 static int32_t launch_pass(vx_ctx* ctx, PassArgs& a, int log_n, size_t n_cols, int inverse) {
     size_t tiles = (size_t)1 << (log_n - a.log_rows - a.log_T);
     a.dbg_skip = g_ntt_skip;
-    if (a.log_rows + a.log_T == 12 && !g_ntt_v1 && !g_ntt_v2 && (a.log_rows == 12 || (a.log_rows >= 4 && a.log_rows <= 8))) {
+    const bool expand_ok = a.expand_bits == 0 || (MODE == 1 && !inverse && a.log_rows == 12 && a.expand_bits <= 3);
+    if (a.log_rows + a.log_T == 12 && !g_ntt_v1 && !g_ntt_v2 && (a.log_rows == 12 || (a.log_rows >= 4 && a.log_rows <= 8)) && expand_ok) {
         a.n_tiles = tiles;
         const unsigned gx = (unsigned)((tiles + VX_NTT3_TPB - 1) / VX_NTT3_TPB);
         switch (a.log_rows) {

@@ -208,14 +208,16 @@ def test_ntt_tile_shapes_special_values(ctx, oracle, rng, log_n):
     assert (buf.download().reshape(cols, n) == x).all()
 
 
-@pytest.mark.parametrize("log_n,rate_bits", [(15, 1), (16, 1), (18, 1), (19, 1), (17, 3)])
-def test_lde_tile_shapes_special_values(ctx, oracle, rng, log_n, rate_bits):
+# rate_bits 1 / 2 / 3 take the zero-padding loads of k_ntt3<1, 0, 12, EB>, 4 the run-time-shape kernel; shift 1 = no coset scaling;
+# (11, 1) and (10, 2) are single-tile transforms
+@pytest.mark.parametrize("log_n,rate_bits,shift", [(15, 1, 7), (16, 1, 7), (18, 1, 7), (19, 1, 7), (17, 3, 7), (14, 2, 7), (16, 2, 49), (13, 4, 7), (15, 1, 1), (11, 1, 7), (10, 2, 7)])
+def test_lde_tile_shapes_special_values(ctx, oracle, rng, log_n, rate_bits, shift):
     n, N = 1 << log_n, 1 << (log_n + rate_bits)
     vals = _special_columns(rng, n)[[0, 2, 4, 5]]
     cols = vals.shape[0]
-    leaves, coeffs = oracle.lde_from_values(vals, rate_bits, 7)
+    leaves, coeffs = oracle.lde_from_values(vals, rate_bits, shift)
     src, dst, co = ctx.from_host(vals), ctx.alloc(N * cols), ctx.alloc(n * cols)
-    ctx.lde(src, log_n, cols, rate_bits, dst, shift=7, coeffs_out=co)
+    ctx.lde(src, log_n, cols, rate_bits, dst, shift=shift, coeffs_out=co)
     got = dst.download().reshape(cols, N)
     assert (got[:, bitrev_perm(log_n + rate_bits)].T == leaves).all()
     assert (co.download().reshape(cols, n) == coeffs).all()

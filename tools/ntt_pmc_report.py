@@ -30,12 +30,12 @@ def main(fetch_dir, write_dir, out):
     cal_f = 16.0 * N / pick(f, "k_batch")[0]
     cal_w = 8.0 * N / pick(w, "k_batch")[0]
     cal_w2 = 8.0 * N / pick(w, "k_fill_random")[-1]
-    ntt_f, ntt_w = pick(f, "k_ntt_tile"), pick(w, "k_ntt_tile")
+    ntt_f, ntt_w = pick(f, "k_ntt"), pick(w, "k_ntt")  # k_ntt3 (round 3) or k_ntt_tile
     per_launch = [(a * cal_f + b * cal_w) for a, b in zip(ntt_f, ntt_w)]
     launches = len(per_launch)
     per_transform = sum(per_launch) / (launches / 2)
     res = {
-        "shape": f"forward NTT 2^{LOG_N} x {COLS}, 2 launches of k_ntt_tile per transform",
+        "shape": f"forward NTT 2^{LOG_N} x {COLS}, 2 launches of the tile kernel per transform",
         "calibration": {"fetch_bytes_per_count": cal_f, "write_bytes_per_count": cal_w, "write_bytes_per_count_fill": cal_w2,
                         "method": "known 8-B/lane streams: k_batch<add> (16N read, 8N written), k_fill_random (8N written)"},
         "fetch_counts": ntt_f, "write_counts": ntt_w,
