@@ -8,7 +8,11 @@
 // message; node g of tree t sits at rows 128 (t N + g) in heap numbering (1 = root, children 2g / 2g+1, leaves N..2N-1,
 // slot 0 a dummy).  Compression rows and column layout are ShaChainAir's (air_sha.cuh, 539 columns); everything positional is a
 // PERIODIC column; the only other witness is the pair of leaf-enable flags ENL / ENR of a bottom-level node (a disabled
-// leaf must be zero and takes nothing from the bus).  Row r < 16 of a DATA block receives message word r:
+// leaf must be zero and takes nothing from the bus) and their running count CNT.  The flags are NOT the prover's to choose:
+// they are boolean, constant over a node, non-increasing in leaf order, and their count over each tree is public input 16 =
+// the number of headers of the range (the verifier sets it to target_block - trusted_block), i.e. leaf i is enabled exactly
+// when i < n -- every header's two roots MUST be taken from the bus, so a prover can no longer drop a header's sends on the
+// Blake2b side together with its receives here.  Row r < 16 of a DATA block receives message word r:
 //   inner nodes:                 (tree, child id, r mod 8, word, TAG_WORD)                         from the children's PAD blocks
 //   bottom level of both trees:  (leaf, 4 (r mod 8) + q, byte q of the word, tree, TAG_BYTE), q = 0..3   from the header bytes
 // and row 63 of a PAD block sends the node's digest (tree, g, j, word_j), except for the root: its digest is public.
@@ -20,21 +24,23 @@
 #include "air_sha.cuh"
 
 namespace sht {
-constexpr int ENL = shc::DG0, ENR = shc::DG0 + 1, COLS = shc::COLS, AUX = 16, N_PERIODIC = 14;
-enum { P_SEL0, P_SEL63, P_SCHED, P_K, P_DATA, P_TREE, P_PWA, P_PBL, P_PBR, P_CID, P_JJ, P_PS, P_ROOT, P_GID };
+constexpr int ENL = shc::DG0, ENR = shc::DG0 + 1, CNT = shc::DG0 + 2, COLS = shc::COLS, AUX = 16, N_PERIODIC = 17;
+// P_NB / P_BB / P_LASTN sit on the last row of a node (row 63 of its PAD block): the next node is a bottom-level node / this
+// node and the next both are / this is the last node of its tree
+enum { P_SEL0, P_SEL63, P_SCHED, P_K, P_DATA, P_TREE, P_PWA, P_PBL, P_PBR, P_CID, P_JJ, P_PS, P_ROOT, P_GID, P_NB, P_BB, P_LASTN };
 }  // namespace sht
 
 template <int LOGN, int ID_>
 struct ShaTreeAirT {
-    static constexpr int ID = ID_, COLS = sht::COLS, PUB = 16, PERIODIC = sht::N_PERIODIC, PERIOD_LOG = 8 + LOGN, QUOT_ROWS_PER_LANE = 1, AUX = sht::AUX, CHAL = 4, AUXPUB = 1, EXACT_LOG = 1;
+    static constexpr int ID = ID_, COLS = sht::COLS, PUB = 17, PERIODIC = sht::N_PERIODIC, PERIOD_LOG = 8 + LOGN, QUOT_ROWS_PER_LANE = 1, AUX = sht::AUX, CHAL = 4, AUXPUB = 1, EXACT_LOG = 1;
     static constexpr int TREE_SIZE = 1 << LOGN;
-    static constexpr int plog(int q) { return q < 4 ? 6 : (q == 4 ? 7 : 8 + LOGN); }  // 4 x 64, 128, then 9 full-period columns
+    static constexpr int plog(int q) { return q < 4 ? 6 : (q == 4 ? 7 : 8 + LOGN); }  // 4 x 64, 128, then 12 full-period columns
 
     // one period of every periodic column, back to back (host)
     static void periodic_values(std::vector<uint64_t>& v) {
         using namespace sht;
         const size_t N = TREE_SIZE, n = 256 * N;
-        v.assign(4 * 64 + 128 + 9 * n, 0);
+        v.assign(4 * 64 + 128 + 12 * n, 0);
         uint64_t* p = v.data();
         p[0] = 1, p[64 + 63] = 1;
         for (int r = 0; r <= 47; ++r) p[128 + r] = 1;
@@ -55,6 +61,9 @@ struct ShaTreeAirT {
             q[(P_PS - 5) * n + row] = send && g >= 2;
             q[(P_ROOT - 5) * n + row] = send && g == 1;
             q[(P_GID - 5) * n + row] = send ? g : 0;
+            q[(P_NB - 5) * n + row] = send && g + 1 >= N / 2 && g + 1 < N;
+            q[(P_BB - 5) * n + row] = send && g >= N / 2 && g + 1 < N;
+            q[(P_LASTN - 5) * n + row] = send && g == N - 1;
         }
     }
 
@@ -81,6 +90,20 @@ struct ShaTreeAirT {
         const F w0 = val(loc, W0B, 32);
         c.constraint(per[P_PBL] * (one - loc[ENL]) * w0);
         c.constraint(per[P_PBR] * (one - loc[ENR]) * w0);
+        // ---- 8b. the leaf-enable flags are forced: leaf i of either tree is enabled exactly when i < pub[16]
+        {
+            const F enl = loc[ENL], enr = loc[ENR], end = per[P_SEL63] * (one - is_data), keep = one - end;
+            c.constraint(enl * (enl - one));
+            c.constraint(enr * (enr - one));
+            c.constraint(enr * (one - enl));                                   // left before right
+            c.constraint(keep * (nxt[ENL] - enl));                             // constant over the 128 rows of a node
+            c.constraint(keep * (nxt[ENR] - enr));
+            c.constraint(keep * (nxt[CNT] - loc[CNT]));
+            c.constraint(per[P_BB] * nxt[ENL] * (one - enr));                  // non-increasing from node to node
+            // the count restarts at slot 0 of a tree and takes in the flags of every bottom-level node
+            c.constraint(end * (nxt[CNT] - loc[CNT]) + per[P_LASTN] * loc[CNT] - per[P_NB] * (nxt[ENL] + nxt[ENR]));
+            c.constraint(per[P_LASTN] * (loc[CNT] - pub[16]));
+        }
         // ---- 9. the bus (logUp): 13 lookups in 7 helper elements of the local row, cyclic running sum
         {
             const X2<F> beta{chal[0], chal[1]}, gamma{chal[2], chal[3]}, g2 = gamma * gamma, g3 = g2 * gamma, g4 = g2 * g2;

@@ -649,7 +649,7 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
     return VX_OK;
 }
 
-static const uint64_t VX_HR_MAGIC = 0x3545474e41525248ULL;  // "HRRANGE5"
+static const uint64_t VX_HR_MAGIC = VX_HR_BLOB_MAGIC;  // "HRRANGE5" (include/vx.h)
 // magic, max_headers, trusted, target, out96 (12), proof lengths: hash chain, authority-set commitment, Merkle, Ed25519, SHA-512; the precommit's round
 static const size_t VX_HR_HDR = 22;
 
@@ -842,7 +842,7 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
     }
     TableJob tree;
     tree.c = side[0];
-    uint64_t tpub[16];
+    uint64_t tpub[17];
     auto prove_tree = [&](vx_ctx* c, TableJob& j) -> int32_t {
         vx_buf* tt = nullptr;
         int32_t r = vx_alloc(c, ((size_t)VX_SHA_TREE_AIR_COLS) << tl, &tt);
@@ -857,7 +857,7 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
         if (r == VX_OK) r = vx_stark_proof_bound(tree_id, cfg, tl, &bound);
         if (r == VX_OK) {
             j.proof.resize(bound);
-            r = vx_stark_prove_impl(c, tree_id, cfg, tt->d, tt->n, /*consume_trace=*/0, tl, tpub, 16, j.proof.data(), j.proof.size(), &j.len, &hooks[1]);
+            r = vx_stark_prove_impl(c, tree_id, cfg, tt->d, tt->n, /*consume_trace=*/0, tl, tpub, 17, j.proof.data(), j.proof.size(), &j.len, &hooks[1]);
         }
         if (tt) (void)vx_free(c, tt);
         return r;

@@ -158,7 +158,7 @@ int32_t vx_scan_cols_dev(vx_ctx* ctx, uint64_t* data, int log_n, size_t n_cols, 
 int32_t vx_blake_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub);
 int32_t vx_lookup_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub);
 int32_t vx_sha_tree_trace_dev(vx_ctx* ctx, const uint8_t* state_roots, const uint8_t* data_roots, size_t n_leaves, int log_tree, uint64_t* trace_d,
-                              uint64_t pub_out[16]);
+                              uint64_t pub_out[17]);
 int32_t vx_bus_close_dev(vx_ctx* ctx, uint64_t* z_cols, int log_n, uint64_t aux_pub[2]);
 int32_t vx_sha_tree_gen_aux_16(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub);
 int32_t vx_sha_tree_gen_aux_256(vx_ctx* ctx, const uint64_t* trace, int log_n, const uint64_t* chal, const uint64_t* pub, uint64_t* aux, uint64_t* aux_pub);

@@ -195,9 +195,9 @@ extern "C" int32_t vx_sha_chain_trace(vx_ctx* ctx, const uint8_t* pubkeys, size_
 // ---- ShaTreeAir: the two SHA-256 Merkle trees over state roots and data roots ------------------------------------------
 // The trees are tiny (2 (N - 1) nodes): node values on the host, then the same row kernel as the chain AIR.  Block
 // descriptor of node g of tree t: DATA block (IV, l || r) and PAD block (DATA's output, the constant second block of a
-// 64-byte message); dg[0] / dg[1] carry the leaf-enable flags ENL / ENR of a bottom-level node.
+// 64-byte message); dg[0] / dg[1] carry the leaf-enable flags ENL / ENR of a bottom-level node, dg[2] their running count.
 int32_t vx_sha_tree_trace_dev(vx_ctx* ctx, const uint8_t* state_roots, const uint8_t* data_roots, size_t n_leaves, int log_tree, uint64_t* trace_d,
-                              uint64_t pub_out[16]) {
+                              uint64_t pub_out[17]) {
     const size_t N = (size_t)1 << log_tree, n = 256 * N, n_blocks = n >> 6;
     VX_CHECK(n_leaves >= 1 && n_leaves <= N, "sha tree: %zu leaves do not fit a tree of %zu", n_leaves, N);
     std::vector<ShaBlock> blocks(n_blocks);
@@ -219,7 +219,11 @@ int32_t vx_sha_tree_trace_dev(vx_ctx* ctx, const uint8_t* state_roots, const uin
             for (int j = 0; j < 8; ++j) p.h_in[j] = mid[j];
             for (int j = 0; j < 16; ++j) p.block[j] = shc::pad64(j);
             h_compress(p.h_in, p.block, &node[g * 8]);
-            if (g >= N / 2) d.dg[0] = p.dg[0] = 2 * g - N < n_leaves, d.dg[1] = p.dg[1] = 2 * g - N + 1 < n_leaves;
+            if (g >= N / 2) {
+                d.dg[0] = p.dg[0] = 2 * g - N < n_leaves, d.dg[1] = p.dg[1] = 2 * g - N + 1 < n_leaves;
+                const size_t cnt = 2 * g - N + 2 < n_leaves ? 2 * g - N + 2 : n_leaves;  // enabled leaves up to and including this node
+                d.dg[2] = p.dg[2] = (uint32_t)cnt;
+            }
         }
         {  // slot 0: a dummy node (zero message), never on the bus
             ShaBlock& d = blocks[2 * (size_t)t * N];
@@ -233,6 +237,7 @@ int32_t vx_sha_tree_trace_dev(vx_ctx* ctx, const uint8_t* state_roots, const uin
         }
         for (int j = 0; j < 8; ++j) pub_out[8 * t + j] = node[8 + j];
     }
+    pub_out[16] = n_leaves;
     uint64_t* sc;
     VX_TRY(vx_scratch(ctx, (n_blocks * sizeof(ShaBlock) + 7) / 8, &sc));
     VX_HIP(hipMemcpyAsync(sc, blocks.data(), n_blocks * sizeof(ShaBlock), hipMemcpyHostToDevice, ctx->stream));

@@ -22,31 +22,12 @@
 #include "air_epoch.cuh"
 #include "air_sha512.cuh"
 #include "air_sha_tree.cuh"
-#include "poseidon_constants.h"
+#include "glh_poseidon.h"
 #include "vx_internal.h"
 
-// ------------------------------------------------------------------ host Poseidon + challenger
+// ------------------------------------------------------------------ challenger over the host Poseidon (glh_poseidon.h)
 namespace {
-const uint64_t H_RC[360] = VX_POSEIDON_RC_INIT;
-const uint64_t H_MDS[12] = VX_POSEIDON_MDS_CIRC_INIT;
-void h_poseidon(uint64_t* s) {
-    for (int r = 0; r < 30; ++r) {
-        for (int i = 0; i < 12; ++i) s[i] = glh::add(s[i], H_RC[12 * r + i]);
-        int full = (r < 4 || r >= 26);
-        for (int i = 0; i < (full ? 12 : 1); ++i) {
-            uint64_t x = s[i], x2 = glh::mul(x, x), x4 = glh::mul(x2, x2);
-            s[i] = glh::mul(glh::mul(x4, x2), x);
-        }
-        uint64_t o[12];
-        for (int row = 0; row < 12; ++row) {
-            unsigned __int128 acc = 0;
-            for (int i = 0; i < 12; ++i) acc += (unsigned __int128)s[(i + row) % 12] * H_MDS[i];
-            if (row == 0) acc += (unsigned __int128)s[0] * VX_POSEIDON_MDS_DIAG0;
-            o[row] = glh::reduce128(acc);
-        }
-        memcpy(s, o, sizeof o);
-    }
-}
+inline void h_poseidon(uint64_t* s) { glh::poseidon(s); }
 struct Ext {
     uint64_t a, b;
 };
@@ -70,28 +51,7 @@ inline Ext e_pow(Ext x, uint64_t e) {
     }
     return r;
 }
-struct Challenger {  // plonky2 iop/challenger.rs
-    uint64_t st[12] = {0}, in[8], out[8];
-    int n_in = 0, n_out = 0;
-    void duplex() {
-        for (int i = 0; i < n_in; ++i) st[i] = in[i];
-        n_in = 0;
-        h_poseidon(st);
-        memcpy(out, st, sizeof out);
-        n_out = 8;
-    }
-    void observe(uint64_t x) {
-        n_out = 0;
-        in[n_in++] = x;
-        if (n_in == 8) duplex();
-    }
-    void observe(const uint64_t* x, size_t n) {
-        for (size_t i = 0; i < n; ++i) observe(x[i]);
-    }
-    uint64_t challenge() {
-        if (n_in > 0 || n_out == 0) duplex();
-        return out[--n_out];
-    }
+struct Challenger : glh::Challenger {  // plonky2 iop/challenger.rs (glh_poseidon.h)
     Ext ext_challenge() {
         uint64_t a = challenge(), b = challenge();
         return {a, b};

@@ -15,31 +15,12 @@
 #include "air_epoch.cuh"
 #include "air_sha512.cuh"
 #include "air_sha_tree.cuh"
-#include "poseidon_constants.h"
+#include "glh_poseidon.h"
 #include "vx_bus.h"
 #include "vx_internal.h"
 
 namespace {
-const uint64_t V_RC[360] = VX_POSEIDON_RC_INIT;
-const uint64_t V_MDS[12] = VX_POSEIDON_MDS_CIRC_INIT;
-void v_poseidon(uint64_t* s) {
-    for (int r = 0; r < 30; ++r) {
-        for (int i = 0; i < 12; ++i) s[i] = glh::add(s[i], V_RC[12 * r + i]);
-        const int nsb = (r < 4 || r >= 26) ? 12 : 1;
-        for (int i = 0; i < nsb; ++i) {
-            const uint64_t x = s[i], x2 = glh::mul(x, x), x3 = glh::mul(x2, x), x4 = glh::mul(x2, x2);
-            s[i] = glh::mul(x3, x4);
-        }
-        uint64_t o[12];
-        for (int row = 0; row < 12; ++row) {
-            unsigned __int128 acc = 0;
-            for (int i = 0; i < 12; ++i) acc += (unsigned __int128)s[(i + row) % 12] * V_MDS[i];
-            if (row == 0) acc += (unsigned __int128)s[0] * VX_POSEIDON_MDS_DIAG0;
-            o[row] = glh::reduce128(acc);
-        }
-        memcpy(s, o, sizeof o);
-    }
-}
+inline void v_poseidon(uint64_t* s) { glh::poseidon(s); }
 void v_hash_or_noop(const uint64_t* in, size_t len, uint64_t* out4) {
     uint64_t s[12] = {0};
     if (len <= 4) {
@@ -71,28 +52,7 @@ bool v_merkle(const uint64_t* leaf, size_t leaf_len, size_t idx, const uint64_t*
     }
     return memcmp(cur, cap + 4 * idx, 32) == 0;
 }
-struct VChallenger {
-    uint64_t st[12] = {0}, in[8], out[8];
-    int n_in = 0, n_out = 0;
-    void duplex() {
-        for (int i = 0; i < n_in; ++i) st[i] = in[i];
-        n_in = 0;
-        v_poseidon(st);
-        memcpy(out, st, sizeof out);
-        n_out = 8;
-    }
-    void observe(uint64_t x) {
-        n_out = 0;
-        in[n_in++] = x;
-        if (n_in == 8) duplex();
-    }
-    void observe(const uint64_t* x, size_t n) {
-        for (size_t i = 0; i < n; ++i) observe(x[i]);
-    }
-    uint64_t challenge() {
-        if (n_in > 0 || n_out == 0) duplex();
-        return out[--n_out];
-    }
+struct VChallenger : glh::Challenger {
     Fx ext() {
         const uint64_t a = challenge(), b = challenge();
         return {a, b};
@@ -224,6 +184,12 @@ void v_shared_challenges_n(const uint64_t* const* pubs, const size_t* n_pubs, co
 int32_t vx_stark_verify_ext(const vx_stark_config* cfg, const uint64_t* pr, size_t len, int expect_air, const uint64_t* expect_public,
                             size_t n_expect_public, const uint64_t* ext_chal, const uint64_t** apub_out, int* log_n_out, char* err, size_t errlen) {
     if (!cfg || !pr) return VX_ERR_ARG;
+    // the configuration steers loops below (a circuit.json can carry it): the same ranges the prover accepts (vx_stark.hip)
+    if (cfg->rate_bits < 1 || cfg->rate_bits > 3 || cfg->arity_bits < 1 || cfg->arity_bits > 5 || cfg->final_poly_bits < 0 || cfg->final_poly_bits > 27 ||
+        cfg->num_queries < 1 || cfg->num_queries > 1024 || cfg->pow_bits < 0 || cfg->pow_bits > 32 || cfg->cap_height < 0 || cfg->cap_height > 27) {
+        if (err && errlen) snprintf(err, errlen, "stark verify: configuration out of range");
+        return VX_ERR_ARG;
+    }
     size_t pos = 0;
     auto have = [&](size_t k) { return pos + k <= len; };
     NEED(have(10), "proof truncated (header)");
@@ -524,8 +490,8 @@ int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob,
                                uint32_t trusted_block, const uint8_t trusted_hash[32], uint64_t authority_set_id, const uint8_t* authority_set_hash,
                                uint32_t target_block, const uint8_t out96[96], char* err, size_t errlen) {
     if (!cfg || !blob || !trusted_hash || !out96) return VX_ERR_ARG;
-    const size_t HDR = 22;
-    NEED(len > HDR && blob[0] == 0x3545474e41525248ULL, "bad header_range blob");
+    const size_t HDR = VX_HR_BLOB_HEADER_WORDS;
+    NEED(len > HDR && blob[0] == VX_HR_BLOB_MAGIC, "bad header_range blob");
     NEED(blob[1] == max_headers && blob[2] == trusted_block && blob[3] == target_block, "blob is for a different request");
     NEED(memcmp(blob + 4, out96, 96) == 0, "public outputs differ from the blob");
     NEED(target_block > trusted_block, "empty block range");
@@ -552,7 +518,7 @@ int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob,
         NEED(vx_stark_proof_peek(proof[t], pl[t], cfg->cap_height, &ppub[t], &npub[t], &pcap[t]), "proofs are too short to hold a trace cap");
     }
     // public inputs of every table, rebuilt from the request and the claimed outputs
-    uint64_t pub[20], tpub[16], spub[10], epub[2], hpub[15];
+    uint64_t pub[20], tpub[17], spub[10], epub[2], hpub[15];
     for (int j = 0; j < 8; ++j) {
         uint32_t a, b;
         memcpy(&a, trusted_hash + 4 * j, 4);
@@ -566,9 +532,11 @@ int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob,
     pub[19] = 1;            // bus on
     for (int j = 0; j < 16; ++j)  // state_root_merkle_root || data_root_merkle_root as big-endian words
         tpub[j] = ((uint64_t)out96[32 + 4 * j] << 24) | ((uint64_t)out96[33 + 4 * j] << 16) | ((uint64_t)out96[34 + 4 * j] << 8) | out96[35 + 4 * j];
+    tpub[16] = (uint64_t)target_block - trusted_block;  // the number of headers = of enabled leaves: the Merkle table MUST take every header's roots from the bus
+    NEED(tpub[16] <= max_headers, "the block range exceeds max_headers");
     int air[5] = {VX_AIR_BLAKE_CHAIN, tree_id, VX_AIR_SHA_CHAIN, 0, 0};
     const uint64_t* want[5] = {pub, tpub, spub, epub, hpub};
-    const size_t n_want[5] = {20, 16, 10, 2, 15};
+    const size_t n_want[5] = {20, 17, 10, 2, 15};
     if (justified) {
         const int32_t rc = vx_justification_expect(ppub[2], npub[2], ppub[3], npub[3], npub[4], authority_set_hash, authority_set_id, out96, target_block, blob[21], spub, epub,
                                                    hpub, air + 2, err, errlen);

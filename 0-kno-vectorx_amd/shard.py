@@ -42,9 +42,14 @@ def gather_blobs(blob, dist=None, device=None):
 
 
 class RcclComm:
-    """A raw ncclComm_t (one rank per GPU) made with the RCCL copy PyTorch ships, for the C-ABI gather
-    `vx_gather_proofs` (include/vx.h).  The unique id travels over the already initialised torch.distributed group.
-    torch must have initialised the HIP runtime on `device` first (RCCL wants the runtime it was built with)."""
+    """A raw ncclComm_t (one rank per GPU) for the C-ABI gather `vx_gather_proofs` (include/vx.h), made with the RCCL copy
+    this process ALREADY has mapped (the one torch.distributed's nccl backend loaded), else the one PyTorch ships, and only
+    then a system librccl -- two different RCCL builds making communicators on one HIP runtime is what this order avoids.
+    The unique id travels over the already initialised torch.distributed group.  torch must have initialised the HIP runtime
+    on `device` first (RCCL wants the runtime it was built with).
+    ncclCommInitRank is a collective: if one rank fails before it, the others block inside it.  The call therefore runs under
+    a watchdog (VX_RCCL_INIT_TIMEOUT seconds, default 180): a rank still inside after that prints why and exits with code 3
+    instead of hanging the job; bench.py's agreement check (all_reduce of an ok flag) covers the ranks that returned."""
 
     def __init__(self, dist, device):
         import ctypes as C
@@ -53,9 +58,16 @@ class RcclComm:
         import torch
 
         self.handle, self._lib = None, None
-        for name in ("librccl.so.1", "librccl.so", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")):
+        mapped = []
+        try:
+            with open("/proc/self/maps") as f:
+                mapped = sorted({ln.split()[-1] for ln in f if ln.split() and "librccl.so" in ln.split()[-1]})
+        except OSError:
+            pass
+        for name in list(mapped) + [os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so.1", "librccl.so"]:
             try:
                 self._lib = C.CDLL(name)
+                self.lib_path = name
                 break
             except OSError:
                 pass
@@ -77,7 +89,17 @@ class RcclComm:
         torch.cuda.set_device(device)
         comm = C.c_void_p()
         self._lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
-        rc = self._lib.ncclCommInitRank(C.byref(comm), world, u, rank)
+        import sys
+        import threading
+
+        res = []
+        th = threading.Thread(target=lambda: res.append(self._lib.ncclCommInitRank(C.byref(comm), world, u, rank)), daemon=True)
+        th.start()
+        th.join(float(os.environ.get("VX_RCCL_INIT_TIMEOUT", "180")))
+        if th.is_alive():
+            print(f"RcclComm: rank {rank} of {world} is still inside ncclCommInitRank -- another rank did not join; giving up", file=sys.stderr, flush=True)
+            os._exit(3)
+        rc = res[0]
         if rc != 0:
             raise OSError(f"ncclCommInitRank failed ({rc})")
         self.handle, self.world = comm.value, world

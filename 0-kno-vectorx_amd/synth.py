@@ -19,6 +19,8 @@ checks:
 PRNG: SplitMix64 (counter form, so it vectorises); seeds from SURVEY.md section 8(d).
 """
 import hashlib
+import os
+import tempfile
 
 import numpy as np
 
@@ -116,6 +118,40 @@ class Chain:
         return self.target_hash + root(self.state_roots) + root(self.data_roots)
 
 
+def _cached_rows(tag, key_bytes, width, make):
+    """`make()` -> list of `width`-byte strings, memoised in this process and in a file of the temp directory: the keys and
+    signatures are pure-Python Ed25519 (seconds for 300 authorities) and every context of a bench rank, and every rank whose
+    input has the same seeds, asks for the same ones.  The file is written by this code (numpy .npy, loaded with
+    allow_pickle=False) and named after a SHA-256 of everything the rows depend on; VX_SYNTH_CACHE=0 turns the file off."""
+    key = tag + hashlib.sha256(key_bytes).hexdigest()[:32]
+    if key in _MEMO:
+        return _MEMO[key]
+    path = None if os.environ.get("VX_SYNTH_CACHE") == "0" else os.path.join(os.environ.get("VX_SYNTH_CACHE") or os.path.join(tempfile.gettempdir(), "vx_synth_cache"), key + ".npy")
+    rows = None
+    if path and os.path.exists(path):
+        try:
+            a = np.load(path, allow_pickle=False)
+            if a.dtype == np.uint8 and a.ndim == 2 and a.shape[1] == width:
+                rows = [a[i].tobytes() for i in range(a.shape[0])]
+        except (OSError, ValueError):
+            rows = None
+    if rows is None:
+        rows = make()
+        if path:
+            try:
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                tmp = f"{path}.{os.getpid()}.tmp.npy"
+                np.save(tmp, np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), width))
+                os.replace(tmp, path)  # atomic: several ranks may write the same file
+            except OSError:
+                pass
+    _MEMO[key] = rows
+    return rows
+
+
+_MEMO = {}
+
+
 class Justification:
     def __init__(self, target_block, target_hash, n_auth=MAX_AUTHORITY_SET_SIZE, n_signed=None, set_id=1, round_=1, seed=JUST_SEED):
         n_signed = n_auth if n_signed is None else n_signed
@@ -123,11 +159,12 @@ class Justification:
         self.precommit = b"\x01" + target_hash + target_block.to_bytes(4, "little") + round_.to_bytes(8, "little") + set_id.to_bytes(8, "little")
         assert len(self.precommit) == 53
         secrets = [rand_bytes(seed + 977 * i, 32) for i in range(n_auth)]
-        self.pubkeys = [ed25519.public_key(s) for s in secrets]
+        self.pubkeys = _cached_rows("pk", b"".join(secrets), 32, lambda: [ed25519.public_key(s) for s in secrets])
         # signers: spread evenly so unsigned validators interleave with signed ones
         self.signed = [((i + 1) * n_signed) // n_auth != (i * n_signed) // n_auth for i in range(n_auth)]
         assert sum(self.signed) == n_signed
-        self.signatures = [ed25519.sign(s, self.precommit) if f else bytes(64) for s, f in zip(secrets, self.signed)]
+        self.signatures = _cached_rows("sg", b"".join(secrets) + self.precommit + bytes(self.signed), 64,
+                                       lambda: [ed25519.sign(s, self.precommit) if f else bytes(64) for s, f in zip(secrets, self.signed)])
         h = b""
         for pk in self.pubkeys:
             h = hashlib.sha256(h + pk).digest()
@@ -144,7 +181,7 @@ class EpochEndHeader:
 
     def __init__(self, number, n_new, size=None, seed=ROTATE_SEED, logs_before=1, parent_hash=None):
         secrets = [rand_bytes(seed + 1009 * i, 32) for i in range(n_new)]
-        self.new_pubkeys = [ed25519.public_key(s) for s in secrets]
+        self.new_pubkeys = _cached_rows("pk", b"".join(secrets), 32, lambda: [ed25519.public_key(s) for s in secrets])
         self.num_authorities = n_new
         self.number = number
         value = b"\x01" + compact_u32(n_new) + b"".join(pk + (1).to_bytes(8, "little") for pk in self.new_pubkeys) + bytes(4)

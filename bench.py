@@ -41,17 +41,29 @@ BLAKE_COLS = 745 + 276  # main + auxiliary (logUp) columns
 
 
 class Workload:
-    def __init__(self, vx, ctx, seed_offset=0):
+    """One header_range input of this rank, resident in HBM.  The contexts of a rank (proofs in flight) prove the SAME input:
+    the host-side chain and the justification (300 pure-Python Ed25519 signatures) are built once per rank and shared."""
+    _shared = {}
+
+    def __init__(self, vx, ctx, seed_offset=0, profile=None):
         self.vx, self.ctx = vx, ctx
-        self.chain = vx.synth.Chain(N_HEADERS, profile=PROFILE, seed=vx.synth.CHAIN_SEED + seed_offset)
+        profile = profile or PROFILE
+        key = (N_HEADERS, profile, seed_offset)
+        if key not in Workload._shared:
+            chain = vx.synth.Chain(N_HEADERS, profile=profile, seed=vx.synth.CHAIN_SEED + seed_offset)
+            # 300 authorities, all signing the precommit of the target header (SURVEY.md section 8d)
+            Workload._shared[key] = (chain, vx.lib.PackedJustification(vx.synth.Justification(chain.target_block, chain.target_hash)))
+        self.chain, self.just = Workload._shared[key]
         self.d_headers = ctx.from_host(self.chain.headers)  # resident in HBM before the timed region
         self.cfg = ctx.stark_config()
-        # 300 authorities, all signing the precommit of the target header
-        self.just = vx.lib.PackedJustification(vx.synth.Justification(self.chain.target_block, self.chain.target_hash))
         if os.environ.get("VX_BENCH_NO_JUSTIFICATION"):  # profiling aid: the hash-chain proof alone on one stream (NOT the metric)
             self.just = None
         self.out = None
         ctx.sync()
+
+    def free(self):
+        self.d_headers.free()
+        self.out = None
 
     def step(self):
         ch = self.chain
@@ -121,7 +133,7 @@ def ntt_roofline(ctx, iters=10):
     alg_bytes = 16.0 * n * NTT_COLS
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
-    for tag in ("r02", "r01"):  # PMC counters cannot be read from inside the bench: the committed rocprofv3 --pmc result of this kernel
+    for tag in ("r03", "r02", "r01"):  # PMC counters cannot be read from inside the bench: the committed rocprofv3 --pmc result of this kernel
         tpath = os.path.join(ROOT, "profiles", f"{tag}_ntt_traffic.json")
         if not os.path.exists(tpath):
             continue
@@ -131,30 +143,39 @@ def ntt_roofline(ctx, iters=10):
             traffic_src = (f"profiles/{tag}_ntt_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/ntt_pmc.py), calibrated on known "
                            "8-B/lane streams; GB per transform")
             break
-    # why the fraction is what it is: the kernel is integer-VALU bound, not bandwidth bound (the committed rocprofv3 --pmc SQ pass of one proof)
-    alu = None
-    ppath = os.path.join(ROOT, "profiles", "r02_pmc_valu_by_kernel.json")
+    # the two launches of this transform, and what the committed profiler runs of the SAME instantiations say (read, not embedded)
+    kernels = [f"k_ntt3<0, 0, {NTT_LOG_N - 12}, 0>", "k_ntt3<0, 0, 12, 0>"] if 16 <= NTT_LOG_N <= 20 else ["k_ntt3 / k_ntt_tile"]
+    rocprof = None
+    spath = os.path.join(ROOT, "profiles", "r03_ntt_kernel_stats.csv")
+    if os.path.exists(spath):
+        import csv
+
+        rows = [r for r in csv.DictReader(open(spath)) if "k_ntt" in r.get("Name", "")]
+        if rows:
+            rocprof = {"source": "profiles/r03_ntt_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this shape, tools/r03_ntt_probe.sh)",
+                       "avg_ms_per_launch": {r["Name"].replace("void ", "").split("(")[0]: round(float(r["AverageNs"]) / 1e6, 4) for r in rows}}
+            rocprof["avg_ms_per_transform"] = round(sum(rocprof["avg_ms_per_launch"].values()), 4)
+    issue = None
+    ppath = os.path.join(ROOT, "profiles", "r03_ntt_sq_new.json")
     if os.path.exists(ppath):
-        k = json.load(open(ppath)).get("k_ntt_tile<1, 0>")
-        if k:
-            alu = {"valu_active_per_wave_cycle": k["SQ_ACTIVE_INST_VALU/WAVE_CYCLES"], "waves_per_simd": 3,
-                   "valu_issue_utilisation_per_simd": round(3 * k["SQ_ACTIVE_INST_VALU/WAVE_CYCLES"], 2),
-                   "note": "three waves per SIMD each issue a VALU instruction in 0.31 of their cycles: the SIMD's VALU port is busy ~0.93 of the time; "
-                           "HBM traffic is 2.0x algorithmic with no re-reads, so fewer instructions per butterfly, not fewer bytes, would raise the fraction",
-                   "source": "profiles/r02_pmc_valu_by_kernel.json (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, rocprofv3 --pmc)"}
+        sq = json.load(open(ppath))
+        issue = {"source": "profiles/r03_ntt_sq_new.json (rocprofv3 --pmc SQ counters of this shape, tools/r03_ntt_pmc.sh)",
+                 "by_kernel": {k: {q: v[q] for q in ("valu_insts_per_wave", "valu_issue_util_per_simd", "SQ_ACTIVE_INST_VALU/WAVE_CYCLES", "SQ_WAIT_ANY/WAVE_CYCLES",
+                                                       "SQ_WAIT_INST_ANY/WAVE_CYCLES") if q in v} for k, v in sq.items() if "k_ntt" in k}}
     return {
-        "bound": "hbm", "alu_bound_evidence": alu, "kernel": "k_ntt_tile<0, 0>", "rocprof_stats": "profiles/r02_ntt_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this shape: 3.10 ms average per launch)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "bound": "hbm", "kernel": " + ".join(kernels), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "per": f"one forward NTT of 2^{NTT_LOG_N} x {NTT_COLS} columns = {launches} launches, {alg_bytes / 1e9:.3f} GB algorithmic (16*n*c)",
         "ms_per_transform": round(ms, 4), "ms_per_launch": round(ms / launches, 4), "ms_per_transform_groups": [round(g, 4) for g in groups],
+        "rocprof_stats": rocprof, "issue_counters": issue,
     }
 
 
-def poseidon_roofline(ctx, vx, iters=3):
+def poseidon_roofline(ctx, vx, log_leaves, iters=3):
     """The proof's dominant kernel, k_hash_leaves (Poseidon sponge over the rows of the trace LDE), on the shape of the
-    main-trace commitment of this workload: 2^20 leaves x 745 columns.  Integer-ALU work: priced against the VALU-issue
+    main-trace commitment of this workload: 2^(log rows + 1) leaves x 745 columns.  Integer-ALU work: priced against the VALU-issue
     peak of the permutation code (instruction count x issue cycles, see below), and its HBM fraction beside it."""
-    log_leaves, cols = (20 if N_HEADERS == 256 else 21), 745
+    cols = 745
     n = 1 << log_leaves
     buf = ctx.alloc(n * cols)
     ctx.fill_random(buf, n * cols, 11)
@@ -287,12 +308,16 @@ def main():
                     help="256 = BASELINE.json configs[1] (the headline metric, default); 512 = configs[2]/[5]")
     ap.add_argument("--inflight", type=int, default=0,
                     help="proofs in flight per GPU (contexts + host threads; steps are handed out from one queue). Default: 4")
+    ap.add_argument("--profile", default="P15k", choices=("P15k", "Pmax", "Pmix"),
+                    help="header sizes (SURVEY.md section 8d): P15k = every header 15,360 B (the headline, default); Pmax = every header MAX_HEADER_SIZE = "
+                         "35,840 B, the capacity the reference circuit always pays for (circuits/consts.rs:9-16); Pmix = uniform in [512, 35840]")
+    ap.add_argument("--no-pmax", action="store_true", help="skip the extra Pmax measurement of the default line")
     ap.add_argument("--circuit", default="header_range", choices=("header_range", "rotate"),
                     help="header_range = the headline metric (default); rotate = BASELINE.json configs[3]")
     ap.add_argument("--dry-launch", action="store_true", help="rehearse the multi-rank launch on CPU (gloo), no GPU work")
     args = ap.parse_args()
-    global N_HEADERS
-    N_HEADERS = args.headers
+    global N_HEADERS, PROFILE
+    N_HEADERS, PROFILE = args.headers, args.profile
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ:
@@ -324,7 +349,7 @@ def main():
     vx = vx_import.load()
     # measured with GPU_MAX_HW_QUEUES=16 (set by the library): 7.76 / 7.86 / 7.93 / 7.92 proofs/s with 3 / 4 / 5 / 6 in flight (every proof already
     # runs its five tables on five streams); with the runtime's default of 4 hardware queues 7.26 / 7.22 with 3 / 4
-    inflight = args.inflight or 4
+    inflight = args.inflight or (4 if PROFILE == "P15k" else 2)  # a Pmax proof holds 4x the memory of a P15k one
     inflight = max(1, min(inflight, args.steps))
     # `inflight` proofs are proven concurrently on this GPU: each worker thread owns a context (stream, pool) and an
     # input resident in HBM and takes the next step from a shared counter, so the tail of one proof (FRI layers, host
@@ -408,8 +433,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
+        gathered_ok = None
         if gathered is not None:
             assert len(gathered) == world and all(g.size == blob.size for g in gathered)
+            if args.circuit == "header_range":
+                # (outside the timed region) every rank's blob is a proof of THAT rank's input: rank r proved the chain of seed + r
+                import hashlib
+
+                digests = set()
+                for r, g in enumerate(gathered):
+                    ch_r = wl.chain if r == rank else vx.synth.Chain(N_HEADERS, profile=PROFILE, seed=vx.synth.CHAIN_SEED + r)
+                    words = np.ascontiguousarray(g).view(np.uint64)
+                    out_r = words[4:16].tobytes()
+                    assert out_r == ch_r.expected_outputs(N_HEADERS), f"rank {r}: public outputs differ from the native mirror"
+                    vx.lib.header_range_verify(words, N_HEADERS, ch_r.trusted_block, ch_r.trusted_hash, ch_r.target_block, out_r, wl.cfg,
+                                               authority_set_hash=wl.just.sh.tobytes() if wl.just is not None else None,
+                                               authority_set_id=wl.just.struct.authority_set_id if wl.just is not None else 0)
+                    digests.add(hashlib.sha256(words.tobytes()).hexdigest())
+                assert len(digests) == world, "ranks proved the same input"
+                gathered_ok = {"verified": world, "distinct": len(digests)}
         wl.check(res)
         roof = ntt_roofline(ctx)
         # single-proof latency: a few steps with ONE proof in flight (value above is throughput with `inflight` in flight)
@@ -418,19 +460,60 @@ def main():
             wl.step()
         ctx.sync()
         latency_ms = 1e3 * (time.perf_counter() - t1) / 2
+        LOG_ROWS = None
+        if args.circuit == "header_range":
+            comps = sum((int(z) + 127) // 128 for z in wl.chain.sizes)
+            LOG_ROWS = max(16, (16 * comps - 1).bit_length())  # 16 rows per compression, padded to a power of two
+        pose = poseidon_roofline(ctx, vx, LOG_ROWS + 1) if args.circuit == "header_range" else None
+        pmax = None
+        if args.circuit == "header_range" and PROFILE == "P15k" and N_HEADERS == 256 and not args.no_pmax and world == 1:
+            # the reference circuit's fixed capacity: every header padded to MAX_HEADER_SIZE (circuits/consts.rs:9-16, 71,680 compressions):
+            # the same step on a Pmax chain, two proofs in flight, after (outside) the timed region.  A Pmax proof holds 4x the
+            # memory of a P15k one: the P15k inputs and the pools of the other contexts are given back first
+            k = min(2, inflight)
+            for w in wls:
+                w.free()
+            for c in ctxs[k:]:
+                c.close()
+            pw = [Workload(vx, ctxs[i], seed_offset=rank, profile="Pmax") for i in range(k)]
+            for w in pw:  # warm-up: pool blocks of the larger shapes
+                w.step()
+
+            def two(w):
+                w.step()
+                w.step()
+
+            for c in ctxs[:k]:
+                c.sync()
+            t2 = time.perf_counter()
+            ths = [threading.Thread(target=two, args=(w,)) for w in pw]
+            for t_ in ths:
+                t_.start()
+            for t_ in ths:
+                t_.join()
+            for c in ctxs[:k]:
+                c.sync()
+            dt = time.perf_counter() - t2
+            res_p = pw[0].step()
+            assert res_p[0] == pw[0].chain.expected_outputs(N_HEADERS), "Pmax public outputs differ from the native mirror"
+            pmax = {"value": round(2 * k / dt, 4), "unit": "proofs/s", "ms_per_step": round(1e3 * dt / (2 * k), 2), "inflight": k, "steps": 2 * k,
+                    "workload": f"header_range_{N_HEADERS} with every header MAX_HEADER_SIZE = 35,840 B (Pmax): 71,680 Blake2b compressions, hash-chain table 2^21 rows -- "
+                                "what the reference circuit always pays for (circuits/consts.rs:9-16); the P15k headline is NOT the circuit's worst case"}
+            for w in pw:
+                w.free()
         line = {
             "metric": f"header_range_{N_HEADERS} proofs/sec", "value": round(world * args.steps / elapsed, 4), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks) / u8 (hashes)",
-            "data": "synthetic", "inflight_per_gpu": inflight, "latency_ms": round(latency_ms, 2), "gather": gather_kind,
+            "data": "synthetic", "inflight_per_gpu": inflight, "latency_ms": round(latency_ms, 2), "gather": gather_kind, "gathered_blobs": gathered_ok,
             "proof_scope": "every statement of HeaderRangeCircuit is inside a STARK: all 96 public output bytes (Blake2b header-chain table + SHA-256 Merkle table "
                            "of the state / data roots), the authority-set commitment, and the justification -- floor(2n/3)+1 = 201 Ed25519 signatures over the precommit of "
                            "the target header (curve table + SHA-512 table), bound to the committed keys; five tables on one logUp bus under shared challenges. "
                            "NOT done: the five STARKs are not aggregated into one succinct proof (no recursion / Groth16 wrap), and the reference's MapReduce "
                            "sub-proof structure is replaced by flat tables",
             "config": {
-                "workload": f"header_range_{N_HEADERS}: {N_HEADERS} x 15,360-B synthetic Avail headers (P15k), 300 authorities, one input per GPU; "
-                            f"{120 * N_HEADERS:,} Blake2b compressions -> BlakeChainAir (byte-lookup AIR) trace 2^{19 if N_HEADERS == 256 else 20} rows x (745 main + 276 logUp) columns + ShaTreeAir (SHA-256 Merkle table, 2^{16 if N_HEADERS == 256 else 17} x 428) "
+                "workload": f"header_range_{N_HEADERS}: {N_HEADERS} x {'15,360-B' if PROFILE == 'P15k' else '35,840-B' if PROFILE == 'Pmax' else '512..35,840-B'} synthetic Avail headers ({PROFILE}), 300 authorities, one input per GPU; "
+                            f"{sum((int(z) + 127) // 128 for z in wl.chain.sizes):,} Blake2b compressions -> BlakeChainAir (byte-lookup AIR) trace 2^{LOG_ROWS} rows x (745 main + 276 logUp) columns + ShaTreeAir (SHA-256 Merkle table, 2^{16 if N_HEADERS == 256 else 17} x 428) "
                             "+ ShaChainAir (2^16 x 418) + EdAir (201 signatures, 2^16 x 1527) + Sha512Air (2^15 x 805) on the same logUp bus",
                 "complete_proof": False,
                 "complete_statement": True,
@@ -449,13 +532,15 @@ def main():
             },
             "roofline": roof,
         }
+        if pmax:
+            line["pmax"] = pmax
         if args.circuit == "header_range":
-            line["roofline_poseidon"] = poseidon_roofline(ctx, vx)
+            line["roofline_poseidon"] = pose
         if args.circuit == "header_range":
             # SURVEY 8d "whole proof" figure: compulsory (algorithmic) bytes of every streaming stage of the BlakeChainAir
             # proof over the time of a step -- trace written 8nc, LDE 8nc(1+2^r), leaf hashing 8Nc, quotient 16Nc,
             # openings 8nc, FRI combine 8Nc (N = 2n, r = 1); the small ShaChainAir proof and FRI tail are left out
-            n_rows = float(1 << (19 if N_HEADERS == 256 else 20))
+            n_rows = float(1 << LOG_ROWS)
             alg = 8 * n_rows * BLAKE_COLS * (1 + 3 + 2 + 4 + 1 + 2)
             line["proof_roofline"] = {"bound": "hbm", "algorithmic_GB": round(alg / 1e9, 1), "achieved": round(alg / 1e9 / (elapsed / args.steps), 1),
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / 1e9 / (elapsed / args.steps) / HBM_PEAK_GBS, 4),
@@ -471,7 +556,7 @@ def main():
                            "verify_epoch_end_header (native on GPU: prefix, 300 x (pubkey, weight), delay)",
                            "two ShaChainAir witnesses + STARKs: current and new authority-set commitments (2^16 x 418 each)",
                            "the justification by the current set in-proof: EdAir (201 signatures, 2^16 x 1527) + Sha512Air (2^15 x 805) on one logUp bus with the current set's commitment"],
-                "missing": ["epoch-end header parsing inside a STARK", "recursive aggregation into one proof"],
+                "missing": ["recursive aggregation of the six STARKs into one proof"],
             }
         elif not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline(vx, ctx)

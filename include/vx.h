@@ -159,8 +159,10 @@ typedef struct vx_stark_config {
     int32_t final_poly_bits;
 } vx_stark_config;
 /* AIRs are COMPILED INTO the library (there is no run-time AIR descriptor): 1 Fibonacci and 2 "cubic mixer" pin the
- * generic prover, 5 is the smallest AIR with an auxiliary (lookup / logUp) commitment round; 3 / 4 below are the
- * Blake2b header-chain and SHA-256 authority-commitment AIRs of the header_range statement. */
+ * generic prover, 5 is the smallest AIR with an auxiliary (lookup / logUp) commitment round.  The tables of the
+ * header_range / rotate statements, each declared with its trace generator below: 6 Blake2b header chain
+ * (VX_AIR_BLAKE_CHAIN), 4 SHA-256 authority-set commitment (VX_AIR_SHA_CHAIN), 7 / 8 / 9 SHA-256 Merkle trees of 256 /
+ * 512 / 16 leaves, 10 / 12 Ed25519 (2^17 / 2^16 rows), 11 / 14 / 13 SHA-512 (2^16 / 2^15 / 2^10 rows), 15 epoch-end log. */
 enum { VX_AIR_FIBONACCI = 1, VX_AIR_MIX = 2, VX_AIR_LOOKUP = 5 };
 int32_t vx_stark_default_config(vx_stark_config* cfg);
 /* K5: batched constraint / quotient-polynomial evaluation (starky prover.rs compute_quotient_polys) for an AIR compiled
@@ -248,7 +250,7 @@ enum { VX_AIR_SHA512 = 11, VX_AIR_SHA512_10 = 13, VX_AIR_SHA512_15 = 14, VX_SHA5
 int32_t vx_sha512_trace(vx_ctx* ctx, const uint8_t* pubkeys, const uint8_t* signatures, const uint8_t* message, uint32_t message_len, const uint8_t* signed_flags,
                         size_t n_signatures, int log_n, uint32_t bus_on, vx_buf* trace_out, uint64_t public_inputs_out[15]);
 
-/* ---- K9: EpochEndAir trace generation (verify_epoch_end_header in-proof, circuits/builder/rotate.rs:74-276): the
+/* ---- K8: EpochEndAir trace generation (verify_epoch_end_header in-proof, circuits/builder/rotate.rs:74-276): the
  * ScheduledChange log of the epoch-end header -- consensus flag 4, "FRNK", a SCALE compact length, flag 1, the compact
  * number of new authorities, num_authorities records (32-byte key, weight 1 as u64 LE), a zero u32 delay -- starting at byte
  * start_position + 1 of `header` (resident in HBM), one row per record in a 512-row table.  The table RECEIVES those bytes
@@ -302,11 +304,16 @@ int32_t vx_verify_simple_justification(vx_ctx* ctx, uint32_t block_number, const
                                        const uint8_t* validator_signed, uint32_t num_authorities, uint32_t max_authorities);
 
 /* ---- top level: HeaderRangeCircuit::prove (circuits/header_range.rs:26-59 via Circuit::prove, :167).
- * Inputs as vx_verify_subchain.  Output blob (uint64 words): "HRRANGE3", max_headers, trusted_block,
- * target_block, the 96 public output bytes (12 words), the two proof lengths, then the BlakeChainAir
- * STARK proof and (when a justification was given) the ShaChainAir proof of the authority-set commitment.
- * What the blob proves today is listed in DESIGN.md section 2 (the justification / Merkle-root /
- * numbering gadgets are checked natively by vx_verify_subchain but not yet inside a STARK). */
+ * Inputs as vx_verify_subchain.  Output blob (uint64 words), VX_HR_BLOB_HEADER_WORDS = 22 header words: the magic "HRRANGE5"
+ * (VX_HR_BLOB_MAGIC), max_headers, trusted_block, target_block, the 96 public output bytes (12 words), the lengths of the
+ * VX_HR_BLOB_TABLES = 5 proofs (words 16..20) and the round of the precommit (word 21); then the proofs in blob order: hash
+ * chain (BlakeChainAir), authority-set commitment (ShaChainAir), SHA-256 Merkle trees (ShaTreeAir), Ed25519 (EdAir), SHA-512
+ * (Sha512Air) -- the last three and the second are empty when no justification was given.  EVERY statement of the circuit is
+ * inside these STARKs: the five tables share one logUp bus under challenges drawn after all their trace
+ * caps; the Merkle table's public inputs are the two roots and the number of headers, which forces it to take every header's
+ * roots from the bus.  Not done: the five proofs are not aggregated into one succinct proof. */
+#define VX_HR_BLOB_MAGIC 0x3545474e41525248ULL /* "HRRANGE5" little-endian */
+enum { VX_HR_BLOB_HEADER_WORDS = 22, VX_HR_BLOB_TABLES = 5 };
 /* The justification witness of circuits/vars.rs:40-46 (host buffers; what HintSimpleJustification
  * returns, justification.rs:69-82) plus the two EVM inputs it is checked against. */
 typedef struct vx_justification {

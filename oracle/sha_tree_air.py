@@ -12,7 +12,10 @@ Rows: a node takes 128 rows -- a DATA compression of l || r (start state IV) and
 children 2g, 2g+1, leaves N..2N-1, slot 0 = a dummy).  The compression rows are ShaChainAir's (oracle/sha_air.py:
 bit-decomposed, one round per row, same column layout); everything positional (which rows load message words, node
 ids, which tree) is a PERIODIC column, so the only witness besides the SHA rows is the pair of leaf-enable flags
-ENL / ENR of a bottom-level node: a disabled leaf must be zero and takes nothing from the bus.
+ENL / ENR of a bottom-level node (a disabled leaf must be zero and takes nothing from the bus) and their running count
+CNT.  The flags are forced: boolean, constant over a node, non-increasing in leaf order, and their count over each tree
+equals public input 16 (the number of headers, which the verifier sets to target_block - trusted_block) -- leaf i is
+enabled exactly when i < n, so every header's roots MUST be taken from the bus.
 Bus (tuples (t0, t1, t2, t3, tag), see blake_air): row r < 16 of a DATA block receives message word r --
   inner nodes:                  (tree, child id, r mod 8, word)                          [words, from the children's PAD blocks]
   bottom level of both trees:   (leaf, 4 (r mod 8) + q, byte q of the word, tree)  q = 0..3  [bytes, from the header bytes]
@@ -30,13 +33,14 @@ from .blake_air import TAG_BYTE, TAG_WORD
 
 P = H.P
 IDS = {256: 7, 512: 8, 16: 9}
-ENL, ENR = H.DG0, H.DG0 + 1  # the chain AIR's digest-register columns are free here
+ENL, ENR, CNT = H.DG0, H.DG0 + 1, H.DG0 + 2  # the chain AIR's digest-register columns are free here
 COLS = H.COLS
 N_HELP = 8  # 7 helper elements (13 lookups) + running sum
-AUX, CHAL, AUXPUB, PUB = 2 * N_HELP, 4, 1, 16
-# periodic columns
-P_SEL0, P_SEL63, P_SCHED, P_K, P_DATA, P_TREE, P_PWA, P_PBL, P_PBR, P_CID, P_JJ, P_PS, P_ROOT, P_GID = range(14)
-PERIODIC = 14
+AUX, CHAL, AUXPUB, PUB = 2 * N_HELP, 4, 1, 17
+# periodic columns; P_NB / P_BB / P_LASTN sit on the last row of a node: the next node is a bottom-level node / this node
+# and the next both are / this is the last node of its tree
+P_SEL0, P_SEL63, P_SCHED, P_K, P_DATA, P_TREE, P_PWA, P_PBL, P_PBR, P_CID, P_JJ, P_PS, P_ROOT, P_GID, P_NB, P_BB, P_LASTN = range(17)
+PERIODIC = 17
 
 
 def make_air(N):
@@ -67,11 +71,14 @@ def make_air(N):
         out[P_PS] = (send & (g >= 2)).astype(np.int64).tolist()
         out[P_ROOT] = (send & (g == 1)).astype(np.int64).tolist()
         out[P_GID] = (g * send).tolist()
+        out[P_NB] = (send & (g + 1 >= N // 2) & (g + 1 < N)).astype(np.int64).tolist()
+        out[P_BB] = (send & (g >= N // 2) & (g + 1 < N)).astype(np.int64).tolist()
+        out[P_LASTN] = (send & (g == N - 1)).astype(np.int64).tolist()
         return out
 
     class ShaTreeAir:
         ID, TREE_SIZE = IDS[N], N
-        PERIOD_LOGS = [6, 6, 6, 6, 7] + [L] * 9
+        PERIOD_LOGS = [6, 6, 6, 6, 7] + [L] * 12
 
         @staticmethod
         def lookups(loc, per):
@@ -122,6 +129,19 @@ def make_air(N):
             w0 = val(loc, H.W0B)
             c.constraint(per[P_PBL] * (1 - loc[ENL]) * w0)
             c.constraint(per[P_PBR] * (1 - loc[ENR]) * w0)
+            # ---- 8b. the leaf-enable flags are forced: leaf i of either tree is enabled exactly when i < pub[16]
+            enl, enr = loc[ENL], loc[ENR]
+            end = per[P_SEL63] * (1 - is_data)
+            keep = 1 - end
+            c.constraint(enl * (enl - 1))
+            c.constraint(enr * (enr - 1))
+            c.constraint(enr * (1 - enl))
+            c.constraint(keep * (nxt[ENL] - enl))
+            c.constraint(keep * (nxt[ENR] - enr))
+            c.constraint(keep * (nxt[CNT] - loc[CNT]))
+            c.constraint(per[P_BB] * nxt[ENL] * (1 - enr))
+            c.constraint(end * (nxt[CNT] - loc[CNT]) + per[P_LASTN] * loc[CNT] - per[P_NB] * (nxt[ENL] + nxt[ENR]))
+            c.constraint(per[P_LASTN] * (loc[CNT] - pub[16]))
             # ---- 9. the bus (logUp): helpers and running sum of the local row
             ds = ShaTreeAir.denominators(loc, per, chal)
             hsum = None
@@ -194,14 +214,14 @@ def tree_nodes(leaves, N):
 
 
 def gen_trace(state_roots, data_roots, N):
-    """Trace [COLS][256 N] and the 16 public inputs (both roots as big-endian words)."""
+    """Trace [COLS][256 N] and the 17 public inputs (both roots as big-endian words, the number of leaves)."""
     n = 256 * N
     tr = np.zeros((COLS, n), dtype=np.uint64)
     words = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "big") for j in range(len(b) // 4)]  # noqa: E731
 
     def fill_block(base, h_in, block, en):
         out = H.fill_block(tr, base, h_in, block)
-        tr[ENL, base: base + 64], tr[ENR, base: base + 64] = en
+        tr[ENL, base: base + 64], tr[ENR, base: base + 64], tr[CNT, base: base + 64] = en
         return out
 
     pub = []
@@ -211,11 +231,12 @@ def gen_trace(state_roots, data_roots, N):
         for g in range(N):
             base = 128 * (t * N + g)
             msg = nodes[2 * g] + nodes[2 * g + 1] if g >= 1 else bytes(64)
-            en = (0, 0)
+            en = (0, 0, 0)
             if g >= N // 2:
-                en = (int(2 * g - N < len(leaves)), int(2 * g - N + 1 < len(leaves)))
+                en = (int(2 * g - N < len(leaves)), int(2 * g - N + 1 < len(leaves)), min(2 * g - N + 2, len(leaves)))
             mid = fill_block(base, list(H.IV), words(msg), en)
             out = fill_block(base + 64, mid, list(H.PAD64), en)
             if g >= 1:
                 assert b"".join(x.to_bytes(4, "big") for x in out) == nodes[g]
-    return tr, pub
+    assert len(state_roots) == len(data_roots)
+    return tr, pub + [len(state_roots)]

@@ -74,3 +74,21 @@ def test_loading_the_library_raises_the_hardware_queue_limit():
     code2 = code.replace("os.environ.pop('GPU_MAX_HW_QUEUES', None)", "os.environ['GPU_MAX_HW_QUEUES'] = '7'")
     out = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, check=True).stdout
     assert out.strip() == "b'7'", out  # a host's own value is kept
+
+
+def test_blob_format_named_in_the_header_is_the_bindings(vx):
+    """include/vx.h is the boundary: the blob magic, header length and table count it states are the ones the binding splits
+    blobs by (the header still described "HRRANGE3" with two proofs)."""
+    text = open(os.path.join(ROOT, "include", "vx.h")).read()
+    magic = int(re.search(r"#define VX_HR_BLOB_MAGIC (0x[0-9a-fA-F]+)ULL", text).group(1), 16)
+    hdr = int(re.search(r"VX_HR_BLOB_HEADER_WORDS = (\d+)", text).group(1))
+    tables = int(re.search(r"VX_HR_BLOB_TABLES = (\d+)", text).group(1))
+    assert magic == vx.lib.HR_MAGIC and magic.to_bytes(8, "little") == b"HRRANGE5" and b"HRRANGE5".decode() in text
+    assert "HRRANGE3" not in text
+    import numpy as np
+
+    blob = np.zeros(hdr + 15, dtype=np.uint64)
+    blob[0] = magic
+    blob[16:16 + tables] = [1, 2, 3, 4, 5]
+    parts = vx.lib.split_blob(blob)
+    assert len(parts) == tables and [len(p) for p in parts] == [1, 2, 3, 4, 5]  # blob order: hash chain, commitment, Merkle, Ed25519, SHA-512

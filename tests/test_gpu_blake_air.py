@@ -167,7 +167,8 @@ def test_header_range_prove_end_to_end(ctx, vx, oracle):
     ia, ib = oracle_verify_blob(vx, blob, ocfg, 16)
     assert all(vx.lib.split_blob(blob)[k].size == 0 for k in (1, 3, 4))
     assert ia["public_inputs"] == limbs(ch.trusted_hash) + limbs(out96[:32]) + [ch.trusted_block + 1, ch.target_block, 16, 1]
-    assert ib["public_inputs"] == [int.from_bytes(out96[32 + 4 * j: 36 + 4 * j], "big") for j in range(16)]  # ALL 96 output bytes are public inputs of a proof
+    # ALL 96 output bytes are public inputs of a proof; the Merkle table's 17th is the number of headers, which forces its leaf flags
+    assert ib["public_inputs"] == [int.from_bytes(out96[32 + 4 * j: 36 + 4 * j], "big") for j in range(16)] + [ch.target_block - ch.trusted_block]
     # with a justification: accepted when > 2/3 signed the target, refused otherwise
     good = vx.lib.PackedJustification(vx.synth.Justification(ch.target_block, ch.target_hash, n_auth=9, n_signed=7), 12)
     o2, b2 = ctx.header_range_prove(ctx.from_host(ch.headers), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg, just=good)
@@ -301,4 +302,66 @@ def test_full_size_header_range(ctx, vx, n_headers, profile):
         vx.lib.header_range_verify(bad, n_headers, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg)
     _, again = ctx.header_range_prove(hb, ch.stride, ch.sizes, n_headers, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
     assert (again == first).all()
+    hb.free()
+
+
+@pytest.mark.parametrize("n_headers", [256, 512])
+def test_full_size_justified_header_range(ctx, vx, n_headers):
+    """The BENCHMARKED step in the test tier: header_range_256 / _512 on a P15k chain WITH the 300-authority
+    justification -- five tables, the 2^19 / 2^20-row hash chain, 201 signatures in-proof (reference shape:
+    circuits/header_range.rs:234-239, 300 x 256).  Too big for the Python prover, so: outputs equal the hashlib mirror, the
+    product's host verifier accepts, two runs give identical bytes, every table's public inputs are what the request implies,
+    and the negatives hold at this size -- a flipped key byte is refused as a statement error before proving, an Ed25519 proof
+    transplanted from another authority set, a blob for another set hash / set id / range, and any flipped word are rejected."""
+    ch = vx.synth.Chain(n_headers, profile="P15k")
+    hb = ctx.from_host(ch.headers)
+    cfg = ctx.stark_config()
+    sj = vx.synth.Justification(ch.target_block, ch.target_hash)
+    just = vx.lib.PackedJustification(sj)
+    args = (hb, ch.stride, ch.sizes, n_headers, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
+    out96, blob = ctx.header_range_prove(*args, just=just)
+    first = blob.copy()
+    assert out96 == ch.expected_outputs(n_headers)
+    ver = dict(authority_set_hash=sj.authority_set_hash, authority_set_id=sj.set_id)
+    vx.lib.header_range_verify(first, n_headers, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg, **ver)
+    _, again = ctx.header_range_prove(*args, just=just)
+    assert (again == first).all()  # deterministic: smallest PoW nonce, fixed transcript order of the five tables
+    # per-table public inputs
+    parts = vx.lib.split_blob(first)
+    assert all(p.size for p in parts)
+    pub = [[int(x) for x in S.proof_peek(p, 4)[0]] for p in parts]
+    words = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "big") for j in range(len(b) // 4)]  # noqa: E731
+    assert pub[0] == limbs(ch.trusted_hash) + limbs(out96[:32]) + [ch.trusted_block + 1, ch.target_block, n_headers, 1]
+    assert pub[2] == words(out96[32:]) + [n_headers]                        # both Merkle roots and the forced leaf count
+    assert pub[1][:8] == words(sj.authority_set_hash) and pub[1][8:] == [300, 1]   # the commitment of n = 300 keys
+    assert pub[3] == [201, 1]                                                 # k = floor(2n/3) + 1 signatures verified: 201 * 3 > 300 * 2
+    assert pub[4][14] == 1 and len(pub[4]) == 15
+    # negatives
+    with pytest.raises(vx.VxError):
+        vx.lib.header_range_verify(first, n_headers, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg, authority_set_hash=bytes(32), authority_set_id=sj.set_id)
+    with pytest.raises(vx.VxError):
+        vx.lib.header_range_verify(first, n_headers, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg, authority_set_hash=sj.authority_set_hash, authority_set_id=sj.set_id + 1)
+    with pytest.raises(vx.VxError):
+        vx.lib.header_range_verify(first, n_headers, ch.trusted_block, ch.trusted_hash, ch.target_block - 1, out96, cfg, **ver)
+    for where in (30, first.size // 5, first.size // 2, first.size - 100):
+        bad = first.copy()
+        bad[where] ^= np.uint64(1 << 17)
+        with pytest.raises(vx.VxError):
+            vx.lib.header_range_verify(bad, n_headers, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg, **ver)
+    # one byte of a signed authority's key flipped in the witness: the statement does not hold (commitment / signature), nothing is proven
+    forged = vx.lib.PackedJustification(sj)
+    forged.pk[32 * 7 + 3] ^= 1
+    with pytest.raises(vx.VxError) as e:
+        ctx.header_range_prove(*args, just=forged)
+    assert e.value.code == -5  # VX_ERR_STATEMENT
+    # the Ed25519 table of ANOTHER authority set (valid for its own keys and the same precommit bytes up to the set) does not fit this blob
+    other = vx.synth.Justification(ch.target_block, ch.target_hash, seed=vx.synth.JUST_SEED + 1)
+    _, blob2 = ctx.header_range_prove(*args, just=vx.lib.PackedJustification(other))
+    parts2 = vx.lib.split_blob(blob2)
+    vx.lib.header_range_verify(blob2, n_headers, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg, authority_set_hash=other.authority_set_hash, authority_set_id=other.set_id)
+    hdr = first[:vx.lib.HR_HDR].copy()
+    hdr[16 + 3] = parts2[3].size
+    graft = np.concatenate([hdr, parts[0], parts[1], parts[2], parts2[3], parts[4]])
+    with pytest.raises(vx.VxError):
+        vx.lib.header_range_verify(graft, n_headers, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg, **ver)
     hb.free()

@@ -168,3 +168,99 @@ def test_keys_between_commitment_and_curve_tables_balance(ed):
     # an unsigned authority's key is not sent, and a slot cannot claim it
     bad = [dict(s) for s in ed["sigs"]]
     assert [s["idx"] for s in bad] == [0, 1, 3, 4]
+
+
+def _total(lookups):
+    beta, gamma = ExtS(CHAL[0], CHAL[1]), ExtS(CHAL[2], CHAL[3])
+    g2 = gamma * gamma
+    g3, g4 = g2 * gamma, g2 * g2
+    acc = ExtS(0)
+    for m, tag, tup in lookups:
+        if m % P:
+            acc = acc + (beta + tup[0] + gamma * tup[1] + g2 * tup[2] + g3 * tup[3] + g4 * tag).inv() * (m % P)
+    return acc
+
+
+def _ed_bus(tr, pub, n_slots, tags):
+    per_e = E.periodic_values(1 << 16)
+    out = []
+    for s in range(n_slots):
+        for r in (0, 1, 255):
+            i = 256 * s + r
+            out += [lk for lk in E.bus_lookups([int(tr[j, i]) for j in range(E.COLS)], [v[i % len(v)] for v in per_e], pub) if lk[1] in tags]
+    return out
+
+
+def test_paired_mutations_of_the_key_bus(ed):
+    """mutations that change BOTH sides of a bus consistently -- the case bus balance cannot see.
+    Keys (commitment table -> curve table): (a) dropping a signer on both sides is a consistent statement about fewer signers: the
+    published count k drops, and with it the 2/3 threshold the verifier checks from the public inputs; (b) verifying one authority
+    twice needs its key sent twice, i.e. a non-boolean 'signed' flag: a constraint of the commitment table; (c) a slot that takes
+    its key from nowhere unbalances the bus."""
+    from oracle import sha_air as A
+
+    n_auth = 5
+    keys = [pyref.ed25519_public(bytes([i + 1]) * 32) for i in range(n_auth)]
+
+    def chain_sends(signed):
+        tr, pub, _ = A.gen_trace(keys, 10, signed=signed, bus_on=1)
+        per_c = A.chain_periodic_values()
+        return tr, pub, [A.key_lookup([int(tr[j, i]) for j in range(A.CHAIN_COLS)], [v[i % 64] for v in per_c], pub) for i in range(1 << 10) if i % 64 < 16]
+
+    # (a) authority 3 dropped on both sides
+    sigs3 = [s for s in ed["sigs"] if s["idx"] != 3]
+    tr_e, pub_e = E.gen_trace(sigs3, 16)
+    _, pub_c, sends = chain_sends([i not in (2, 3) for i in range(n_auth)])
+    t = _total(sends) + _total(_ed_bus(tr_e, pub_e, len(sigs3), (E.TAG_KEY,)))
+    assert (t.a, t.b) == (0, 0)                                    # consistent: the bus balances ...
+    assert pub_e[0] == 3 and pub_c[8] == n_auth and not pub_e[0] * 3 > pub_c[8] * 2  # ... for k = 3 of 5, which is no quorum
+    # (b) authority 0 verified in two slots: the receives need SGC = 2 on its block
+    twice = [dict(s) for s in ed["sigs"][:2]] + [dict(ed["sigs"][0])]
+    tr_e2, pub_e2 = E.gen_trace(twice, 16)
+    tr_c, pub_c2, _ = chain_sends([i in (0, 1) for i in range(n_auth)])
+    forged = tr_c.copy()
+    forged[A.SGC, 0:64] = 2
+    per_c = A.chain_periodic_values()
+    sends2 = [A.key_lookup([int(forged[j, i]) for j in range(A.CHAIN_COLS)], [v[i % 64] for v in per_c], pub_c2) for i in range(1 << 10) if i % 64 < 16]
+    t = _total(sends2) + _total(_ed_bus(tr_e2, pub_e2, 3, (E.TAG_KEY,)))
+    assert (t.a, t.b) == (0, 0)                                    # the totals cancel with a multiplicity of two ...
+    aux_c, apub_c = A.ShaChainAir.gen_aux(forged, CHAL, pub_c2)
+    assert S.check_trace(A.ShaChainAir, forged, pub_c2, CHAL, aux_c, apub_c, rows=(0, 64)) is not None  # ... which the boolean flag forbids
+    # (c) a signed slot without a sender
+    _, _, sends3 = chain_sends([i in (0, 1) for i in range(n_auth)])
+    t = _total(sends3) + _total(_ed_bus(ed["tr"], ed["pub"], 4, (E.TAG_KEY,)))
+    assert (t.a, t.b) != (0, 0)
+
+
+def test_paired_mutations_of_the_digest_bus(ed):
+    """R || A and H between the curve table and the SHA-512 table: a slot of the hash table that is switched off (no receive, no
+    send -- one flag drives both, so it cannot hash bytes of its own choosing) leaves the curve table's slot without its digest;
+    switching the curve slot off as well is a consistent statement about one signature fewer (the count k is public)."""
+    ts, pubs, _ = H.gen_trace(ed["slots"], MSG, 10)
+    air_s = H.make_air(10)
+    per_s = H.periodic_values(1 << 10)
+
+    def sha_bus(t):
+        return [H.bus_lookup([int(t[j, i]) for j in range(H.COLS)], [v[i] for v in per_s], pubs) for i in range(1 << 10)
+                if per_s[H.P_RCV][i] or any(per_s[H.P_SD0 + j][i] for j in range(6))]
+
+    ed_side = _ed_bus(ed["tr"], ed["pub"], 6, (E.TAG_EDMSG, E.TAG_EDH))
+    t = _total(ed_side) + _total(sha_bus(ts))
+    assert (t.a, t.b) == (0, 0)
+    off = ts.copy()
+    off[H.SGF, 160:320] = 0  # slot 1 of the hash table neither receives nor sends
+    aux_s, apub_s = H.gen_aux(off, CHAL, pubs)
+    assert S.check_trace(air_s, off, pubs, CHAL, aux_s, apub_s, rows=(150, 330)) is None  # its own constraints hold
+    t = _total(ed_side) + _total(sha_bus(off))
+    assert (t.a, t.b) != (0, 0)                                    # but the curve table's slot 1 still wants its digest
+    # the consistent version: the curve table leaves that signature out too -- k = 3, a different public input
+    sigs3 = [s for i, s in enumerate(ed["sigs"]) if i != 1]
+    tr_e, pub_e = E.gen_trace(sigs3, 16)
+    ts3, pubs3, _ = H.gen_trace([s for i, s in enumerate(ed["slots"]) if i != 1], MSG, 10)
+    t = _total(_ed_bus(tr_e, pub_e, 6, (E.TAG_EDMSG, E.TAG_EDH))) + _total(sha_bus(ts3))
+    assert (t.a, t.b) == (0, 0) and pub_e[0] == 3 != ed["pub"][0]
+    # half a switch is no option: a slot's flag is constant over its rows (receive rows and send rows share it)
+    half = ts.copy()
+    half[H.SGF, 160:240] = 0
+    aux_h, apub_h = H.gen_aux(half, CHAL, pubs)
+    assert S.check_trace(air_s, half, pubs, CHAL, aux_h, apub_h, rows=(230, 250)) is not None

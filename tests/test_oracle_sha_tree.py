@@ -43,7 +43,7 @@ def test_tree_constraints_roots_and_bus_balance(oracle):
     msgs, trusted, _ = make([300, 129, 104, 131, 500])  # 104: the data root starts in the row after the state root's last; leaves 5..15 are zero leaves
     sr, dr = [m[36:68] for m in msgs], [m[-32:] for m in msgs]
     ttr, tpub = T.gen_trace(sr, dr, N)
-    assert tpub == mirror_root(sr, N) + mirror_root(dr, N)
+    assert tpub == mirror_root(sr, N) + mirror_root(dr, N) + [5]
     taux, apub_b = A.gen_aux(ttr, CHAL, tpub)
     assert S.check_trace(A, ttr, tpub, CHAL, taux, apub_b) is None
     # the hash-chain table for the same headers puts exactly what the tree takes on the bus
@@ -75,6 +75,65 @@ def test_tree_constraints_roots_and_bus_balance(oracle):
         bad[col, row] ^= np.uint64(1)
         assert S.check_trace(A, bad, tpub, CHAL, taux, apub_b, rows=(max(0, row - 2), row + 2)) is not None, (col, row)
     assert S.check_trace(A, ttr, [tpub[0] ^ 1] + tpub[1:], CHAL, taux, apub_b, rows=(128 + 127, 128 + 128)) is not None  # wrong claimed root
+
+
+def test_dropping_a_header_on_both_sides_of_the_bus_is_rejected(oracle):
+    """the forgery bus balance alone cannot see -- the hash-chain table stops sending header 1's roots AND the
+    Merkle table disables leaf 1 (a zero leaf in both trees), so everything sent is still received.  The leaf flags are forced by
+    the public header count now: every way of filling them in violates a constraint of the Merkle table, or needs a count the
+    verifier does not accept."""
+    msgs, trusted, _ = make([300, 129, 104, 131, 500])
+    sr, dr = [m[36:68] for m in msgs], [m[-32:] for m in msgs]
+    tr, pub, _ = B.gen_trace(msgs, 16, trusted, tree_size=N)
+    hdr1 = np.nonzero((tr[B.NUM] == pub[16] + 1) & (tr[B.ACT] == 1))[0]
+    forged = tr.copy()
+    assert forged[B.E0:B.E0 + 8][:, hdr1].sum() == 64  # header 1 sends its 32 + 32 root bytes ...
+    forged[B.E0:B.E0 + 8, hdr1.min():hdr1.max() + 1] = 0  # ... and now nothing
+    aux_f, apub_f = B.BlakeChainAir.gen_aux(forged, CHAL, pub)
+    lo, hi = int(hdr1.min()), int(hdr1.max()) + 1
+    assert S.check_trace(B.BlakeChainAir, forged, pub, CHAL, aux_f, apub_f, rows=(max(0, lo - 2), hi + 2)) is None  # the sender's flags are free: its table is satisfied
+    sr2, dr2 = list(sr), list(dr)
+    sr2[1] = dr2[1] = bytes(32)
+    t2, p2 = T.gen_trace(sr2, dr2, N)  # trees with a zero leaf 1, all five flags still set
+    assert p2[:16] != (mirror_root(sr, N) + mirror_root(dr, N))  # the roots the forger would publish are not the mirror's
+    g, rows = (N + 1) // 2, None
+    variants = {}
+    # (a) just clear leaf 1's flag (and keep the counter as it was): the count / order constraints break
+    v = t2.copy()
+    for t in range(2):
+        rows = slice(128 * (t * N + g), 128 * (t * N + g) + 128)
+        v[T.ENR, rows] = 0
+    variants["flag only"] = (v, p2)
+    # (b) clear it and re-count: four enabled leaves per tree, but leaf 2 is enabled behind a disabled leaf 1
+    v = v.copy()
+    for t in range(2):
+        for gg in range(N // 2, N):
+            rows = slice(128 * (t * N + gg), 128 * (t * N + gg) + 128)
+            v[T.CNT, rows] = int(v[T.ENL, 128 * (t * N + gg)]) + int(v[T.ENR, 128 * (t * N + gg)]) + (int(v[T.CNT, 128 * (t * N + gg - 1)]) if gg > N // 2 else 0)
+    variants["recount"] = (v, p2[:16] + [4])
+    # (c) keep the count at five by enabling zero leaf 5 instead
+    w = v.copy()
+    g5 = (N + 5) // 2
+    for t in range(2):
+        w[T.ENR, 128 * (t * N + g5): 128 * (t * N + g5) + 128] = 1
+        for gg in range(g5, N):
+            w[T.CNT, 128 * (t * N + gg): 128 * (t * N + gg) + 128] += np.uint64(1)
+    variants["swap leaf"] = (w, p2)
+    for name, (tt, pp) in variants.items():
+        aux_t, apub_t = A.gen_aux(tt, CHAL, pp)
+        assert balance(apub_f, 1 << 16, apub_t, 256 * N) == [0, 0] or name == "swap leaf", name  # (the bus alone sees nothing in a and b)
+        assert S.check_trace(A, tt, pp, CHAL, aux_t, apub_t) is not None, name
+    # (d) the one forgery the table's own constraints allow: drop the LAST header on both sides -- flags 1 1 1 1 0, count 4.  It
+    # balances and satisfies both tables, but only under public count 4: the verifier rebuilds the count as target_block -
+    # trusted_block = 5 (vx_header_range_verify), so such a proof is a proof of another statement
+    hdr4 = np.nonzero((tr[B.NUM] == pub[16] + 4) & (tr[B.ACT] == 1))[0]
+    forged4 = tr.copy()
+    forged4[B.E0:B.E0 + 8, hdr4.min():hdr4.max() + 1] = 0
+    aux_4, apub_4 = B.BlakeChainAir.gen_aux(forged4, CHAL, pub)
+    t4, p4 = T.gen_trace(sr[:4], dr[:4], N)
+    aux_t, apub_t = A.gen_aux(t4, CHAL, p4)
+    assert p4[16] == 4 and S.check_trace(A, t4, p4, CHAL, aux_t, apub_t) is None and balance(apub_4, 1 << 16, apub_t, 256 * N) == [0, 0]
+    assert S.check_trace(A, t4, p4[:16] + [5], CHAL, aux_t, apub_t) is not None
 
 
 def test_tree_prove_verify_under_shared_challenges(oracle):
@@ -122,7 +181,7 @@ def test_every_compact_mode_of_the_block_number(oracle, first):
     assert len(set(lens)) == 2
     sr, dr = [m[32 + l: 64 + l] for m, l in zip(msgs, lens)], [m[-32:] for m in msgs]
     ttr, tpub = T.gen_trace(sr, dr, N)
-    assert tpub == mirror_root(sr, N) + mirror_root(dr, N)
+    assert tpub == mirror_root(sr, N) + mirror_root(dr, N) + [4]
     taux, apub_b = A.gen_aux(ttr, CHAL, tpub)
     tr, pub, _ = B.gen_trace(msgs, 16, trusted, tree_size=N)
     assert pub[16:18] == [first, first + 3]
