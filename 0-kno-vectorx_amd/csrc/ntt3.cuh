@@ -64,13 +64,14 @@ __device__ __forceinline__ size_t e_off(int e, int log_m) {  // uniform
 #ifndef VX_NTT3_TPB
 #define VX_NTT3_TPB 4
 #endif
-// waves per SIMD the register allocation aims at: the contiguous 12-stage pass needs 37 KB of LDS per block (4 blocks per CU),
-// the strided passes stage the between-pass table as well (52 KB: 3 blocks per CU)
-#ifndef VX_NTT3_DIRECT0
-#define VX_NTT3_DIRECT0 0
-#endif
+// waves per SIMD the register allocation aims at.  3 everywhere: the contiguous 12-stage pass would fit 4 blocks per CU
+// (37 KB of LDS each), but at 128 VGPRs it spills 7 registers to scratch -- rocprofv3 --pmc counted 0.98 GB of extra HBM
+// traffic per launch (8.59 -> 9.57 GB) for no gain in time (4.04 vs 4.09 ms per transform, tools/ntt_ab.py)
 #ifndef VX_NTT3_WAVES
-#define VX_NTT3_WAVES(LR, MODE) ((LR) == 12 && (MODE) == 0 ? 4 : 3)
+#define VX_NTT3_WAVES(LR, MODE) 3
+#endif
+#ifndef VX_NTT3_DIRECT0
+#define VX_NTT3_DIRECT0 0  // 1: a three-round DIT pass without zero padding also loads straight into layout 0 (A/B aid)
 #endif
 
 namespace n3 {

@@ -27,7 +27,7 @@ SYMBOLS = [
     "vx_ed25519_verify_batch", "vx_verify_simple_justification", "vx_sha_chain_trace",
     "vx_verify_epoch_end_header", "vx_rotate_proof_bound", "vx_rotate_prove", "vx_rotate_verify",
     "vx_gather_proofs", "vx_quotient_eval", "vx_decode_header_batch", "vx_decode_precommit_batch", "vx_stark_aux_trace",
-    "vx_ed_trace", "vx_sha512_trace", "vx_epoch_end_trace",
+    "vx_ed_trace", "vx_sha512_trace", "vx_epoch_end_trace", "vx_partial_products",
 ]
 
 VX_AIR_FIBONACCI, VX_AIR_MIX, VX_AIR_BLAKE_CHAIN, VX_AIR_LOOKUP = 1, 2, 6, 5
@@ -138,6 +138,7 @@ def load_library():
         "vx_rotate_verify": [C.POINTER(StarkConfig), vp, sz, u64, vp, vp, C.c_char_p, sz],
         "vx_gather_proofs": [vp, vp, C.c_int, vp, sz, vp],
         "vx_quotient_eval": [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, sz, vp],
+        "vx_partial_products": [vp, vp, vp, C.c_int, sz, vp, u64, u64, sz, vp],
         "vx_decode_header_batch": [vp, vp, sz, vp, sz, vp, vp, vp, vp, vp, vp],
         "vx_decode_precommit_batch": [vp, vp, sz, vp, vp, vp, vp, vp],
         "vx_stark_aux_trace": [vp, C.c_int, vp, C.c_int, vp, sz, vp, sz, vp, vp],
@@ -452,6 +453,14 @@ class Context:
         self._ck(self.L.vx_rotate_prove(self.h, header_buf.h, header_size, epoch_end_block_number, num_authorities, start_position, _ptr(pk),
                                         C.byref(just.struct), C.byref(cfg), _ptr(out32), _ptr(out), out.size, C.byref(need)))
         return out32.tobytes(), out[: need.value]
+
+    def partial_products(self, wires_buf, sigmas_buf, log_n, n_routed, k_is, beta, gamma, chunk=8, out=None):
+        """K9: Z and the partial products of the permutation argument -> Buffer [ceil(n_routed / chunk)][2^log_n] (column 0 = Z)."""
+        m = (n_routed + chunk - 1) // chunk
+        out = out or self.alloc(m << log_n)
+        k = np.ascontiguousarray(k_is, dtype=np.uint64)
+        self._ck(self.L.vx_partial_products(self.h, wires_buf.h, sigmas_buf.h, log_n, n_routed, _ptr(k), int(beta), int(gamma), chunk, out.h))
+        return out
 
     def quotient_eval(self, air_id, rate_bits, trace_lde_buf, log_n, alphas, public_inputs):
         """-> [2][N] quotient values on the coset for the two challenges."""

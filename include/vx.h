@@ -170,6 +170,16 @@ int32_t vx_stark_default_config(vx_stark_config* cfg);
  * 7 * <w_N>.  out[k*N + i] = (sum_j alpha_k^(K-1-j) c_j(x_i)) / Z_H(x_i) for the two challenges k = 0, 1. */
 int32_t vx_quotient_eval(vx_ctx* ctx, int air_id, int rate_bits, const vx_buf* trace_lde, int log_n, const uint64_t alphas[2],
                          const uint64_t* public_inputs, size_t n_public, vx_buf* out);
+/* K9: the partial products of Plonk's permutation argument, as plonky2 computes them (plonky2 v0.2.0 plonk/prover.rs
+ * wires_permutation_partial_products_and_zs, util/partial_products.rs; reached from Circuit::prove, circuits/header_range.rs:167).
+ * Rows x_i = g^i of the subgroup of order 2^log_n; wires / sigmas: [n_routed][2^log_n] column-major (sigmas = the values of the
+ * sigma polynomials, coset shifts included); k_is: the n_routed coset shifts (host); one challenge pair (beta, gamma).
+ *   q_j(i) = (w_j(i) + beta k_j x_i + gamma) / (w_j(i) + beta s_j(i) + gamma),  chunk_c = product of `chunk` consecutive q_j,
+ *   out column 0 = Z (Z(x_0) = 1, Z(x_(i+1)) = Z(x_i) * all chunks of row i), column t + 1 = Z(x_i) chunk_0(i) .. chunk_t(i)
+ *   for t < m - 1, m = ceil(n_routed / chunk) <= 32 columns in all.  This library's own provers are STARK-only and do not
+ * call it (no Plonk layer exists here): it is the primitive a patched plonky2 would forward to. */
+int32_t vx_partial_products(vx_ctx* ctx, const vx_buf* wires, const vx_buf* sigmas, int log_n, size_t n_routed, const uint64_t* k_is,
+                            uint64_t beta, uint64_t gamma, size_t chunk, vx_buf* out);
 /* The auxiliary (lookup / logUp) columns an AIR derives from its trace once the lookup challenges are known -- the step
  * vx_stark_prove runs between the trace cap and the constraint challenges, exposed on its own as a test surface.
  * trace: the AIR's main columns [cols][2^log_n]; challenges: the AIR's CHAL base-field elements (canonical);

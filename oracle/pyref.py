@@ -162,3 +162,29 @@ def ed25519_verify(public, msg, sig):
     hA = _mul(h, A)
     lhs, rhs = sB, _add(R, hA)
     return (lhs[0] * rhs[2] - rhs[0] * lhs[2]) % _q == 0 and (lhs[1] * rhs[2] - rhs[1] * lhs[2]) % _q == 0
+
+
+def partial_products(wires, sigmas, k_is, beta, gamma, chunk=8):
+    """Plonk permutation argument as plonky2 v0.2.0 lays it out (plonk/prover.rs wires_permutation_partial_products_and_zs,
+    util/partial_products.rs; not vendored in /root/reference: restated from its published algorithm -- PARITY UNPINNED).
+    wires, sigmas: [R][n] Python ints; rows x_i = g^i, g = root(log2 n).  Returns the m = ceil(R / chunk) columns
+    [Z, pp_0 .. pp_(m-2)]: Z(x_0) = 1, pp_t(i) = Z(x_i) chunk_0(i) .. chunk_t(i), Z(x_(i+1)) = Z(x_i) * every chunk of row i,
+    chunk_c(i) = prod over the c-th group of `chunk` wires of (w + beta k x + gamma) / (w + beta s + gamma)."""
+    R, n = len(wires), len(wires[0])
+    m = (R + chunk - 1) // chunk
+    g = root(n.bit_length() - 1)
+    cols = [[0] * n for _ in range(m)]
+    z, x = 1, 1
+    for i in range(n):
+        cols[0][i] = z
+        acc = z
+        for c in range(m):
+            num = den = 1
+            for j in range(c * chunk, min((c + 1) * chunk, R)):
+                num = num * ((wires[j][i] + beta * k_is[j] * x + gamma) % P) % P
+                den = den * ((wires[j][i] + beta * sigmas[j][i] + gamma) % P) % P
+            acc = acc * num % P * pow(den, P - 2, P) % P
+            if c + 1 < m:
+                cols[c + 1][i] = acc
+        z, x = acc, x * g % P
+    return cols, z  # z = Z after the last row: 1 when the wires respect the permutation

@@ -5,7 +5,7 @@
 # and tools/pmc_kernel_report.py.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-for V in new old; do
+for V in ${@:-new old}; do
   if [ $V = old ]; then export VX_NTT_V2=1; else unset VX_NTT_V2; fi
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/r03_pmc_$V/fetch -o p -- python3 $R/tools/ntt_pmc.py > $O/r03_pmc_${V}_f.log 2>&1 || exit 1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/r03_pmc_$V/write -o p -- python3 $R/tools/ntt_pmc.py > $O/r03_pmc_${V}_w.log 2>&1 || exit 1
