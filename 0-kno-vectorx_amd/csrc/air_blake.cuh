@@ -403,7 +403,10 @@ struct BlakeAir {
             {
                 F r8n = sel[0] * F::from(8);
                 for (int r = 1; r < 15; ++r) r8n = r8n + sel[r] * F::from(8 * (r + 1));
-                const F leaf = nxt[NUM] - pub[16], bus_on = pub[19] * (F::from(3) - pub[19]) * F::from(0x7FFFFFFF80000001ULL);  // m (3 - m) / 2: 0 = a stand-alone proof
+                // leaves are counted from public input 18 in bus mode 1 (the first block of the whole RANGE: a table may hold one map
+                // segment of it) and from the table's own first block otherwise (mode 2: one header, leaf 0)
+                const F is1 = pub[19] * (two - pub[19]);  // [mode = 1]
+                const F leaf = nxt[NUM] - (pub[16] + is1 * (pub[18] - pub[16])), bus_on = pub[19] * (F::from(3) - pub[19]) * F::from(0x7FFFFFFF80000001ULL);  // m (3 - m) / 2: 0 = a stand-alone proof
                 const F pos0 = nxt[T] - nxt[INC] + r8n - nxt[KOF];
                 const X2<F> base = beta + leaf + g3 * nxt[TR] + g4 * F::from(TAG_BYTE);
                 const F live = nxt[ACT] * bus_on;  // an inactive (padding / junk) message shares its block number with the last real header: it must not send

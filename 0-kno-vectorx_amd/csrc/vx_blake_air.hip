@@ -320,7 +320,7 @@ struct AuxArgs {
     uint64_t* part;  // [9][2][n]
     size_t n;
     gl2 beta, gamma;
-    uint64_t first_number, tree_size, bus_on;  // public inputs 16, 18, 19: leaf = NUM - first, node id = tree_size + leaf
+    uint64_t first_number, tree_size, bus_on;  // the block number of leaf 0 (public input 18 in bus mode 1, else 16), public inputs 18, 19
 };
 #ifndef VX_AUX_WAVES
 #define VX_AUX_WAVES 4  // measured: 2 -> 6.7 ms, 3 -> 6.4, 4 -> 4.9 (64 VGPRs + scratch: the kernel lives on occupancy hiding its dependent multiply chains)
@@ -525,7 +525,7 @@ int32_t vx_blake_air_gen_aux(vx_ctx* ctx, const uint64_t* trace, int log_n, cons
     const size_t n = (size_t)1 << log_n;
     uint64_t* part = (uint64_t*)vx_pool_alloc(ctx, 18 * n * 8);
     if (!part) return vx_fail(ctx, VX_ERR_OOM, "blake aux: out of device memory");
-    AuxArgs a{trace, aux, part, n, gl2{chal[0], chal[1]}, gl2{chal[2], chal[3]}, pub[16], pub[18], pub[19]};
+    AuxArgs a{trace, aux, part, n, gl2{chal[0], chal[1]}, gl2{chal[2], chal[3]}, pub[19] == 1 ? pub[18] : pub[16], pub[18], pub[19]};  // bus mode 1 counts leaves from the range's first block
     hipLaunchKernelGGL(k_blake_aux, dim3((unsigned)((n + 255) / 256), 9), dim3(256), 0, ctx->stream, a);
     hipLaunchKernelGGL(k_blake_aux_z, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint64_t*)part, aux, n);
     const hipError_t e = hipGetLastError();
@@ -546,6 +546,7 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
     VX_CHECK((uint64_t)first_block_number + n_headers <= (1ULL << 32), "blake trace: block numbers %u.. overflow 32 bits", first_block_number);
     VX_CHECK(!window_length || (n_headers == 1 && !tree_size && window_offset >= 72 && (uint64_t)window_offset + window_length < (1u << 24)),
              "blake trace: a byte window (offset %u, length %u) goes with one header, no Merkle tree, and starts behind the state root", window_offset, window_length);
+    VX_CHECK(window_length || window_offset == 0 || (tree_size && window_offset < first_block_number), "blake trace: a leaf offset (%u) goes with tree_size != 0", window_offset);
     const size_t n = (size_t)1 << log_n, n_blocks = n >> 4;
     VX_CHECK(trace_out->n >= n * blk::COLS, "blake trace: trace buffer holds %zu < %zu elements", trace_out->n, n * (size_t)blk::COLS);
     std::vector<uint32_t> base(n_headers);
@@ -643,7 +644,9 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
     }
     public_inputs_out[16] = first_block_number;
     public_inputs_out[17] = first_block_number + (uint64_t)n_headers - 1;
-    public_inputs_out[18] = window_length ? window_offset : tree_size;
+    // bus mode 1: the block number of leaf 0 = this table's first block minus the headers of the range before it (window_offset
+    // doubles as that count when window_length = 0: a map segment of a longer range; 0 = the table starts the range)
+    public_inputs_out[18] = window_length ? window_offset : (tree_size ? (uint64_t)first_block_number - window_offset : 0);
     public_inputs_out[19] = window_length ? 2 : (tree_size ? 1 : 0);  // bus mode: 1 the state / data roots go to a Merkle AIR, 2 a window of message bytes
     if (digests_out) memcpy(digests_out, dig.data(), dig.size());
     return VX_OK;

@@ -528,7 +528,7 @@ int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob,
     }
     pub[16] = (uint64_t)trusted_block + 1;
     pub[17] = target_block;
-    pub[18] = max_headers;  // the Merkle tree size the state / data roots are sent to
+    pub[18] = (uint64_t)trusted_block + 1;  // the block of Merkle leaf 0
     pub[19] = 1;            // bus on
     for (int j = 0; j < 16; ++j)  // state_root_merkle_root || data_root_merkle_root as big-endian words
         tpub[j] = ((uint64_t)out96[32 + 4 * j] << 24) | ((uint64_t)out96[33 + 4 * j] << 16) | ((uint64_t)out96[34 + 4 * j] << 8) | out96[35 + 4 * j];

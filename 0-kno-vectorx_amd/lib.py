@@ -493,13 +493,13 @@ class Context:
         self._ck(self.L.vx_sha256_pairs(self.h, _ptr(p), p.shape[0], _ptr(out)))
         return out
 
-    def blake_chain_trace(self, headers_buf, stride, sizes, trusted_hash, first_block_number, log_n, trace_buf=None, tree_size=0, window=(0, 0)):
+    def blake_chain_trace(self, headers_buf, stride, sizes, trusted_hash, first_block_number, log_n, trace_buf=None, tree_size=0, window=(0, 0), leaf_offset=0):
         sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
         th = np.frombuffer(bytes(trusted_hash), dtype=np.uint8).copy()
         trace_buf = trace_buf or self.alloc(VX_BLAKE_AIR_COLS << log_n)
         pub = np.zeros(20, dtype=np.uint64)
         dig = np.zeros((sizes.size, 32), dtype=np.uint8)
-        self._ck(self.L.vx_blake_chain_trace(self.h, headers_buf.h, stride, _ptr(sizes), sizes.size, _ptr(th), first_block_number, tree_size, window[0], window[1], log_n,
+        self._ck(self.L.vx_blake_chain_trace(self.h, headers_buf.h, stride, _ptr(sizes), sizes.size, _ptr(th), first_block_number, tree_size, window[0] if window[1] else leaf_offset, window[1], log_n,
                                              trace_buf.h, _ptr(pub), _ptr(dig)))
         return trace_buf, pub, dig
 

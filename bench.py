@@ -247,13 +247,22 @@ def cpu_baseline(vx, ctx):
     S.verify(proof, expect_air=B.ID)
     rows_ratio = (1 << (19 if N_HEADERS == 256 else 20)) / float(1 << 16)
     total = t_chain + rows_ratio * t_prove
+    # the WHOLE step -- all five tables at their real sizes, nothing scaled -- takes minutes on the CPU: it was run once on a GPU box's
+    # host cores and committed (tools/cpu_full_step.py); the live sample above is what fits the bench's time budget
+    full = None
+    fpath = os.path.join(ROOT, "profiles", "r03_cpu_full_step.json")
+    if os.path.exists(fpath) and N_HEADERS == 256:
+        rec = json.load(open(fpath))
+        full = {"source": "profiles/r03_cpu_full_step.json (tools/cpu_full_step.py, run once offline on a GPU box's host cores)", "cores": rec["cores"],
+                "seconds": rec["total_s"], "proofs_per_s": rec["proofs_per_s"], "tables_s": {k: v["prove_s"] for k, v in rec["tables"].items()}, "not_timed": rec["not_timed"]}
     return {
         "value": round(1.0 / total, 6), "unit": "proofs/s", "cores": cores, "kind": "port",
         "sample": f"oracle/ (C + OpenMP kernels under numpy, {cores} threads): COMPLETE BlakeChainAir STARK of header_range over {CPU_SAMPLE_HEADERS} of the "
                   f"{N_HEADERS} headers (2^16 x 1018 trace: logUp columns, LDE, Poseidon caps, quotient, openings, FRI, PoW, 84 queries; proof verified) "
                   f"= {t_prove:.1f} s, scaled x{rows_ratio:.0f} by rows (under-counts the n log n terms), + verify_subchain on all {N_HEADERS} headers {t_chain:.2f} s. "
-                  f"Not included: witness generation (trace taken from the GPU path) and the other four tables of the step (Merkle, authority-set commitment, Ed25519, SHA-512: about a third of the hash-chain table's area again) -- so the CPU is over-stated",
+                  f"Not included in this live sample: witness generation (trace taken from the GPU path) and the other four tables of the step -- full_step_record has the same step with every table at its real size, run once offline",
         "seconds": {"stark_prove_sample": round(t_prove, 2), "verify_subchain": round(t_chain, 3), "scaled_total": round(total, 1)},
+        "full_step_record": full,
     }
 
 

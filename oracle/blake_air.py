@@ -196,7 +196,8 @@ def lookups(loc, nxt, sel, pub=None):
     r8n = sel[0] * 8
     for r in range(1, 15):
         r8n = r8n + sel[r] * (8 * (r + 1))  # 8 * (row index of the next row); sel[15] -> next row is row 0
-    leaf = nxt[NUM] - pub[16]
+    is1 = pub[19] * (2 - pub[19])  # [mode = 1]: leaves are counted from the first block of the whole range (public input 18)
+    leaf = nxt[NUM] - (pub[16] + is1 * (pub[18] - pub[16]))
     pos0 = nxt[T] - nxt[INC] + r8n - nxt[KOF]  # position of byte 0 of the next row, counted from the row's window offset
     bus_on = bus_mode(pub)[0]  # 0 for a stand-alone proof (nothing on the bus, published total 0)
     live = nxt[ACT] * bus_on  # an inactive (padding / junk) message shares its block number with the last real header: it must not send
@@ -421,7 +422,7 @@ def multiplicities(tr):
     return m1, m2
 
 
-def gen_trace(messages, log_n, trusted_hash, first_number=None, forge=None, tree_size=0, window=None):
+def gen_trace(messages, log_n, trusted_hash, first_number=None, forge=None, tree_size=0, window=None, leaf_offset=0):
     """Full main trace [COLS][n] + public inputs (trusted / target hash limbs, first / last block number, Merkle tree
     size, bus flag).  tree_size = 0: a stand-alone proof, nothing goes on the bus."""
     n = 1 << log_n
@@ -466,7 +467,8 @@ def gen_trace(messages, log_n, trusted_hash, first_number=None, forge=None, tree
         sr = np.tile(np.array([1 if 4 <= r <= 8 else 0 for r in range(16)], dtype=np.uint64), (n - 16 * len(real_blocks)) // 16)
         tr[KOF, pad_rows] = np.where(sr == 1, tr[KOF, pad_rows], np.uint64(off))
         return tr, lt + lg + [first_number, last_number, off, 2], target
-    return tr, lt + lg + [first_number, last_number, tree_size, 1 if tree_size else 0], target
+    # public input 18 in bus mode 1: the block number of Merkle leaf 0 (leaf_offset headers of the range precede this table's)
+    return tr, lt + lg + [first_number, last_number, first_number - leaf_offset if tree_size else 0, 1 if tree_size else 0], target
 
 
 # ----------------------------------------------------------------------------- constraints

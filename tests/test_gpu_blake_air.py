@@ -166,7 +166,7 @@ def test_header_range_prove_end_to_end(ctx, vx, oracle):
     assert blob[4:16].tobytes() == out96
     ia, ib = oracle_verify_blob(vx, blob, ocfg, 16)
     assert all(vx.lib.split_blob(blob)[k].size == 0 for k in (1, 3, 4))
-    assert ia["public_inputs"] == limbs(ch.trusted_hash) + limbs(out96[:32]) + [ch.trusted_block + 1, ch.target_block, 16, 1]
+    assert ia["public_inputs"] == limbs(ch.trusted_hash) + limbs(out96[:32]) + [ch.trusted_block + 1, ch.target_block, ch.trusted_block + 1, 1]
     # ALL 96 output bytes are public inputs of a proof; the Merkle table's 17th is the number of headers, which forces its leaf flags
     assert ib["public_inputs"] == [int.from_bytes(out96[32 + 4 * j: 36 + 4 * j], "big") for j in range(16)] + [ch.target_block - ch.trusted_block]
     # with a justification: accepted when > 2/3 signed the target, refused otherwise
@@ -331,7 +331,7 @@ def test_full_size_justified_header_range(ctx, vx, n_headers):
     assert all(p.size for p in parts)
     pub = [[int(x) for x in S.proof_peek(p, 4)[0]] for p in parts]
     words = lambda b: [int.from_bytes(b[4 * j: 4 * j + 4], "big") for j in range(len(b) // 4)]  # noqa: E731
-    assert pub[0] == limbs(ch.trusted_hash) + limbs(out96[:32]) + [ch.trusted_block + 1, ch.target_block, n_headers, 1]
+    assert pub[0] == limbs(ch.trusted_hash) + limbs(out96[:32]) + [ch.trusted_block + 1, ch.target_block, ch.trusted_block + 1, 1]
     assert pub[2] == words(out96[32:]) + [n_headers]                        # both Merkle roots and the forced leaf count
     assert pub[1][:8] == words(sj.authority_set_hash) and pub[1][8:] == [300, 1]   # the commitment of n = 300 keys
     assert pub[3] == [201, 1]                                                 # k = floor(2n/3) + 1 signatures verified: 201 * 3 > 300 * 2

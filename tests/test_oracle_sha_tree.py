@@ -48,7 +48,7 @@ def test_tree_constraints_roots_and_bus_balance(oracle):
     assert S.check_trace(A, ttr, tpub, CHAL, taux, apub_b) is None
     # the hash-chain table for the same headers puts exactly what the tree takes on the bus
     tr, pub, _ = B.gen_trace(msgs, 16, trusted, tree_size=N)
-    assert pub[18:] == [N, 1]
+    assert pub[18:] == [pub[16], 1]  # bus mode 1, leaves counted from the first block
     aux, apub_a = B.BlakeChainAir.gen_aux(tr, CHAL, pub)
     assert S.check_trace(B.BlakeChainAir, tr, pub, CHAL, aux, apub_a, rows=(0, 200)) is None
     assert balance(apub_a, 1 << 16, apub_b, 256 * N) == [0, 0]
@@ -198,3 +198,26 @@ def test_every_compact_mode_of_the_block_number(oracle, first):
 def test_a_header_too_short_for_separate_root_rows_is_refused():
     with pytest.raises(AssertionError, match="short"):
         B.gen_trace(make([72])[0], 16, hashlib.sha256(b"t").digest(), tree_size=N)
+
+
+def test_two_map_segments_feed_one_merkle_table(oracle):
+    """The hash-chain table split into map segments (the reference's MapReduce jobs): segment B starts from the
+    hash segment A ends with, numbers its blocks on, and counts its Merkle leaves from the first block of the WHOLE range (public
+    input 18 in bus mode 1), so that both segments together send exactly what the one Merkle table takes."""
+    msgs, trusted, target = make([300, 129, 104, 131, 500])
+    sr, dr = [m[36:68] for m in msgs], [m[-32:] for m in msgs]
+    ttr, tpub = T.gen_trace(sr, dr, N)
+    taux, apub_t = A.gen_aux(ttr, CHAL, tpub)
+    tr_a, pub_a, mid = B.gen_trace(msgs[:3], 16, trusted, first_number=70000, tree_size=N)
+    tr_b, pub_b, end = B.gen_trace(msgs[3:], 16, mid, first_number=70003, tree_size=N, leaf_offset=3)
+    assert end == target and pub_a[8:16] == pub_b[0:8]                      # the link the verifier checks between segments
+    assert pub_a[16:] == [70000, 70002, 70000, 1] and pub_b[16:] == [70003, 70004, 70000, 1]
+    aux_a, apub_a = B.BlakeChainAir.gen_aux(tr_a, CHAL, pub_a)
+    aux_b, apub_b = B.BlakeChainAir.gen_aux(tr_b, CHAL, pub_b)
+    assert S.check_trace(B.BlakeChainAir, tr_b, pub_b, CHAL, aux_b, apub_b, rows=(0, 120)) is None
+    tot = [(apub_a[i] * (1 << 16) + apub_b[i] * (1 << 16) + apub_t[i] * 256 * N) % P for i in range(2)]
+    assert tot == [0, 0]
+    # a segment that counts its leaves from its own first block would feed leaves 0 and 1 a second time: the bus does not balance
+    wrong = pub_b[:18] + [70003, 1]
+    aux_w, apub_w = B.BlakeChainAir.gen_aux(tr_b, CHAL, wrong)
+    assert [(apub_a[i] * (1 << 16) + apub_w[i] * (1 << 16) + apub_t[i] * 256 * N) % P for i in range(2)] != [0, 0]
