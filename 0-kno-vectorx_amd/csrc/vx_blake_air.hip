@@ -654,7 +654,7 @@ int32_t vx_blake_chain_trace(vx_ctx* ctx, const vx_buf* headers, size_t stride, 
 
 static const uint64_t VX_HR_MAGIC = VX_HR_BLOB_MAGIC;  // "HRRANGE5" (include/vx.h)
 // magic, max_headers, trusted, target, out96 (12), proof lengths: hash chain, authority-set commitment, Merkle, Ed25519, SHA-512; the precommit's round
-static const size_t VX_HR_HDR = 22;
+static const size_t VX_HR_HDR = VX_HR_BLOB_FIXED_WORDS + 1;  // one segment
 
 static int sha_log_n(size_t n_keys) {
     int log_n = 6;
@@ -691,14 +691,41 @@ int32_t vx_header_range_proof_bound(const vx_stark_config* cfg, size_t n_chunks,
 
 }  // extern "C"
 
+void BusMeet::finish_locked(size_t cap_words) {
+    if (done) return;
+    if (xch && xch->fn) {
+        // slot t: [state (0 absent, 1 present, 2 failed), n_pub, pub[MAX_PUB], cap[cap_words]]; the shards' arrays are summed
+        const size_t slot = 2 + MAX_PUB + cap_words;
+        std::vector<uint64_t> w((size_t)n_parties * slot, 0);
+        for (int t = 0; t < n_parties; ++t)
+            if (local[t]) {
+                uint64_t* q = w.data() + (size_t)t * slot;
+                if (deposited[t] && pub[t].size() <= (size_t)MAX_PUB && cap[t].size() == cap_words) {
+                    q[0] = 1, q[1] = pub[t].size();
+                    memcpy(q + 2, pub[t].data(), pub[t].size() * 8);
+                    memcpy(q + 2 + MAX_PUB, cap[t].data(), cap_words * 8);
+                } else q[0] = 2;
+            }
+        if (xch->fn(xch->user, w.data(), w.size()) != 0) failed = true;
+        for (int t = 0; t < n_parties && !failed; ++t) {
+            const uint64_t* q = w.data() + (size_t)t * slot;
+            if (q[0] != 1 || q[1] > (uint64_t)MAX_PUB) failed = true;  // a table nobody proved, one proved twice, or one whose prover gave up
+            else if (!local[t]) pub[t].assign(q + 2, q + 2 + q[1]), cap[t].assign(q + 2 + MAX_PUB, q + 2 + MAX_PUB + cap_words);
+        }
+    }
+    done = true;
+    cv.notify_all();
+}
 int32_t BusMeet::meet(BusMeet* r, int who, const uint64_t* pub, size_t n_pub, const uint64_t* cap, size_t cap_words, uint64_t* chal, size_t n_chal) {
     std::unique_lock<std::mutex> lk(r->m);
     r->pub[who].assign(pub, pub + n_pub);
     r->cap[who].assign(cap, cap + cap_words);
+    r->deposited[who] = true;
     ++r->arrived;
-    r->cv.notify_all();
-    r->cv.wait(lk, [&] { return r->arrived == r->n_parties || r->failed; });
-    if (r->arrived != r->n_parties) return VX_ERR_STATEMENT;  // another table's prover gave up
+    r->capw = cap_words;
+    if (r->arrived == r->n_local()) r->finish_locked(cap_words);
+    r->cv.wait(lk, [&] { return r->done || (r->failed && !r->xch); });
+    if (r->failed) return VX_ERR_STATEMENT;  // another table's prover gave up
     const uint64_t *pubs[MAX], *caps[MAX];
     size_t ns[MAX];
     for (int t = 0; t < r->n_parties; ++t) pubs[t] = r->pub[t].data(), ns[t] = r->pub[t].size(), caps[t] = r->cap[t].data();
@@ -707,9 +734,16 @@ int32_t BusMeet::meet(BusMeet* r, int who, const uint64_t* pub, size_t n_pub, co
     for (size_t q = 0; q < n_chal && q < 4; ++q) chal[q] = c[q];
     return VX_OK;
 }
-void BusMeet::fail() {
+void BusMeet::fail(int who) {
     std::lock_guard<std::mutex> lk(m);
     failed = true;
+    if (xch && who >= 0 && who < n_parties && local[who] && !deposited[who] && !done) {
+        // a sharded proof: the other shards are (or will be) inside the exchange -- this table arrives as a failure marker
+        deposited[who] = false;
+        ++arrived;
+        local_failed[who] = true;
+        if (arrived == n_local()) finish_locked(capw);
+    }
     cv.notify_all();
 }
 int32_t vx_bus_hook(void* u, const uint64_t* pub, size_t n_pub, const uint64_t* cap, size_t cw, uint64_t* chal, size_t n_chal) {
@@ -727,7 +761,7 @@ size_t vx_justification_proof_bound(const vx_stark_config* cfg, size_t n_authori
 }
 
 int32_t vx_justification_tables_start(vx_ctx* const ctxs[3], const vx_justification* just, const vx_stark_config* cfg, BusMeet* rv, int first,
-                                      int32_t (*pre)(vx_ctx*, void*), void* pre_user, JustificationTables* jt) {
+                                      int32_t (*pre)(vx_ctx*, void*), void* pre_user, JustificationTables* jt, unsigned mask) {
     // the signatures the proof verifies: the first floor(2n/3) + 1 signed authorities (more would only cost rows); when fewer
     // signed, all of them -- the native threshold check refuses the justification before anything is proven
     jt->chosen.assign(just->num_authorities, 0);
@@ -778,15 +812,17 @@ int32_t vx_justification_tables_start(vx_ctx* const ctxs[3], const vx_justificat
         return r;
     };
     for (int t = 0; t < 3; ++t) {
+        if (!(mask >> t & 1)) continue;  // another shard's table
         TableJob* j = &jt->job[t];
         try {
             j->th = std::thread([=] {
                 (void)hipSetDevice(j->c->device);
                 j->rc = t == 0 ? prove_chain(j->c, *j) : t == 1 ? prove_ed(j->c, *j) : prove_s512(j->c, *j);
-                if (j->rc != VX_OK) rv->fail();  // do not leave the other provers waiting at their hooks
+                if (j->rc != VX_OK) rv->fail(first + t);  // do not leave the other provers waiting at their hooks
             });
         } catch (...) {
-            rv->fail();
+            for (int u = t; u < 3; ++u)
+                if (mask >> u & 1) rv->fail(first + u);
             return VX_ERR_DEVICE;
         }
     }
@@ -804,47 +840,113 @@ int32_t vx_justification_tables_join(vx_ctx* ctx, JustificationTables* jt) {
     return VX_OK;
 }
 
-extern "C" {
+// Map segments: contiguous runs of headers with (nearly) equal numbers of Blake2b compressions.  bounds[s] .. bounds[s + 1]
+static void hr_segments(const uint32_t* sizes, size_t n, uint32_t S, std::vector<size_t>& bounds, std::vector<size_t>& chunks) {
+    size_t total = 0;
+    for (size_t i = 0; i < n; ++i) total += (sizes[i] + 127) / 128;
+    bounds.assign(1, 0), chunks.clear();
+    size_t acc = 0, seg = 0;
+    for (size_t i = 0; i < n; ++i) {
+        acc += (sizes[i] + 127) / 128, seg += (sizes[i] + 127) / 128;
+        const size_t s = bounds.size();  // the segment being filled is s - 1
+        const size_t left_h = n - 1 - i, left_s = S - s;  // headers / segments still to come
+        if (s < S && (acc * S >= s * total || left_h == left_s) && left_h >= left_s) bounds.push_back(i + 1), chunks.push_back(seg), seg = 0;
+    }
+    bounds.push_back(n), chunks.push_back(seg);
+}
+static int blake_log_n(size_t chunks) {
+    int log_n = blk::TABLE_LOG;  // at least one copy of the lookup tables
+    while (((size_t)1 << log_n) < 16 * chunks) ++log_n;
+    return log_n;
+}
 
-int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_fetched,
-                              uint32_t max_headers, uint32_t trusted_block, const uint8_t trusted_hash[32], uint32_t target_block,
-                              const vx_justification* just, const vx_stark_config* cfg, uint8_t out96[96], uint64_t* proof_out,
-                              size_t proof_cap, size_t* proof_len) {
+static int32_t hr_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_fetched, uint32_t max_headers, uint32_t trusted_block,
+                        const uint8_t trusted_hash[32], uint32_t target_block, const vx_justification* just, const vx_stark_config* cfg, uint32_t S, uint32_t shard,
+                        uint32_t n_shards, const vx_hr_exchange* xch, uint8_t out96[96], uint64_t* proof_out, size_t proof_cap, size_t* proof_len) {
     if (!ctx || !cfg || !proof_len || !out96) return VX_ERR_ARG;
     const int tree_id = tree_air_id(max_headers);
     VX_CHECK(tree_id, "header_range: max_headers %u has no Merkle AIR (16, 256 or 512)", max_headers);
     VX_CHECK(!just || (just->num_authorities >= 1 && just->num_authorities <= 512), "header_range: %u authorities (the EdDSA table holds 512)", just ? just->num_authorities : 0);
+    VX_CHECK(S >= 1 && S <= VX_HR_MAX_SEGMENTS && S <= n_fetched, "header_range: %u map segments for %zu headers (1 .. %d, at most one per header)", S, n_fetched, (int)VX_HR_MAX_SEGMENTS);
+    VX_CHECK(n_shards >= 1 && shard < n_shards && (n_shards == 1 || (xch && xch->fn)), "header_range: shard %u of %u (an exchange function goes with more than one shard)", shard, n_shards);
+    VX_CHECK(cfg->cap_height >= 0 && cfg->cap_height <= 8, "header_range: cap_height %d", cfg->cap_height);
     // 1. statement + public outputs (map/reduce chain rules, Merkle roots)
     VX_TRY(vx_verify_subchain(ctx, headers, stride, sizes, n_fetched, max_headers, trusted_block, trusted_hash, target_block, out96));
-    const bool room = proof_out && proof_cap > VX_HR_HDR;
-    size_t chunks = 0;
-    for (size_t i = 0; i < n_fetched; ++i) chunks += (sizes[i] + 127) / 128;
-    int log_n = blk::TABLE_LOG;  // at least one copy of the lookup tables
-    while (((size_t)1 << log_n) < 16 * chunks) ++log_n;
+    const size_t HDR = VX_HR_BLOB_FIXED_WORDS + S;
     const int tl = tree_log_n(max_headers);
-    // the leaves of the two Merkle trees: decode_header on the GPU (all four compact modes natively; the AIR covers mode 2)
+    // 2. the tables, all on ONE logUp bus under shared lookup challenges (BusMeet), in bus order:
+    //    0 .. S-1  BlakeChainAir   map segment s: every compression of its headers; sends state-root and data-root bytes
+    //    S         ShaTreeAir      the two SHA-256 Merkle trees over exactly those roots (subchain_verification.rs:213-220, 268-274)
+    //   with a justification (header_range.rs:49-54 -> justification.rs:195-257):
+    //    S+1       ShaChainAir     the authority-set commitment (justification.rs:127-162); sends the keys of the signed authorities
+    //    S+2       EdAir           [S]B = R + [h]A for every signed authority (:229-243); receives the keys, exchanges R || A / H with
+    //    S+3       Sha512Air       H = SHA-512(R || A || precommit)
+    //   table t is proven here when t mod n_shards == shard
+    const int n_tables = (int)S + 1 + (just ? 3 : 0);
+    auto mine = [&](int t) { return (uint32_t)t % n_shards == shard; };
+    BusMeet rv;
+    rv.n_parties = n_tables;
+    rv.capw = (size_t)4 << cfg->cap_height;
+    for (int t = 0; t < n_tables; ++t) rv.local[t] = mine(t);
+    rv.xch = n_shards > 1 ? xch : nullptr;
+    std::vector<size_t> bounds, seg_chunks;
+    hr_segments(sizes, n_fetched, S, bounds, seg_chunks);
+    // the hash every segment starts from: the Blake2b-256 digest of the header before it
+    std::vector<uint8_t> digests;
+    if (S > 1) {
+        digests.resize(32 * n_fetched);
+        VX_TRY(vx_blake2b_256_batch(ctx, headers, stride, sizes, n_fetched, digests.data()));
+    }
+    // the leaves of the two Merkle trees: decode_header on the GPU (all four compact modes)
     std::vector<uint32_t> numbers(n_fetched);
     std::vector<uint8_t> modes(n_fetched), oks(n_fetched), parents(32 * n_fetched), sroots(32 * n_fetched), droots(32 * n_fetched);
-    VX_TRY(vx_decode_header_batch(ctx, headers, stride, sizes, n_fetched, numbers.data(), modes.data(), oks.data(), parents.data(), sroots.data(), droots.data()));
-    // 2. the tables, all on ONE logUp bus under shared lookup challenges (BusMeet):
-    //    0 BlakeChainAir  (this context)  every compression of every header; sends state-root words and data-root bytes
-    //    1 ShaTreeAir     the two SHA-256 Merkle trees over exactly those roots (subchain_verification.rs:213-220, 268-274)
-    //   with a justification (header_range.rs:49-54 -> justification.rs:195-257):
-    //    2 ShaChainAir    the authority-set commitment (justification.rs:127-162); sends the keys of the signed authorities
-    //    3 EdAir          [S]B = R + [h]A for every signed authority (:229-243); receives the keys, exchanges R || A / H with
-    //    4 Sha512Air      H = SHA-512(R || A || precommit)
-    BusMeet rv;
-    rv.n_parties = just ? 5 : 2;
-    BusParty party[2] = {{&rv, 0}, {&rv, 1}};
-    const vx_chal_hook hooks[2] = {{vx_bus_hook, &party[0]}, {vx_bus_hook, &party[1]}};
-    vx_ctx* side[4] = {nullptr, nullptr, nullptr, nullptr};  // a chain of side contexts, one per table
+    if (mine((int)S)) VX_TRY(vx_decode_header_batch(ctx, headers, stride, sizes, n_fetched, numbers.data(), modes.data(), oks.data(), parents.data(), sroots.data(), droots.data()));
+    // one context per local table: the first local segment runs on `ctx` from this thread, everything else on a chain of side contexts
+    std::vector<BusParty> party(n_tables);
+    std::vector<vx_chal_hook> hooks(n_tables);
+    for (int t = 0; t < n_tables; ++t) party[t] = {&rv, t}, hooks[t] = {vx_bus_hook, &party[t]};
+    int main_seg = -1;
+    for (int t = 0; t < (int)S && main_seg < 0; ++t)
+        if (mine(t)) main_seg = t;
+    std::vector<vx_ctx*> tctx(n_tables, nullptr);
     {
         vx_ctx* c = ctx;
-        for (int t = 0; t < rv.n_parties - 1; ++t) side[t] = c = c ? vx_side_ctx(c) : nullptr;
-        VX_CHECK(c, "header_range: no side context for every table (the provers meet at their challenge hooks, each on its own context)");
+        for (int t = 0; t < n_tables; ++t) {
+            if (!mine(t)) continue;
+            if (t == main_seg) tctx[t] = ctx;
+            else {
+                c = c ? vx_side_ctx(c) : nullptr;
+                VX_CHECK(c, "header_range: no side context for every table (the provers meet at their challenge hooks, each on its own context)");
+                tctx[t] = c;
+            }
+        }
     }
+    std::vector<TableJob> seg(S);
+    auto prove_segment = [&](int s, vx_ctx* c, TableJob& j) -> int32_t {
+        const size_t a = bounds[s], b = bounds[s + 1];
+        const int log_n = blake_log_n(seg_chunks[s]);
+        size_t bound = 0;
+        VX_TRY(vx_stark_proof_bound(VX_AIR_BLAKE_CHAIN, cfg, log_n, &bound));
+        j.proof.resize(bound);
+        vx_buf* trace = nullptr;
+        VX_TRY(vx_alloc(c, ((size_t)blk::COLS) << log_n, &trace));
+        vx_buf view{headers->d + a * stride / 8, headers->n - a * stride / 8};
+        uint64_t pub[20];
+        int32_t r = vx_blake_chain_trace(c, &view, stride, sizes + a, b - a, a ? digests.data() + 32 * (a - 1) : trusted_hash, trusted_block + 1 + (uint32_t)a, max_headers,
+                                         (uint32_t)a, 0, log_n, trace, pub, nullptr);
+        if (r == VX_OK && b == n_fetched) {
+            uint8_t tgt[32];
+            for (int q = 0; q < 8; ++q) {
+                uint32_t l = (uint32_t)pub[8 + q];
+                memcpy(tgt + 4 * q, &l, 4);
+            }
+            if (memcmp(tgt, out96, 32) != 0) r = vx_fail(c, VX_ERR_STATEMENT, "header_range: chain digest differs from the subchain target hash");
+        }
+        if (r == VX_OK) r = vx_stark_prove_impl(c, VX_AIR_BLAKE_CHAIN, cfg, trace->d, trace->n, /*consume_trace=*/1, log_n, pub, 20, j.proof.data(), j.proof.size(), &j.len, &hooks[s]);
+        (void)vx_free(c, trace);
+        return r;
+    };
     TableJob tree;
-    tree.c = side[0];
     uint64_t tpub[17];
     auto prove_tree = [&](vx_ctx* c, TableJob& j) -> int32_t {
         vx_buf* tt = nullptr;
@@ -860,13 +962,13 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
         if (r == VX_OK) r = vx_stark_proof_bound(tree_id, cfg, tl, &bound);
         if (r == VX_OK) {
             j.proof.resize(bound);
-            r = vx_stark_prove_impl(c, tree_id, cfg, tt->d, tt->n, /*consume_trace=*/0, tl, tpub, 17, j.proof.data(), j.proof.size(), &j.len, &hooks[1]);
+            r = vx_stark_prove_impl(c, tree_id, cfg, tt->d, tt->n, /*consume_trace=*/0, tl, tpub, 17, j.proof.data(), j.proof.size(), &j.len, &hooks[S]);
         }
         if (tt) (void)vx_free(c, tt);
         return r;
     };
     // the target header is justified by > 2/3 of the committed authority set: every rule natively first (error behaviour of
-    // the reference's hint, justification.rs:29-83), on the commitment table's thread
+    // the reference's hint, justification.rs:29-83) -- on the commitment table's thread, or here when that table is another shard's
     struct PreArgs {
         const vx_justification* just;
         uint32_t target_block;
@@ -878,60 +980,68 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
                                               a->just->pubkeys, a->just->signatures, a->just->validator_signed, a->just->num_authorities, a->just->max_authorities);
     };
     int32_t rc = VX_OK;
-    JustificationTables jt;
-    try {
-        tree.th = std::thread([&] {
-            (void)hipSetDevice(tree.c->device);
-            tree.rc = prove_tree(tree.c, tree);
-            if (tree.rc != VX_OK) rv.fail();  // do not leave the other provers waiting at their hooks
-        });
-    } catch (...) {
-        rc = vx_fail(ctx, VX_ERR_DEVICE, "header_range: no host thread for the Merkle table");
+    if (just && !mine((int)S + 1)) rc = pre(ctx, &pre_args);
+    if (rc != VX_OK) {  // nothing has been started yet; the other shards see this shard's tables fail
+        for (int t = 0; t < n_tables; ++t)
+            if (mine(t)) rv.fail(t);
+        return rc;
     }
-    if (rc == VX_OK && just) {
-        rc = vx_justification_tables_start(side + 1, just, cfg, &rv, 2, pre, &pre_args, &jt);
+    JustificationTables jt;
+    auto start = [&](TableJob& j, int t, auto&& fn) {
+        j.c = tctx[t];
+        try {
+            j.th = std::thread([&j, &rv, t, fn] {
+                (void)hipSetDevice(j.c->device);
+                j.rc = fn(j.c, j);
+                if (j.rc != VX_OK) rv.fail(t);  // do not leave the other provers waiting at their hooks
+            });
+        } catch (...) {
+            j.rc = VX_ERR_DEVICE;
+            rv.fail(t);
+        }
+    };
+    for (int s = 0; s < (int)S; ++s)
+        if (mine(s) && s != main_seg) start(seg[s], s, [&, s](vx_ctx* c, TableJob& j) { return prove_segment(s, c, j); });
+    if (mine((int)S)) start(tree, (int)S, [&](vx_ctx* c, TableJob& j) { return prove_tree(c, j); });
+    if (just) {
+        vx_ctx* jc[3] = {tctx[S + 1], tctx[S + 2], tctx[S + 3]};
+        const unsigned mask = (mine((int)S + 1) ? 1u : 0) | (mine((int)S + 2) ? 2u : 0) | (mine((int)S + 3) ? 4u : 0);
+        rc = vx_justification_tables_start(jc, just, cfg, &rv, (int)S + 1, pre, &pre_args, &jt, mask);
         if (rc != VX_OK) (void)vx_fail(ctx, rc, "header_range: no host thread for the justification tables");
     }
-    vx_buf* trace = nullptr;
-    size_t len1 = 0;
-    if (rc == VX_OK) rc = vx_alloc(ctx, ((size_t)blk::COLS) << log_n, &trace);
-    uint64_t pub[20];
-    if (rc == VX_OK) rc = vx_blake_chain_trace(ctx, headers, stride, sizes, n_fetched, trusted_hash, trusted_block + 1, max_headers, 0, 0, log_n, trace, pub, nullptr);
-    if (rc == VX_OK) {
-        uint8_t tgt[32];
-        for (int q = 0; q < 8; ++q) {
-            uint32_t l = (uint32_t)pub[8 + q];
-            memcpy(tgt + 4 * q, &l, 4);
-        }
-        if (memcmp(tgt, out96, 32) != 0) rc = vx_fail(ctx, VX_ERR_STATEMENT, "header_range: chain digest differs from the subchain target hash");
+    if (main_seg >= 0) {
+        seg[main_seg].c = ctx;
+        if (rc == VX_OK) seg[main_seg].rc = prove_segment(main_seg, ctx, seg[main_seg]);
+        else seg[main_seg].rc = rc;
+        if (seg[main_seg].rc != VX_OK) rv.fail(main_seg);
     }
-    if (rc == VX_OK)
-        rc = vx_stark_prove_impl(ctx, VX_AIR_BLAKE_CHAIN, cfg, trace->d, trace->n, /*consume_trace=*/1, log_n, pub, 20, room ? proof_out + VX_HR_HDR : nullptr,
-                                 room ? proof_cap - VX_HR_HDR : 0, &len1, &hooks[0]);
-    if (rc != VX_OK && rc != VX_ERR_BUFSZ) rv.fail();
-    if (trace) (void)vx_free(ctx, trace);
+    for (int s = 0; s < (int)S; ++s)
+        if (seg[s].th.joinable()) seg[s].th.join();
     if (tree.th.joinable()) tree.th.join();
     const int32_t rc_just = just ? vx_justification_tables_join(ctx, &jt) : VX_OK;  // (the justification's own rules name the error first)
-    if (rc == VX_OK || rc == VX_ERR_BUFSZ) {
+    if (rc == VX_OK) {
         if (rc_just != VX_OK) rc = rc_just;
         else if (tree.rc != VX_OK) rc = vx_fail(ctx, tree.rc, "%s", vx_last_error(tree.c));
-    }
-    *proof_len = VX_HR_HDR + len1 + tree.len + (just ? jt.job[0].len + jt.job[1].len + jt.job[2].len : 0);
-    if (rc == VX_OK) {
-        if (proof_out && proof_cap >= *proof_len) {
-            size_t off = VX_HR_HDR + len1;
-            const TableJob* order[4] = {just ? &jt.job[0] : nullptr, &tree, just ? &jt.job[1] : nullptr, just ? &jt.job[2] : nullptr};  // commitment, Merkle, Ed25519, SHA-512
-            for (int q = 0; q < 4; ++q)
-                if (order[q]) memcpy(proof_out + off, order[q]->proof.data(), order[q]->len * 8), off += order[q]->len;
-        } else rc = vx_fail(ctx, VX_ERR_BUFSZ, "header_range: proof needs %zu words, buffer has %zu", *proof_len, proof_cap);
+        else
+            for (int s = 0; s < (int)S && rc == VX_OK; ++s)
+                if (seg[s].rc != VX_OK) rc = s == main_seg ? seg[s].rc : vx_fail(ctx, seg[s].rc, "%s", vx_last_error(seg[s].c));
     }
     if (rc != VX_OK) return rc;
+    size_t total = HDR + tree.len + (just ? jt.job[0].len + jt.job[1].len + jt.job[2].len : 0);
+    for (int s = 0; s < (int)S; ++s) total += seg[s].len;
+    *proof_len = total;
+    if (!proof_out || proof_cap < total) return vx_fail(ctx, VX_ERR_BUFSZ, "header_range: proof needs %zu words, buffer has %zu", total, proof_cap);
+    size_t off = HDR;
+    for (int s = 0; s < (int)S; ++s) memcpy(proof_out + off, seg[s].proof.data(), seg[s].len * 8), off += seg[s].len;
+    const TableJob* order[4] = {just ? &jt.job[0] : nullptr, &tree, just ? &jt.job[1] : nullptr, just ? &jt.job[2] : nullptr};  // commitment, Merkle, Ed25519, SHA-512
+    for (int q = 0; q < 4; ++q)
+        if (order[q]) memcpy(proof_out + off, order[q]->proof.data(), order[q]->len * 8), off += order[q]->len;
     proof_out[0] = VX_HR_MAGIC;
     proof_out[1] = max_headers;
     proof_out[2] = trusted_block;
     proof_out[3] = target_block;
     memcpy(proof_out + 4, out96, 96);
-    proof_out[16] = len1;
+    proof_out[16] = S;
     proof_out[17] = just ? jt.job[0].len : 0;
     proof_out[18] = tree.len;
     proof_out[19] = just ? jt.job[1].len : 0;
@@ -939,6 +1049,77 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
     uint64_t round = 0;
     if (just) memcpy(&round, just->precommit + 37, 8);  // 0x01 || hash 32 || block 4 || round 8 || set id 8 (decoder.rs:159-200)
     proof_out[21] = round;
+    for (int s = 0; s < (int)S; ++s) proof_out[VX_HR_BLOB_FIXED_WORDS + s] = seg[s].len;
+    return VX_OK;
+}
+
+extern "C" {
+
+int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_fetched,
+                              uint32_t max_headers, uint32_t trusted_block, const uint8_t trusted_hash[32], uint32_t target_block,
+                              const vx_justification* just, const vx_stark_config* cfg, uint8_t out96[96], uint64_t* proof_out,
+                              size_t proof_cap, size_t* proof_len) {
+    return hr_prove(ctx, headers, stride, sizes, n_fetched, max_headers, trusted_block, trusted_hash, target_block, just, cfg, 1, 0, 1, nullptr, out96, proof_out, proof_cap, proof_len);
+}
+int32_t vx_header_range_prove_ex(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_fetched, uint32_t max_headers, uint32_t trusted_block,
+                                 const uint8_t trusted_hash[32], uint32_t target_block, const vx_justification* just, const vx_stark_config* cfg, uint32_t n_segments,
+                                 uint32_t shard, uint32_t n_shards, const vx_hr_exchange* exchange, uint8_t out96[96], uint64_t* proof_out, size_t proof_cap, size_t* proof_len) {
+    return hr_prove(ctx, headers, stride, sizes, n_fetched, max_headers, trusted_block, trusted_hash, target_block, just, cfg, n_segments, shard, n_shards, exchange, out96,
+                    proof_out, proof_cap, proof_len);
+}
+int32_t vx_header_range_proof_bound_ex(const vx_stark_config* cfg, size_t n_chunks, size_t n_authorities, uint32_t n_segments, size_t* n_words) {
+    if (!cfg || !n_words || n_chunks == 0 || n_segments < 1 || n_segments > VX_HR_MAX_SEGMENTS) return VX_ERR_ARG;
+    size_t one = 0;
+    // a segment is never taller than the unsegmented table: S copies of that bound (generous), plus the longer header
+    const int32_t rc = vx_header_range_proof_bound(cfg, n_chunks, n_authorities, &one);
+    size_t w1 = 0;
+    int32_t rc2 = vx_stark_proof_bound(VX_AIR_BLAKE_CHAIN, cfg, blake_log_n(n_chunks), &w1);
+    *n_words = one + (size_t)(n_segments - 1) * w1 + n_segments;
+    return rc != VX_OK ? rc : rc2;
+}
+// host only: the blobs of the shards of one proof -> the request's blob
+int32_t vx_header_range_merge(const uint64_t** blobs, const size_t* lens, size_t n_blobs, uint64_t* out, size_t out_cap, size_t* out_len, char* err, size_t errlen) {
+    auto bad = [&](const char* why) {
+        if (err && errlen) snprintf(err, errlen, "%s", why);
+        return (int32_t)VX_ERR_STATEMENT;
+    };
+    if (!blobs || !lens || !out_len || n_blobs == 0) return VX_ERR_ARG;
+    for (size_t k = 0; k < n_blobs; ++k)
+        if (!blobs[k] || lens[k] <= VX_HR_BLOB_FIXED_WORDS || blobs[k][0] != VX_HR_MAGIC) return bad("merge: not a header_range blob");
+    const uint64_t S = blobs[0][16];
+    if (S < 1 || S > VX_HR_MAX_SEGMENTS) return bad("merge: bad segment count");
+    const size_t HDR = VX_HR_BLOB_FIXED_WORDS + S, NT = S + 4;
+    // table lengths of blob k in blob order: segments, commitment, Merkle, Ed25519, SHA-512
+    auto tlen = [&](size_t k, size_t t) -> uint64_t { return t < S ? blobs[k][VX_HR_BLOB_FIXED_WORDS + t] : blobs[k][17 + (t - S)]; };
+    std::vector<int> src(NT, -1);
+    std::vector<std::vector<size_t>> offs(n_blobs, std::vector<size_t>(NT, 0));
+    for (size_t k = 0; k < n_blobs; ++k) {
+        if (lens[k] < HDR || blobs[k][16] != S || memcmp(blobs[k], blobs[0], 16 * 8) != 0 || blobs[k][21] != blobs[0][21]) return bad("merge: the blobs are not shards of one proof");
+        size_t off = HDR;
+        for (size_t t = 0; t < NT; ++t) {
+            const uint64_t l = tlen(k, t);
+            if (l > lens[k] - off) return bad("merge: blob lengths are inconsistent");
+            offs[k][t] = off, off += l;
+            if (l) {
+                if (src[t] >= 0) return bad("merge: a table is present in two shards");
+                src[t] = (int)k;
+            }
+        }
+        if (off != lens[k]) return bad("merge: blob lengths are inconsistent");
+    }
+    size_t total = HDR;
+    for (size_t t = 0; t < NT; ++t)
+        if (src[t] >= 0) total += tlen(src[t], t);
+    *out_len = total;
+    if (!out || out_cap < total) return VX_ERR_BUFSZ;
+    memcpy(out, blobs[0], HDR * 8);
+    size_t off = HDR;
+    for (size_t t = 0; t < NT; ++t) {
+        const uint64_t l = src[t] >= 0 ? tlen(src[t], t) : 0;
+        if (t < S) out[VX_HR_BLOB_FIXED_WORDS + t] = l;
+        else out[17 + (t - S)] = l;
+        if (l) memcpy(out + off, blobs[src[t]] + offs[src[t]][t], l * 8), off += l;
+    }
     return VX_OK;
 }
 }

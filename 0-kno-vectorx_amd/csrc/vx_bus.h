@@ -11,15 +11,31 @@
 
 #include "vx_internal.h"
 
+// A statement proven by several processes (one per GPU, vx_header_range_prove_ex with n_shards > 1): `local[t]` says which
+// of the n_parties tables are proven here; once every LOCAL table has arrived -- or failed: a failed table arrives as a
+// failure marker, so that the other shards are not left waiting -- one thread calls `xch` with an array of n_parties slots
+// (only the local ones filled) and gets the union back.
 struct BusMeet {
-    static constexpr int MAX = 5;
+    static constexpr int MAX = 72, MAX_PUB = 32;
     std::mutex m;
     std::condition_variable cv;
     int n_parties = 0, arrived = 0;
-    bool failed = false;
+    bool failed = false, done = false;
     std::vector<uint64_t> pub[MAX], cap[MAX];
+    bool local[MAX], deposited[MAX], local_failed[MAX];
+    size_t capw = 64;  // words of a trace cap (4 << cap_height); set by the caller for a sharded proof, by the first arrival otherwise
+    const vx_hr_exchange* xch = nullptr;
+    BusMeet() {
+        for (int t = 0; t < MAX; ++t) local[t] = true, deposited[t] = local_failed[t] = false;
+    }
+    int n_local() const {
+        int k = 0;
+        for (int t = 0; t < n_parties; ++t) k += local[t] ? 1 : 0;
+        return k;
+    }
     static int32_t meet(BusMeet* r, int who, const uint64_t* pub, size_t n_pub, const uint64_t* cap, size_t cap_words, uint64_t* chal, size_t n_chal);
-    void fail();
+    void fail(int who = -1);  // who >= 0: the table whose prover gave up (counts as arrived when it had not deposited yet)
+    void finish_locked(size_t cap_words);  // all local tables are in: exchange with the other shards (if any), release everybody
 };
 struct BusParty {
     BusMeet* rv;
@@ -48,7 +64,7 @@ struct JustificationTables {
 };
 size_t vx_justification_proof_bound(const vx_stark_config* cfg, size_t n_authorities, int32_t* rc);
 int32_t vx_justification_tables_start(vx_ctx* const ctxs[3], const vx_justification* just, const vx_stark_config* cfg, BusMeet* rv, int first,
-                                      int32_t (*pre)(vx_ctx*, void*), void* pre_user, JustificationTables* jt);
+                                      int32_t (*pre)(vx_ctx*, void*), void* pre_user, JustificationTables* jt, unsigned mask = 7 /* bit t: start table t here */);
 // joins the three threads; the first failure with a message of its own is reported on `ctx` (the justification's own rules
 // come first); returns VX_OK when all three proofs exist
 int32_t vx_justification_tables_join(vx_ctx* ctx, JustificationTables* jt);

@@ -490,63 +490,91 @@ int32_t vx_header_range_verify(const vx_stark_config* cfg, const uint64_t* blob,
                                uint32_t trusted_block, const uint8_t trusted_hash[32], uint64_t authority_set_id, const uint8_t* authority_set_hash,
                                uint32_t target_block, const uint8_t out96[96], char* err, size_t errlen) {
     if (!cfg || !blob || !trusted_hash || !out96) return VX_ERR_ARG;
-    const size_t HDR = VX_HR_BLOB_HEADER_WORDS;
-    NEED(len > HDR && blob[0] == VX_HR_BLOB_MAGIC, "bad header_range blob");
+    NEED(len > VX_HR_BLOB_FIXED_WORDS + 1 && blob[0] == VX_HR_BLOB_MAGIC, "bad header_range blob");
     NEED(blob[1] == max_headers && blob[2] == trusted_block && blob[3] == target_block, "blob is for a different request");
     NEED(memcmp(blob + 4, out96, 96) == 0, "public outputs differ from the blob");
     NEED(target_block > trusted_block, "empty block range");
-    // proofs in blob order: hash chain, authority-set commitment, Merkle, Ed25519, SHA-512
-    size_t plen[5], off[5], tot = HDR;
-    for (int t = 0; t < 5; ++t) {
-        plen[t] = blob[16 + t];
+    const uint64_t S = blob[16];
+    NEED(S >= 1 && S <= VX_HR_MAX_SEGMENTS && S <= (uint64_t)target_block - trusted_block, "bad number of map segments");
+    const size_t HDR = VX_HR_BLOB_FIXED_WORDS + (size_t)S;
+    NEED(len > HDR, "bad header_range blob");
+    // proofs in blob order: the S hash-chain segments, authority-set commitment, Merkle, Ed25519, SHA-512
+    const size_t NB = (size_t)S + 4;
+    std::vector<size_t> plen(NB), off(NB);
+    size_t tot = HDR;
+    for (size_t t = 0; t < NB; ++t) {
+        plen[t] = t < S ? blob[VX_HR_BLOB_FIXED_WORDS + t] : blob[17 + (t - S)];
         NEED(plen[t] <= len, "blob lengths are inconsistent");
         off[t] = tot, tot += plen[t];
     }
     NEED(tot == len, "blob lengths are inconsistent");
-    const bool justified = plen[1] > 0;
-    NEED(justified ? (plen[3] > 0 && plen[4] > 0) : (plen[3] == 0 && plen[4] == 0), "blob carries part of a justification");
+    for (size_t s = 0; s < S; ++s) NEED(plen[s] > 0, "a map segment of the hash-chain table is missing");
+    NEED(plen[S + 1] > 0, "the Merkle table is missing");
+    const bool justified = plen[S] > 0;
+    NEED(justified ? (plen[S + 2] > 0 && plen[S + 3] > 0) : (plen[S + 2] == 0 && plen[S + 3] == 0), "blob carries part of a justification");
     NEED(!authority_set_hash || justified, "blob carries no authority-set commitment proof");
     NEED(!justified || authority_set_hash, "blob carries a justification: the request's authority_set_hash is needed to check it");
     const int tree_id = max_headers == 256 ? 7 : max_headers == 512 ? 8 : max_headers == 16 ? 9 : 0;
     NEED(tree_id, "max_headers %u has no Merkle AIR", max_headers);
-    // bus order (the order of the shared-challenge transcript): hash chain, Merkle, commitment, Ed25519, SHA-512
-    const int n_tab = justified ? 5 : 2, blob_idx[5] = {0, 2, 1, 3, 4};
-    const uint64_t *proof[5], *ppub[5], *pcap[5];
-    size_t pl[5], npub[5];
-    for (int t = 0; t < n_tab; ++t) {
-        proof[t] = blob + off[blob_idx[t]], pl[t] = plen[blob_idx[t]];
+    // bus order (the order of the shared-challenge transcript): segments, Merkle, commitment, Ed25519, SHA-512
+    const size_t n_tab = (size_t)S + (justified ? 4 : 1);
+    std::vector<const uint64_t*> proof(n_tab), ppub(n_tab), pcap(n_tab);
+    std::vector<size_t> pl(n_tab), npub(n_tab);
+    for (size_t t = 0; t < n_tab; ++t) {
+        const size_t b = t < S ? t : (t == S ? S + 1 : (t == S + 1 ? S : t));  // bus index -> blob index
+        proof[t] = blob + off[b], pl[t] = plen[b];
         NEED(vx_stark_proof_peek(proof[t], pl[t], cfg->cap_height, &ppub[t], &npub[t], &pcap[t]), "proofs are too short to hold a trace cap");
     }
-    // public inputs of every table, rebuilt from the request and the claimed outputs
-    uint64_t pub[20], tpub[17], spub[10], epub[2], hpub[15];
-    for (int j = 0; j < 8; ++j) {
-        uint32_t a, b;
-        memcpy(&a, trusted_hash + 4 * j, 4);
-        memcpy(&b, out96 + 4 * j, 4);  // target_header_hash = first 32 output bytes
-        pub[j] = a;
-        pub[8 + j] = b;
+    // public inputs of every table, rebuilt from the request and the claimed outputs.  The hash a segment ends with is read from
+    // its own proof and must be the hash the next segment starts from (the reference's reduce step, subchain_verification.rs:
+    // 247-257): the first starts at trusted_header_hash / trusted_block + 1, the last ends at target_header_hash / target_block,
+    // block numbers run on from segment to segment, and every segment counts its Merkle leaves from trusted_block + 1
+    std::vector<uint64_t> spubs(20 * (size_t)S);
+    uint64_t tpub[17], cpub[10], epub[2], hpub[15];
+    uint64_t next_first = (uint64_t)trusted_block + 1;
+    for (size_t s = 0; s < S; ++s) {
+        uint64_t* pub = spubs.data() + 20 * s;
+        NEED(npub[s] == 20, "a hash-chain segment has %zu public inputs", npub[s]);
+        for (int j = 0; j < 8; ++j) {
+            uint32_t a;
+            memcpy(&a, trusted_hash + 4 * j, 4);
+            pub[j] = s == 0 ? a : ppub[s - 1][8 + j];                        // starts where the previous segment ended
+            uint32_t b;
+            memcpy(&b, out96 + 4 * j, 4);                                     // target_header_hash = first 32 output bytes
+            pub[8 + j] = s + 1 == S ? b : ppub[s][8 + j];                     // an inner boundary: the segment's own claim, bound by the next one
+            NEED(pub[8 + j] >> 32 == 0, "a segment hash limb is out of range");
+        }
+        const uint64_t last = s + 1 == S ? target_block : ppub[s][17];
+        NEED(last >= next_first && last <= target_block, "the block numbers of the map segments do not run on");
+        pub[16] = next_first, pub[17] = last;
+        pub[18] = (uint64_t)trusted_block + 1;  // the block of Merkle leaf 0
+        pub[19] = 1;                            // bus on
+        next_first = last + 1;
     }
-    pub[16] = (uint64_t)trusted_block + 1;
-    pub[17] = target_block;
-    pub[18] = (uint64_t)trusted_block + 1;  // the block of Merkle leaf 0
-    pub[19] = 1;            // bus on
+    NEED(next_first == (uint64_t)target_block + 1, "the map segments do not cover the block range");
     for (int j = 0; j < 16; ++j)  // state_root_merkle_root || data_root_merkle_root as big-endian words
         tpub[j] = ((uint64_t)out96[32 + 4 * j] << 24) | ((uint64_t)out96[33 + 4 * j] << 16) | ((uint64_t)out96[34 + 4 * j] << 8) | out96[35 + 4 * j];
     tpub[16] = (uint64_t)target_block - trusted_block;  // the number of headers = of enabled leaves: the Merkle table MUST take every header's roots from the bus
     NEED(tpub[16] <= max_headers, "the block range exceeds max_headers");
-    int air[5] = {VX_AIR_BLAKE_CHAIN, tree_id, VX_AIR_SHA_CHAIN, 0, 0};
-    const uint64_t* want[5] = {pub, tpub, spub, epub, hpub};
-    const size_t n_want[5] = {20, 17, 10, 2, 15};
+    std::vector<int> air(n_tab, VX_AIR_BLAKE_CHAIN);
+    std::vector<const uint64_t*> want(n_tab);
+    std::vector<size_t> n_want(n_tab, 20);
+    for (size_t s = 0; s < S; ++s) want[s] = spubs.data() + 20 * s;
+    air[S] = tree_id, want[S] = tpub, n_want[S] = 17;
     if (justified) {
-        const int32_t rc = vx_justification_expect(ppub[2], npub[2], ppub[3], npub[3], npub[4], authority_set_hash, authority_set_id, out96, target_block, blob[21], spub, epub,
-                                                   hpub, air + 2, err, errlen);
+        int jair[3];
+        const int32_t rc = vx_justification_expect(ppub[S + 1], npub[S + 1], ppub[S + 2], npub[S + 2], npub[S + 3], authority_set_hash, authority_set_id, out96, target_block, blob[21], cpub, epub,
+                                                   hpub, jair, err, errlen);
         if (rc != VX_OK) return rc;
+        air[S + 1] = jair[0], air[S + 2] = jair[1], air[S + 3] = jair[2];
+        want[S + 1] = cpub, want[S + 2] = epub, want[S + 3] = hpub;
+        n_want[S + 1] = 10, n_want[S + 2] = 2, n_want[S + 3] = 15;
     }
     // the lookup challenges every proof must have used: a transcript of all public inputs and trace caps
     uint64_t chal[4];
-    v_shared_challenges_n(ppub, npub, pcap, (size_t)n_tab, (size_t)4 << cfg->cap_height, chal, 4);
+    v_shared_challenges_n(ppub.data(), npub.data(), pcap.data(), n_tab, (size_t)4 << cfg->cap_height, chal, 4);
     uint64_t bus[2] = {0, 0};
-    for (int t = 0; t < n_tab; ++t) {
+    for (size_t t = 0; t < n_tab; ++t) {
         const uint64_t* apub = nullptr;
         int L = 0;
         const int32_t rc = vx_stark_verify_ext(cfg, proof[t], pl[t], air[t], want[t], n_want[t], chal, &apub, &L, err, errlen);

@@ -23,6 +23,7 @@ SYMBOLS = [
     "vx_poseidon_permute_batch", "vx_merkle_build", "vx_merkle_free", "vx_merkle_cap", "vx_merkle_open", "vx_merkle_leaf_digests",
     "vx_fri_fold", "vx_fri_layer_tree", "vx_fri_leaves", "vx_fri_pow",
     "vx_stark_default_config", "vx_stark_proof_bound", "vx_stark_prove", "vx_stark_verify", "vx_header_range_proof_bound", "vx_header_range_prove", "vx_header_range_verify",
+    "vx_header_range_proof_bound_ex", "vx_header_range_prove_ex", "vx_header_range_merge",
     "vx_blake2b_256_batch", "vx_sha256_pairs", "vx_verify_subchain", "vx_blake_chain_trace",
     "vx_ed25519_verify_batch", "vx_verify_simple_justification", "vx_sha_chain_trace",
     "vx_verify_epoch_end_header", "vx_rotate_proof_bound", "vx_rotate_prove", "vx_rotate_verify",
@@ -120,6 +121,10 @@ def load_library():
         "vx_stark_proof_bound": [C.c_int, C.POINTER(StarkConfig), C.c_int, C.POINTER(sz)],
         "vx_header_range_proof_bound": [C.POINTER(StarkConfig), sz, sz, C.POINTER(sz)],
         "vx_header_range_prove": [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.POINTER(JustificationStruct), C.POINTER(StarkConfig), vp, vp, sz, C.POINTER(sz)],
+        "vx_header_range_proof_bound_ex": [C.POINTER(StarkConfig), sz, sz, C.c_uint32, C.POINTER(sz)],
+        "vx_header_range_prove_ex": [vp, vp, sz, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.POINTER(JustificationStruct), C.POINTER(StarkConfig),
+                                     C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, sz, C.POINTER(sz)],
+        "vx_header_range_merge": [vp, vp, sz, vp, sz, C.POINTER(sz), C.c_char_p, sz],
         "vx_stark_verify": [C.POINTER(StarkConfig), vp, sz, C.c_int, vp, sz, C.c_char_p, sz],
         "vx_header_range_verify": [C.POINTER(StarkConfig), vp, sz, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, C.c_uint32, vp, C.c_char_p, sz],
         "vx_stark_prove": [vp, C.c_int, C.POINTER(StarkConfig), vp, C.c_int, vp, sz, vp, sz, C.POINTER(sz)],
@@ -178,19 +183,57 @@ def stark_verify(proof, cfg=None, expect_air=0, expect_public=None):
         raise VxError(rc, err.value.decode())
 
 
-HR_HDR = 22  # words before the first proof in a header_range blob
-HR_MAGIC = 0x3545474E41525248  # "HRRANGE5"
+HR_FIXED = 22  # fixed words of a header_range blob's header; the lengths of its S hash-chain segments follow
+HR_HDR = HR_FIXED + 1  # words before the first proof of an UNSEGMENTED blob (S = 1)
+HR_MAGIC = 0x3645474E41525248  # "HRRANGE6"
+
+
+def blob_segments(blob):
+    return int(blob[16])
+
+
+def split_blob_segments(blob):
+    """([hash-chain segment proofs], authority-commitment, Merkle, Ed25519, SHA-512) of a header_range blob (include/vx.h: the last
+    two and the commitment are empty when it was proven without a justification; a shard's blob holds its own tables only)."""
+    S = blob_segments(blob)
+    off = HR_FIXED + S
+    segs = []
+    for s in range(S):
+        ln = int(blob[HR_FIXED + s])
+        segs.append(blob[off: off + ln])
+        off += ln
+    rest = []
+    for t in range(4):
+        ln = int(blob[17 + t])
+        rest.append(blob[off: off + ln])
+        off += ln
+    return (segs,) + tuple(rest)
 
 
 def split_blob(blob):
-    """(hash-chain, authority-commitment, Merkle, Ed25519, SHA-512) proofs of a header_range blob (the last two and the second
-    are empty when it was proven without a justification)."""
-    out, off = [], HR_HDR
-    for t in range(5):
-        ln = int(blob[16 + t])
-        out.append(blob[off: off + ln])
-        off += ln
-    return tuple(out)
+    """(hash-chain, authority-commitment, Merkle, Ed25519, SHA-512) proofs of an unsegmented header_range blob."""
+    parts = split_blob_segments(blob)
+    assert len(parts[0]) == 1, "a segmented blob: use split_blob_segments"
+    return (parts[0][0],) + parts[1:]
+
+
+class HrExchange(C.Structure):
+    _fields_ = [("fn", C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t)), ("user", C.c_void_p)]
+
+
+def merge_blobs(blobs):
+    """The request's blob from the blobs of the shards of one proof (vx_header_range_merge; host only)."""
+    L = load_library()
+    arrs = [np.ascontiguousarray(b, dtype=np.uint64) for b in blobs]
+    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    lens = (C.c_size_t * len(arrs))(*[a.size for a in arrs])
+    out = np.empty(sum(a.size for a in arrs), dtype=np.uint64)
+    n = C.c_size_t(0)
+    err = C.create_string_buffer(256)
+    rc = L.vx_header_range_merge(ptrs, lens, len(arrs), _ptr(out), out.size, C.byref(n), err, 256)
+    if rc != 0:
+        raise VxError(rc, err.value.decode())
+    return out[: n.value]
 
 
 def header_range_verify(blob, max_headers, trusted_block, trusted_hash, target_block, out96, cfg=None, authority_set_hash=None, authority_set_id=0):
@@ -420,21 +463,42 @@ class Context:
         self._ck(self.L.vx_stark_aux_trace(self.h, air_id, trace_buf.h, log_n, _ptr(pub) if pub.size else None, pub.size, _ptr(ch), ch.size, out.h, _ptr(apub)))
         return out, apub
 
-    def header_range_prove(self, headers_buf, stride, sizes, max_headers, trusted_block, trusted_hash, target_block, cfg=None, out=None, just=None):
+    def header_range_prove(self, headers_buf, stride, sizes, max_headers, trusted_block, trusted_hash, target_block, cfg=None, out=None, just=None,
+                           n_segments=1, shard=None):
         """HeaderRangeCircuit::prove for a chain resident in HBM -> (96-byte output, proof blob words).
-        just: PackedJustification (or None to skip the justification check)."""
+        just: PackedJustification (or None to skip the justification check); n_segments: map segments of the hash-chain table;
+        shard = (index, n_shards, exchange): prove only this shard's tables -- exchange(words) must return the element-wise sum
+        over the shards of the uint64 array it is given (an all-reduce); the blob then holds the local proofs (lib.merge_blobs)."""
         cfg = cfg or self.stark_config()
         sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
         th = np.frombuffer(bytes(trusted_hash), dtype=np.uint8).copy()
         chunks = int(((sizes.astype(np.int64) + 127) // 128).sum())
         need = C.c_size_t(0)
-        self._ck(self.L.vx_header_range_proof_bound(C.byref(cfg), chunks, just.struct.num_authorities if just is not None else 0, C.byref(need)))
+        self._ck(self.L.vx_header_range_proof_bound_ex(C.byref(cfg), chunks, just.struct.num_authorities if just is not None else 0, n_segments, C.byref(need)))
         if out is None or out.size < need.value:
             out = np.empty(need.value, dtype=np.uint64)
         out96 = np.zeros(96, dtype=np.uint8)
-        self._ck(self.L.vx_header_range_prove(self.h, headers_buf.h, stride, _ptr(sizes), sizes.size, max_headers, trusted_block, _ptr(th),
-                                              target_block, C.byref(just.struct) if just is not None else None, C.byref(cfg), _ptr(out96),
-                                              _ptr(out), out.size, C.byref(need)))
+        xch, idx, n_shards = None, 0, 1
+        if shard is not None:
+            idx, n_shards, fn = shard
+            errs = []
+
+            def cb(_user, words, n_words):
+                try:
+                    a = np.ctypeslib.as_array(words, shape=(n_words,))
+                    a[:] = fn(a.copy())
+                    return 0
+                except BaseException as e:  # noqa: BLE001 -- reported to the prover as a failed exchange
+                    errs.append(e)
+                    return -1
+
+            xch = HrExchange(HrExchange._fields_[0][1](cb), None)
+        rc = self.L.vx_header_range_prove_ex(self.h, headers_buf.h, stride, _ptr(sizes), sizes.size, max_headers, trusted_block, _ptr(th),
+                                              target_block, C.byref(just.struct) if just is not None else None, C.byref(cfg), n_segments, idx, n_shards,
+                                              C.byref(xch) if xch is not None else None, _ptr(out96), _ptr(out), out.size, C.byref(need))
+        if shard is not None and errs:
+            raise errs[0]
+        self._ck(rc)
         return out96.tobytes(), out[: need.value]
 
     def verify_epoch_end_header(self, header_buf, num_authorities, start_position, new_pubkeys, max_authorities=300):

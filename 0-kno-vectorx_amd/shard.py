@@ -121,3 +121,55 @@ def gather_blobs_abi(ctx, comm, blob):
         words = np.concatenate([words, np.zeros(8 - words.size % 8, dtype=np.uint8)])
     got = ctx.gather_proofs(comm.handle, comm.world, words.view(np.uint64))
     return [got[r].view(np.uint8)[: np.asarray(blob).nbytes] for r in range(comm.world)]
+
+
+# ---- intra-proof sharding: ONE proof, its tables spread over the ranks ------------------------------
+# The hash-chain table of a header_range proof is split into map segments (the reference's MapReduce jobs,
+# circuits/builder/subchain_verification.rs:72-79); segments and the four small tables are independent STARK tables on one
+# logUp bus, table t (bus order) proven by rank t mod world.  The ranks meet ONCE per proof: after every table's trace is
+# committed they all-reduce a small array of (public inputs, trace cap) slots -- the shared lookup challenges are a transcript of
+# all of them -- and at the end rank 0 gathers the partial blobs and merges them (vx_header_range_merge).
+def exchange_over(dist, device=None):
+    """The all-reduce vx_header_range_prove_ex asks for (element-wise wrapping sum of uint64 words) on torch.distributed.
+    It runs on one of the prover's host threads while the caller's thread is inside the C call."""
+    import torch
+
+    def exchange(words):
+        t = torch.from_numpy(np.ascontiguousarray(words).view(np.int64).copy())
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)  # int64 wrap-around = uint64 wrap-around; only one rank fills a slot anyway
+        return t.cpu().numpy().view(np.uint64)
+
+    return exchange
+
+
+def prove_header_range_sharded(ctx, dist, headers_buf, stride, sizes, max_headers, trusted_block, trusted_hash, target_block, cfg=None, just=None,
+                               n_segments=8, device=None, lib=None):
+    """Every rank calls this with the SAME input (resident in ITS GPU's memory); returns (out96, blob) on rank 0 -- the blob is
+    byte for byte what one prover makes with the same segment count -- and (out96, None) elsewhere."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    out96, part = ctx.header_range_prove(headers_buf, stride, sizes, max_headers, trusted_block, trusted_hash, target_block, cfg, just=just, n_segments=n_segments,
+                                         shard=(rank, world, exchange_over(dist, device)))
+    return out96, gather_and_merge(part, dist, device=device, lib=lib)
+
+
+def gather_and_merge(part, dist, device=None, lib=None):
+    """Partial blobs of the shards (different lengths) -> the merged blob on rank 0, None elsewhere."""
+    import torch
+
+    part = np.ascontiguousarray(part, dtype=np.uint64)
+    mx = torch.tensor([part.size], dtype=torch.int64, device=device or "cpu")
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    padded = np.zeros(int(mx.item()) + 1, dtype=np.uint64)
+    padded[0] = part.size
+    padded[1: 1 + part.size] = part
+    got = gather_blobs(padded.view(np.uint8), dist, device=device)
+    if dist.get_rank() != 0:
+        return None
+    blobs = [g.view(np.uint64) for g in got]
+    if lib is None:
+        from . import lib as lib_mod
+
+        lib = lib_mod
+    return lib.merge_blobs([b[1: 1 + int(b[0])] for b in blobs])

@@ -266,6 +266,51 @@ def cpu_baseline(vx, ctx):
     }
 
 
+def sharded_proof_bench(args, vx, ctx, wl, dist, rank, world, local_rank, barrier):
+    """--shard-proof S: K steps = K proofs, each proven by ALL ranks together (table t of the proof on rank t mod world); strong scaling."""
+    S = args.shard_proof
+    ch = wl.chain
+    tdev = "cuda" if dist and dist.get_backend() == "nccl" else None
+
+    def step():
+        if dist is None:
+            return ctx.header_range_prove(wl.d_headers, ch.stride, ch.sizes, N_HEADERS, ch.trusted_block, ch.trusted_hash, ch.target_block, wl.cfg, just=wl.just, n_segments=S)
+        return vx.shard.prove_header_range_sharded(ctx, dist, wl.d_headers, ch.stride, ch.sizes, N_HEADERS, ch.trusted_block, ch.trusted_hash, ch.target_block, wl.cfg,
+                                                   just=wl.just, n_segments=S, device=tdev, lib=vx.lib)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out96, blob = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        import torch
+
+        t = torch.tensor([elapsed], device=tdev or "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        assert out96 == ch.expected_outputs(N_HEADERS)
+        vx.lib.header_range_verify(blob, N_HEADERS, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, wl.cfg,
+                                   authority_set_hash=wl.just.sh.tobytes() if wl.just is not None else None,
+                                   authority_set_id=wl.just.struct.authority_set_id if wl.just is not None else 0)
+        print(json.dumps({
+            "metric": f"header_range_{N_HEADERS} proofs/sec, ONE proof sharded over the GPUs", "value": round(args.steps / elapsed, 4), "unit": "proofs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u64 (Goldilocks) / u8 (hashes)", "data": "synthetic",
+            "config": {"workload": f"header_range_{N_HEADERS} ({PROFILE}), 300 authorities: ONE input for all ranks; hash-chain table in {S} map segments; table t of "
+                                   f"{S + 4} (segments, Merkle, commitment, Ed25519, SHA-512) proven by rank t mod {world}; one all-reduce of the trace caps per proof, "
+                                   "partial blobs gathered and merged on rank 0", "map_segments": S, "blob_bytes": int(blob.size * 8),
+                       "exchange": f"torch.distributed all_reduce ({dist.get_backend()})" if dist else "none (1 rank)"},
+            "verified": True}), flush=True)
+    ctx.close()
+    if dist:
+        dist.destroy_process_group()
+
+
 def launch_ranks(n_gpus, argv):
     """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run as a CHILD process (one
     rank per GPU, rendezvous on 127.0.0.1) and exit with its code.  Nothing in this parent has touched the GPU or
@@ -323,6 +368,10 @@ def main():
     ap.add_argument("--no-pmax", action="store_true", help="skip the extra Pmax measurement of the default line")
     ap.add_argument("--circuit", default="header_range", choices=("header_range", "rotate"),
                     help="header_range = the headline metric (default); rotate = BASELINE.json configs[3]")
+    ap.add_argument("--shard-proof", type=int, default=0, metavar="S",
+                    help="STRONG scaling: every step is ONE proof whose tables (S map segments of the hash-chain table + the four small tables) are "
+                         "spread over the ranks (SURVEY 8 f2); the ranks exchange their trace caps once per proof and rank 0 merges the partial blobs. "
+                         "Not the headline metric (that is one proof per rank, weak scaling)")
     ap.add_argument("--dry-launch", action="store_true", help="rehearse the multi-rank launch on CPU (gloo), no GPU work")
     args = ap.parse_args()
     global N_HEADERS, PROFILE
@@ -360,6 +409,8 @@ def main():
     # runs its five tables on five streams); with the runtime's default of 4 hardware queues 7.26 / 7.22 with 3 / 4
     inflight = args.inflight or (4 if PROFILE == "P15k" else 2)  # a Pmax proof holds 4x the memory of a P15k one
     inflight = max(1, min(inflight, args.steps))
+    if args.shard_proof:
+        inflight = 1  # one proof at a time, spread over the ranks
     # `inflight` proofs are proven concurrently on this GPU: each worker thread owns a context (stream, pool) and an
     # input resident in HBM and takes the next step from a shared counter, so the tail of one proof (FRI layers, host
     # transcript, queries -- small kernels and syncs) overlaps the bulk kernels of another.  K steps are still K proofs.
@@ -367,7 +418,8 @@ def main():
 
     ctxs = [vx.Context(local_rank) for _ in range(inflight)]
     ctx = ctxs[0]
-    wls = [(RotateWorkload if args.circuit == "rotate" else Workload)(vx, c, seed_offset=rank) for c in ctxs]
+    # (one proof sharded over the ranks: every rank holds the SAME input)
+    wls = [(RotateWorkload if args.circuit == "rotate" else Workload)(vx, c, seed_offset=0 if args.shard_proof else rank) for c in ctxs]
     wl = wls[0]
 
     def barrier():
@@ -378,6 +430,9 @@ def main():
 
             dist.barrier()
             torch.cuda.synchronize()
+
+    if args.shard_proof:
+        return sharded_proof_bench(args, vx, ctx, wls[0], dist, rank, world, local_rank, barrier)
 
     def run_steps(n_steps):
         lock, nxt, last, errs = threading.Lock(), [0], [None] * inflight, []

@@ -314,16 +314,24 @@ int32_t vx_verify_simple_justification(vx_ctx* ctx, uint32_t block_number, const
                                        const uint8_t* validator_signed, uint32_t num_authorities, uint32_t max_authorities);
 
 /* ---- top level: HeaderRangeCircuit::prove (circuits/header_range.rs:26-59 via Circuit::prove, :167).
- * Inputs as vx_verify_subchain.  Output blob (uint64 words), VX_HR_BLOB_HEADER_WORDS = 22 header words: the magic "HRRANGE5"
- * (VX_HR_BLOB_MAGIC), max_headers, trusted_block, target_block, the 96 public output bytes (12 words), the lengths of the
- * VX_HR_BLOB_TABLES = 5 proofs (words 16..20) and the round of the precommit (word 21); then the proofs in blob order: hash
- * chain (BlakeChainAir), authority-set commitment (ShaChainAir), SHA-256 Merkle trees (ShaTreeAir), Ed25519 (EdAir), SHA-512
- * (Sha512Air) -- the last three and the second are empty when no justification was given.  EVERY statement of the circuit is
- * inside these STARKs: the five tables share one logUp bus under challenges drawn after all their trace
- * caps; the Merkle table's public inputs are the two roots and the number of headers, which forces it to take every header's
- * roots from the bus.  Not done: the five proofs are not aggregated into one succinct proof. */
-#define VX_HR_BLOB_MAGIC 0x3545474e41525248ULL /* "HRRANGE5" little-endian */
-enum { VX_HR_BLOB_HEADER_WORDS = 22, VX_HR_BLOB_TABLES = 5 };
+ * Inputs as vx_verify_subchain.  Output blob (uint64 words): the magic "HRRANGE6" (VX_HR_BLOB_MAGIC), max_headers,
+ * trusted_block, target_block, the 96 public output bytes (12 words), word 16 = S, the number of MAP SEGMENTS of the hash-chain
+ * table (1 = one table over the whole range), words 17..20 = the lengths of the authority-set commitment, Merkle, Ed25519 and
+ * SHA-512 proofs, word 21 = the round of the precommit, words 22 .. 22 + S = the lengths of the S hash-chain proofs: a header
+ * of VX_HR_BLOB_FIXED_WORDS + S words; then the proofs -- the S segments in range order (BlakeChainAir), commitment
+ * (ShaChainAir), SHA-256 Merkle trees (ShaTreeAir), Ed25519 (EdAir), SHA-512 (Sha512Air); the commitment / Ed25519 / SHA-512
+ * proofs are empty when no justification was given.  EVERY statement of the circuit is inside these STARKs:
+ * the tables share one logUp bus under challenges drawn after all their trace caps; the Merkle table's public inputs are the
+ * two roots and the number of headers, which forces it to take every header's roots from the bus.
+ * MAP SEGMENTS (the reference's MapReduce jobs, circuits/builder/subchain_verification.rs:72-79, 81-232): segment s proves the
+ * headers of a contiguous part of the range -- it starts from the hash segment s - 1 ends with, numbers its blocks on and counts
+ * its Merkle leaves from the first block of the range; the verifier checks those links between the segments' public inputs
+ * (the reference's reduce step, :233-289, without recursion).  Segments are independent tables: vx_header_range_prove_ex can
+ * prove a subset of the tables on this GPU (n_shards > 1, one process per GPU) -- the shards of one proof exchange their trace
+ * caps once (vx_hr_exchange) and vx_header_range_merge puts their partial blobs together.  Not done: the proofs of a request
+ * are not aggregated into one succinct proof (S segments open S times the columns: a segmented blob is larger). */
+#define VX_HR_BLOB_MAGIC 0x3645474e41525248ULL /* "HRRANGE6" little-endian */
+enum { VX_HR_BLOB_FIXED_WORDS = 22, VX_HR_MAX_SEGMENTS = 64 };
 /* The justification witness of circuits/vars.rs:40-46 (host buffers; what HintSimpleJustification
  * returns, justification.rs:69-82) plus the two EVM inputs it is checked against. */
 typedef struct vx_justification {
@@ -342,6 +350,27 @@ int32_t vx_header_range_prove(vx_ctx* ctx, const vx_buf* headers, size_t stride,
                               uint32_t max_headers, uint32_t trusted_block, const uint8_t trusted_hash[32],
                               uint32_t target_block, const vx_justification* just, const vx_stark_config* cfg,
                               uint8_t out96[96], uint64_t* proof_out, size_t proof_cap, size_t* proof_len);
+/* The same proof with the hash-chain table split into n_segments map segments (1 .. VX_HR_MAX_SEGMENTS, at most one per
+ * header; a segment is never smaller than the 2^16-row lookup tables, so more segments than compressions / 4096 only add
+ * padding), and optionally only the tables of shard `shard` of `n_shards`: table t in bus order (segments, Merkle, commitment,
+ * Ed25519, SHA-512) belongs to shard t mod n_shards.  With n_shards > 1 every shard calls this function on its own GPU with the
+ * SAME inputs; `exchange` is called once per proof on each shard, from a prover thread, and must return the element-wise
+ * (wrapping) SUM over the shards of the word array it is given (an all-reduce: every shard fills only the slots of its own
+ * tables -- public inputs and trace cap -- so the sum is the union).  The blob then holds the local proofs only (the other
+ * lengths are 0); vx_header_range_merge makes the request's blob from the shards' blobs.  n_shards = 1: exchange is not used. */
+typedef struct vx_hr_exchange {
+    int32_t (*fn)(void* user, uint64_t* words, size_t n_words); /* 0 = ok */
+    void* user;
+} vx_hr_exchange;
+int32_t vx_header_range_proof_bound_ex(const vx_stark_config* cfg, size_t n_chunks, size_t n_authorities, uint32_t n_segments, size_t* n_words);
+int32_t vx_header_range_prove_ex(vx_ctx* ctx, const vx_buf* headers, size_t stride, const uint32_t* sizes, size_t n_fetched,
+                                 uint32_t max_headers, uint32_t trusted_block, const uint8_t trusted_hash[32],
+                                 uint32_t target_block, const vx_justification* just, const vx_stark_config* cfg,
+                                 uint32_t n_segments, uint32_t shard, uint32_t n_shards, const vx_hr_exchange* exchange,
+                                 uint8_t out96[96], uint64_t* proof_out, size_t proof_cap, size_t* proof_len);
+/* blobs of the n_shards shards of ONE proof (same request, same segment count) -> the request's blob; host only */
+int32_t vx_header_range_merge(const uint64_t** blobs, const size_t* blob_lens, size_t n_blobs, uint64_t* out, size_t out_cap, size_t* out_len,
+                              char* err, size_t errlen);
 /* HeaderRangeCircuit verify: checks the blob of vx_header_range_prove against the request (the five fields of the
  * circuit's 80-byte EVM input, header_range.rs:30-37) and the claimed 96 output bytes: every table's STARK under the
  * shared lookup challenges, the bus balance, and -- when the blob carries a justification -- that the committed

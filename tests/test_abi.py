@@ -77,18 +77,23 @@ def test_loading_the_library_raises_the_hardware_queue_limit():
 
 
 def test_blob_format_named_in_the_header_is_the_bindings(vx):
-    """include/vx.h is the boundary: the blob magic, header length and table count it states are the ones the binding splits
-    blobs by (the header still described "HRRANGE3" with two proofs)."""
+    """include/vx.h is the boundary: the blob magic and header layout it states are the ones the binding splits blobs by
+    (the header still described "HRRANGE3" with two proofs)."""
     text = open(os.path.join(ROOT, "include", "vx.h")).read()
     magic = int(re.search(r"#define VX_HR_BLOB_MAGIC (0x[0-9a-fA-F]+)ULL", text).group(1), 16)
-    hdr = int(re.search(r"VX_HR_BLOB_HEADER_WORDS = (\d+)", text).group(1))
-    tables = int(re.search(r"VX_HR_BLOB_TABLES = (\d+)", text).group(1))
-    assert magic == vx.lib.HR_MAGIC and magic.to_bytes(8, "little") == b"HRRANGE5" and b"HRRANGE5".decode() in text
-    assert "HRRANGE3" not in text
+    fixed = int(re.search(r"VX_HR_BLOB_FIXED_WORDS = (\d+)", text).group(1))
+    assert magic == vx.lib.HR_MAGIC and magic.to_bytes(8, "little") == b"HRRANGE6" and "HRRANGE6" in text
+    assert "HRRANGE3" not in text and "HRRANGE5" not in text and fixed == vx.lib.HR_FIXED
     import numpy as np
 
-    blob = np.zeros(hdr + 15, dtype=np.uint64)
-    blob[0] = magic
-    blob[16:16 + tables] = [1, 2, 3, 4, 5]
-    parts = vx.lib.split_blob(blob)
-    assert len(parts) == tables and [len(p) for p in parts] == [1, 2, 3, 4, 5]  # blob order: hash chain, commitment, Merkle, Ed25519, SHA-512
+    # a blob of three map segments: header = fixed words + one length per segment; blob order = segments, commitment, Merkle, Ed25519, SHA-512
+    blob = np.zeros(fixed + 3 + 6 + 7 + 8 + 1 + 2 + 3 + 4, dtype=np.uint64)
+    blob[0], blob[16] = magic, 3
+    blob[17:21] = [1, 2, 3, 4]
+    blob[fixed:fixed + 3] = [6, 7, 8]
+    segs, p_sha, p_tree, p_ed, p_h = vx.lib.split_blob_segments(blob)
+    assert [len(p) for p in segs] == [6, 7, 8] and [len(p) for p in (p_sha, p_tree, p_ed, p_h)] == [1, 2, 3, 4]
+    one = np.zeros(fixed + 1 + 5 + 1 + 2 + 3 + 4, dtype=np.uint64)
+    one[0], one[16], one[fixed] = magic, 1, 5
+    one[17:21] = [1, 2, 3, 4]
+    assert [len(p) for p in vx.lib.split_blob(one)] == [5, 1, 2, 3, 4]

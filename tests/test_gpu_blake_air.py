@@ -137,8 +137,8 @@ def test_forged_act_flag_cannot_be_proven(ctx, vx, oracle):
 def oracle_verify_blob(vx, blob, cfg, max_headers):
     """The reference verifier on a header_range blob: every table under the shared challenges (a transcript of all trace caps in
     bus order: hash chain, Merkle, commitment, Ed25519, SHA-512), and the bus balance."""
-    p_blake, p_sha, p_tree, p_ed, p_h = vx.lib.split_blob(blob)
-    tables = [(p_blake, B.ID), (p_tree, T.IDS[max_headers])]
+    segs, p_sha, p_tree, p_ed, p_h = vx.lib.split_blob_segments(blob)
+    tables = [(p, B.ID) for p in segs] + [(p_tree, T.IDS[max_headers])]
     if p_sha.size:
         from oracle import ed_air as E
         from oracle import sha512_air as H5
@@ -185,7 +185,8 @@ def test_header_range_prove_end_to_end(ctx, vx, oracle):
     with pytest.raises(vx.VxError):  # a request that names an authority set cannot be answered without a justification
         vx.lib.header_range_verify(blob, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg, authority_set_hash=good.sh.tobytes(), authority_set_id=sid)
     with pytest.raises(vx.VxError):  # ... and a justification cannot be dropped from the blob
-        cut = np.concatenate([b2[:17], np.array([0, b2[18], 0, 0, 0], dtype=np.uint64), vx.lib.split_blob(b2)[0], vx.lib.split_blob(b2)[2]])
+        # header words: 16 = segment count, 17..20 = commitment / Merkle / Ed25519 / SHA-512 lengths, 21 = round, 22 = the segment's length
+        cut = np.concatenate([b2[:17], np.array([0, b2[18], 0, 0, 0, b2[22]], dtype=np.uint64), vx.lib.split_blob(b2)[0], vx.lib.split_blob(b2)[2]])
         vx.lib.header_range_verify(cut, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, o2, cfg)
     bad_round = b2.copy()
     bad_round[21] += np.uint64(1)  # the precommit's round is part of the signed message
@@ -360,8 +361,111 @@ def test_full_size_justified_header_range(ctx, vx, n_headers):
     parts2 = vx.lib.split_blob(blob2)
     vx.lib.header_range_verify(blob2, n_headers, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg, authority_set_hash=other.authority_set_hash, authority_set_id=other.set_id)
     hdr = first[:vx.lib.HR_HDR].copy()
-    hdr[16 + 3] = parts2[3].size
+    hdr[19] = parts2[3].size  # word 19 = the length of the Ed25519 proof
     graft = np.concatenate([hdr, parts[0], parts[1], parts[2], parts2[3], parts[4]])
     with pytest.raises(vx.VxError):
         vx.lib.header_range_verify(graft, n_headers, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg, **ver)
     hb.free()
+
+
+def test_map_segments_small(ctx, vx, oracle):
+    """The hash-chain table split into map segments (the reference's MapReduce jobs, subchain_verification.rs:72-79, 81-232):
+    every segment is its own table on the bus; the reference verifier accepts all of them under the shared challenges and the
+    bus balances; the product verifier also checks the links between consecutive segments (the reduce step, :233-289)."""
+    ch = vx.synth.Chain(16, profile="Ptiny", stride=512)
+    cfg, ocfg = ctx.stark_config(num_queries=6), dict(S.DEFAULT_CFG, num_queries=6)
+    hb = ctx.from_host(ch.headers)
+    args = (hb, 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
+    good = vx.lib.PackedJustification(vx.synth.Justification(ch.target_block, ch.target_hash, n_auth=9, n_signed=7), 12)
+    ver = dict(authority_set_hash=good.sh.tobytes(), authority_set_id=good.struct.authority_set_id)
+    out1, b1 = ctx.header_range_prove(*args, just=good)
+    b1 = b1.copy()
+    for n_seg in (2, 3, 16):
+        out, blob = ctx.header_range_prove(*args, just=good, n_segments=n_seg)
+        blob = blob.copy()
+        assert out == out1 == ch.expected_outputs(16) and vx.lib.blob_segments(blob) == n_seg
+        vx.lib.header_range_verify(blob, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, out, cfg, **ver)
+        infos = oracle_verify_blob(vx, blob, ocfg, 16)
+        pubs = [i["public_inputs"] for i in infos[:n_seg]]
+        assert pubs[0][:8] == limbs(ch.trusted_hash) and pubs[-1][8:16] == limbs(out[:32])
+        firsts = [p[16] for p in pubs]
+        assert firsts[0] == ch.trusted_block + 1 and pubs[-1][17] == ch.target_block
+        for a, b in zip(pubs, pubs[1:]):
+            assert a[8:16] == b[:8] and b[16] == a[17] + 1       # hash and numbering links
+        assert all(p[18:] == [ch.trusted_block + 1, 1] for p in pubs)   # leaves counted from the range's first block
+        if n_seg == 16:
+            assert all(p[16] == p[17] for p in pubs)              # one header per segment
+        segs = vx.lib.split_blob_segments(blob)[0]
+        if n_seg >= 3:
+            # two segments swapped: each proof is valid, the chain of links is not
+            sw = [segs[1], segs[0]] + list(segs[2:])
+            hdr = blob[: vx.lib.HR_FIXED + n_seg].copy()
+            hdr[vx.lib.HR_FIXED: vx.lib.HR_FIXED + n_seg] = [p.size for p in sw]
+            rest = blob[vx.lib.HR_FIXED + n_seg + sum(p.size for p in segs):]
+            with pytest.raises(vx.VxError):
+                vx.lib.header_range_verify(np.concatenate([hdr] + sw + [rest]), 16, ch.trusted_block, ch.trusted_hash, ch.target_block, out, cfg, **ver)
+        # a segment taken from the unsegmented proof does not fit either (other range, other challenges)
+        if n_seg == 2:
+            hdr = blob[: vx.lib.HR_FIXED + 2].copy()
+            one = vx.lib.split_blob(b1)[0]
+            hdr[vx.lib.HR_FIXED] = one.size
+            rest = blob[vx.lib.HR_FIXED + 2 + segs[0].size:]
+            with pytest.raises(vx.VxError):
+                vx.lib.header_range_verify(np.concatenate([hdr, one, rest]), 16, ch.trusted_block, ch.trusted_hash, ch.target_block, out, cfg, **ver)
+    with pytest.raises(vx.VxError):  # more segments than headers
+        ctx.header_range_prove(*args, just=good, n_segments=17)
+
+
+def test_shards_of_one_proof_merge_to_the_segmented_blob(vx):
+    """Intra-proof sharding: the tables of ONE proof proven by two shards -- here two host threads with a context
+    each on the one GPU, exchanging their trace caps through the all-reduce the C ABI asks for -- and merged: byte for byte the
+    blob a single prover makes with the same segment count.  (Across GPUs the exchange is a torch.distributed all-reduce:
+    shard.prove_header_range_sharded, tests/test_gpu_bench_ranks.py.)"""
+    import threading
+
+    ch = vx.synth.Chain(16, profile="Ptiny", stride=512)
+    sj = vx.synth.Justification(ch.target_block, ch.target_hash, n_auth=9, n_signed=7)
+    n_seg, n_shards = 4, 2
+    with vx.Context(0) as c0:
+        cfg = c0.stark_config(num_queries=6)
+        out_ref, ref = c0.header_range_prove(c0.from_host(ch.headers), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg,
+                                             just=vx.lib.PackedJustification(sj, 12), n_segments=n_seg)
+        ref = ref.copy()
+    bar, slots, res, errs = threading.Barrier(n_shards), [None] * n_shards, [None] * n_shards, []
+
+    def exchange_for(k):
+        def exchange(words):
+            slots[k] = words
+            bar.wait(timeout=120)
+            total = sum(slots[1:], slots[0].copy())  # uint64 wrap-around sum
+            bar.wait(timeout=120)
+            return total
+        return exchange
+
+    def worker(k):
+        try:
+            with vx.Context(0) as c:
+                just = vx.lib.PackedJustification(sj, 12)
+                out, blob = c.header_range_prove(c.from_host(ch.headers), 512, ch.sizes, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, c.stark_config(num_queries=6),
+                                                 just=just, n_segments=n_seg, shard=(k, n_shards, exchange_for(k)))
+                res[k] = (out, blob.copy())
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+            bar.abort()
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(n_shards)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    assert res[0][0] == res[1][0] == out_ref
+    lens = [[p.size for p in vx.lib.split_blob_segments(b)[0]] + [p.size for p in vx.lib.split_blob_segments(b)[1:]] for _, b in res]
+    assert all((a == 0) != (b == 0) for a, b in zip(*lens))  # every table in exactly one shard (bus order t mod 2: blob order differs, the partition does not)
+    merged = vx.lib.merge_blobs([b for _, b in res])
+    assert merged.size == ref.size and (merged == ref).all()
+    vx.lib.header_range_verify(merged, 16, ch.trusted_block, ch.trusted_hash, ch.target_block, out_ref, cfg, authority_set_hash=sj.authority_set_hash, authority_set_id=sj.set_id)
+    with pytest.raises(vx.VxError):  # a shard's blob alone is not a proof
+        vx.lib.header_range_verify(res[0][1], 16, ch.trusted_block, ch.trusted_hash, ch.target_block, out_ref, cfg, authority_set_hash=sj.authority_set_hash, authority_set_id=sj.set_id)
+    with pytest.raises(vx.VxError):  # the same shard twice
+        vx.lib.merge_blobs([res[0][1], res[0][1]])

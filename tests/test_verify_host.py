@@ -146,14 +146,32 @@ def test_circuit_verifiers_on_gpu_made_blobs(vx):
         with pytest.raises(vx.VxError):
             ok(**kw)
     rng = np.random.default_rng(5)
-    for w in list(range(22)) + [int(x) for x in rng.integers(22, hr.size, size=60)]:
+    for w in list(range(23)) + [int(x) for x in rng.integers(23, hr.size, size=60)]:
         bad = hr.copy()
         bad[w] ^= np.uint64(1) << np.uint64(rng.integers(64))
         with pytest.raises(vx.VxError):
             ok(blob=bad)
-    for cut in (0, 5, 22, hr.size // 2, hr.size - 1):
+    for cut in (0, 5, 22, 23, hr.size // 2, hr.size - 1):
         with pytest.raises(vx.VxError):
             ok(blob=hr[:cut])
+    # the same request proven with the hash-chain table in three map segments: accepted; any header word (segment count, the
+    # segment lengths) or proof word flipped, segments swapped or one dropped: rejected
+    seg = z["hr_blob_seg3"]
+    assert vx.lib.blob_segments(seg) == 3
+    ok(blob=seg)
+    for w in list(range(25)) + [int(x) for x in rng.integers(25, seg.size, size=60)]:
+        bad = seg.copy()
+        bad[w] ^= np.uint64(1) << np.uint64(rng.integers(64))
+        with pytest.raises(vx.VxError):
+            ok(blob=bad)
+    segs, p_sha, p_tree, p_ed, p_h = vx.lib.split_blob_segments(seg)
+    F = vx.lib.HR_FIXED
+    for order in ([1, 0, 2], [0, 2, 1], [0, 1], [0, 0, 2]):
+        hdr = seg[:F + 3].copy()
+        hdr[16] = len(order)
+        hdr = np.concatenate([hdr[:F], np.array([segs[k].size for k in order], dtype=np.uint64)])
+        with pytest.raises(vx.VxError):
+            ok(blob=np.concatenate([hdr] + [segs[k] for k in order] + [p_sha, p_tree, p_ed, p_h]))
     rot, out32, rsh, rid = z["rot_blob"], z["rot_out32"].tobytes(), z["rot_set_hash"].tobytes(), int(z["rot_set_id"])
     vx.lib.rotate_verify(rot, rid, rsh, out32, cfg)
     for args in ((rid + 1, rsh, out32), (rid, flip(rsh), out32), (rid, rsh, flip(out32, 31))):

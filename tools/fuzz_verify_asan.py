@@ -104,7 +104,7 @@ def child(iters):
         rc = L.vx_header_range_verify(C.byref(cfg), b.ctypes.data_as(vp), b.size, 256, 100, h32, 0, h32, 356, out96, err, 256)
         assert rc != 0
         total += 1
-    # a real blob (tests/golden/circuit_blobs.npz, made on the GPU): five proofs behind a 22-word header
+    # a real blob (tests/golden/circuit_blobs.npz, made on the GPU): five proofs behind a 23-word header (22 fixed words + one segment length)
     z = np.load(os.path.join(ROOT, "tests", "golden", "circuit_blobs.npz"), allow_pickle=False)
     cfg2 = StarkConfig()
     for k, v in dict(S.DEFAULT_CFG, num_queries=2).items():
@@ -125,7 +125,7 @@ def child(iters):
         if kind == 0:
             p[rng.integers(n)] ^= np.uint64(1) << np.uint64(rng.integers(64))
         elif kind == 1:
-            p[rng.integers(0, 22)] = np.uint64([0, 1, 21, 22, n, n - 22, 2**32, 2**63, 2**64 - 1][rng.integers(9)])
+            p[rng.integers(0, 23)] = np.uint64([0, 1, 21, 22, n, n - 22, 2**32, 2**63, 2**64 - 1][rng.integers(9)])
         elif kind == 2:
             p = p[: rng.integers(0, n)]
         elif kind == 3:
