@@ -49,6 +49,9 @@ __device__ __forceinline__ uint32_t lane_off(int tid, int log_m) {  // in BYTES 
 }
 __device__ __forceinline__ uint64_t ld_at(const uint64_t* p, uint32_t byte_off) { return *(const uint64_t*)((const char*)p + byte_off); }
 __device__ __forceinline__ void st_at(uint64_t* p, uint32_t byte_off, uint64_t v) { *(uint64_t*)((char*)p + byte_off) = v; }
+// strided DIF passes (they end in the between-pass twiddle) take VX_NTT3_NC columns per block; the DIT side would have to keep the
+// 16 products alive through a column's rounds (its kernels sit at the register budget already)
+__host__ __device__ constexpr int cols_per_block(int mode, int lr);
 template <int F, int LT>
 __device__ __forceinline__ size_t e_off(int e, int log_m) {  // uniform
     const int ep = e << F;
@@ -70,6 +73,14 @@ __device__ __forceinline__ size_t e_off(int e, int log_m) {  // uniform
 #ifndef VX_NTT3_WAVES
 #define VX_NTT3_WAVES(LR, MODE) 3
 #endif
+// columns per block of a strided DIF pass: the between-pass twiddle w = hi * lo of a (tile, lane, element) is the same for
+// every column, so the block walks VX_NTT3_NC columns per tile and computes it once (16 products kept in registers)
+#ifndef VX_NTT3_NC
+#define VX_NTT3_NC 2
+#endif
+namespace n3 {
+__host__ __device__ constexpr int cols_per_block(int mode, int lr) { return (mode == 0 && lr <= 8) ? VX_NTT3_NC : 1; }
+}  // namespace n3
 #ifndef VX_NTT3_DIRECT0
 #define VX_NTT3_DIRECT0 0  // 1: a three-round DIT pass without zero padding also loads straight into layout 0 (A/B aid)
 #endif
@@ -145,9 +156,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_NTT3_WAV
     // consecutive elements per lane: with VX_NTT3_DIRECT0 it stores (loads) them from there -- 128 contiguous bytes per lane as
     // 16-byte accesses -- instead of paying one more LDS exchange for 512-byte wave rows
     constexpr int FE = (NR == 3 && (EB > 0 || (VX_NTT3_DIRECT0 && MODE == 1))) ? 0 : S::F_EDGE;
-    __shared__ __attribute__((aligned(16))) uint64_t lds[4096 + 256 + (WBN ? WBN : 1) + (T2N ? T2N : 1)];
+    // strided passes (LR <= 8) look their first-round twiddles up in a full-circle table of w_(2^LR) (at most 256 entries) instead of
+    // keeping 15 of them per lane in registers: the registers go to the 16 between-pass products shared by the columns of a block
+    constexpr int WAN = (LR > 4 && LR <= 8) ? (1 << LR) : 0;
+    __shared__ __attribute__((aligned(16))) uint64_t lds[4096 + 256 + (WBN ? WBN : 1) + (T2N ? T2N : 1) + (WAN ? WAN : 1)];
     uint64_t* const wsB = lds + 4096 + 256;
     uint64_t* const t2s = wsB + (WBN ? WBN : 1);
+    uint64_t* const wsA = t2s + (T2N ? T2N : 1);
     const int tid = threadIdx.x;
     const int log_m = a.log_sub - LR;
     const bool strided = log_m > 0;                     // m > 1: this pass carries the between-pass twiddle
@@ -158,20 +173,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_NTT3_WAV
 
     // round-A twiddles of this lane, w_(2^LR)^(R bitrev4(e)) with R = rho mod 2^(LR-4) = tid >> LT in layout 8: the same for
     // every tile, so they live in registers (the sign of the upper half circle is folded in here, once)
-    uint64_t wA[15];
-    if (LR > 4) {
-        const int RA = tid >> LT;
+    if (WAN) {  // w_(2^LR)^j for every j (the upper half circle is the negation): no sign fix-up at the look-up
+        const int j = tid & (WAN - 1), e4096 = j << (12 - LR);
+        if (tid < WAN) wsA[j] = (e4096 & 2048) ? GL_P - a.w12[e4096 & 2047] : a.w12[e4096 & 2047];
+    }
+    uint64_t wA[WAN ? 1 : 15];
+    const int RA = tid >> LT;
+    if (LR > 4 && !WAN) {
 #pragma unroll
         for (int e = 1; e < 16; ++e) {
             const int idx = (RA * n3::brev_c(e, 4)) << (12 - LR);   // exponent of w_4096, below 4096
             const uint64_t w = a.w12[idx & 2047];
-            wA[e - 1] = (idx & 2048) ? GL_P - w : w;
+            wA[WAN ? 0 : e - 1] = (idx & 2048) ? GL_P - w : w;
         }
     }
-    if (WBN || T2N) __syncthreads();
+    if (WBN || T2N || WAN) __syncthreads();
+    auto twiddle_a = [&](uint64_t* y) {
+        if (WAN) {
+#pragma unroll
+            for (int e = 1; e < 16; ++e) y[e] = gl_mul_nc(y[e], wsA[(RA * n3::brev_c(e, 4)) & (WAN ? WAN - 1 : 0)]);
+        } else n3::mul15(y, wA);
+    };
 
-    const uint64_t* src = a.src + blockIdx.y * a.src_col_stride;
-    uint64_t* dst = a.dst + blockIdx.y * a.dst_col_stride;
+    constexpr int NC = n3::cols_per_block(MODE, LR);
+    const size_t col_first = (size_t)blockIdx.y * NC;
+    const int ncol_here = (int)(a.n_cols - col_first < (size_t)NC ? a.n_cols - col_first : (size_t)NC);
     const int log_tps = a.log_sub - 12;                 // tiles per sub-array
     const size_t tile0 = (size_t)blockIdx.x * VX_NTT3_TPB;
     const int n_here = (int)(a.n_tiles - tile0 < (size_t)VX_NTT3_TPB ? a.n_tiles - tile0 : (size_t)VX_NTT3_TPB);
@@ -204,19 +230,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_NTT3_WAV
     }
 
     gl96::X x[16];
-    uint64_t y[16];
+    uint64_t y[16], wip[NC > 1 ? 16 : 1];
 #pragma unroll 1
     for (int t = 0; t < n_here; ++t) {
         const size_t tile = tile0 + t;
         const size_t sub = tile >> log_tps;
         const uint32_t col0 = (uint32_t)(tile - (sub << log_tps)) << LT;
         const size_t base = (sub << a.log_sub) + col0;
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) {  // (unrolled: as a rolled loop the compiler hoists per-element address terms across it and spills)
+        if (NC > 1 && cc >= ncol_here) break;
+        const uint64_t* src = a.src + (col_first + cc) * a.src_col_stride;
+        uint64_t* dst = a.dst + (col_first + cc) * a.dst_col_stride;
         if (MODE == 0) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) x[e] = gl96::from64(n3::ld_at(src + base + n3::e_off<8, LT>(e, log_m), off8));
             gl96::dif_round<4, INV>(x);
             n3::fold16(y, x);
-            if (LR > 4) n3::mul15(y, wA);
+            if (LR > 4) twiddle_a(y);
             if (NR >= 2) {
                 __syncthreads();
                 n3::exch_write<8>(y, lds, s8);
@@ -243,8 +274,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_NTT3_WAV
                 }
             }
             if (strided) {
+                if (NC > 1) {
+                    if (cc == 0) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) y[e] = gl_mul_nc(y[e], ip_twiddle(col0, e));
+                        for (int e = 0; e < 16; ++e) wip[NC > 1 ? e : 0] = ip_twiddle(col0, e);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) y[e] = gl_mul_nc(y[e], wip[NC > 1 ? e : 0]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) y[e] = gl_mul_nc(y[e], ip_twiddle(col0, e));
+                }
             }
             if (a.scale > 1) {
 #pragma unroll
@@ -308,7 +348,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_NTT3_WAV
                 __syncthreads();
                 n3::exch_read<8>(y, lds, s8);
             }
-            if (LR > 4) n3::mul15(y, wA);
+            if (LR > 4) twiddle_a(y);
             n3::widen(x, y);
             gl96::dit_round<4, INV>(x);
             n3::fold16(y, x);
@@ -316,5 +356,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_NTT3_WAV
 #pragma unroll
             for (int e = 0; e < 16; ++e) n3::st_at(dst + base + n3::e_off<8, LT>(e, log_m), off8, y[e]);
         }
+      }
     }
 }

@@ -40,6 +40,7 @@ struct PassArgs {
     const uint64_t* tw2_hi;
     int tw2_bits;
     unsigned tw2_total;  // entries of lo | hi back to back (k_ntt3 stages them in LDS when they fit)
+    size_t n_cols;       // k_ntt3: a block may take several columns (blockIdx.y counts groups of n3::cols_per_block)
     size_t n_tiles;  // tiles per column in this pass (a block takes NTT_TPB consecutive ones)
     int dbg_skip;  // timing experiments only (VX_NTT_SKIP bit mask): 1 = tile twiddles, 2 = inter-pass twiddle, 4 = butterflies
 };
@@ -467,8 +468,10 @@ static inline size_t lds_bytes(int lr, int lT) {
 static bool g_ntt_v1 = getenv("VX_NTT_V1") != nullptr;  // debugging aid: force the LDS-stage kernel
 static bool g_ntt_v2 = getenv("VX_NTT_V2") != nullptr;  // A/B aid: the run-time-shape tile kernel instead of k_ntt3
 template <int MODE, int LR>
-static void launch_ntt3(vx_ctx* ctx, const PassArgs& a, unsigned gx, size_t n_cols, int inverse) {
-    const dim3 grid(gx, (unsigned)n_cols), block(256);
+static void launch_ntt3(vx_ctx* ctx, PassArgs& a, unsigned gx, size_t n_cols, int inverse) {
+    a.n_cols = n_cols;
+    constexpr int NC = n3::cols_per_block(MODE, LR);
+    const dim3 grid(gx, (unsigned)((n_cols + NC - 1) / NC)), block(256);
     if constexpr (MODE == 1 && LR == 12) {  // the zero-padding first pass of an LDE (forward only: the callers never expand an inverse)
         if (a.expand_bits == 1) { hipLaunchKernelGGL((k_ntt3<1, 0, 12, 1>), grid, block, 0, ctx->stream, a); return; }
         if (a.expand_bits == 2) { hipLaunchKernelGGL((k_ntt3<1, 0, 12, 2>), grid, block, 0, ctx->stream, a); return; }
