@@ -93,9 +93,22 @@ class RcclComm:
         import threading
 
         res = []
-        th = threading.Thread(target=lambda: res.append(self._lib.ncclCommInitRank(C.byref(comm), world, u, rank)), daemon=True)
-        th.start()
-        th.join(float(os.environ.get("VX_RCCL_INIT_TIMEOUT", "180")))
+        # the RCCL build PyTorch ships prints a version banner on STDOUT at the first communicator of a process: stdout carries the
+        # bench's one JSON line, so file descriptor 1 points at stderr while the call runs
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            th = threading.Thread(target=lambda: res.append(self._lib.ncclCommInitRank(C.byref(comm), world, u, rank)), daemon=True)
+            th.start()
+            th.join(float(os.environ.get("VX_RCCL_INIT_TIMEOUT", "180")))
+        finally:
+            try:
+                C.CDLL(None).fflush(None)  # the banner sits in C stdio's buffer (stdout is a pipe or a file: fully buffered)
+            except OSError:
+                pass
+            os.dup2(saved, 1)
+            os.close(saved)
         if th.is_alive():
             print(f"RcclComm: rank {rank} of {world} is still inside ncclCommInitRank -- another rank did not join; giving up", file=sys.stderr, flush=True)
             os._exit(3)

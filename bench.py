@@ -297,7 +297,7 @@ def sharded_proof_bench(args, vx, ctx, wl, dist, rank, world, local_rank, barrie
         vx.lib.header_range_verify(blob, N_HEADERS, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, wl.cfg,
                                    authority_set_hash=wl.just.sh.tobytes() if wl.just is not None else None,
                                    authority_set_id=wl.just.struct.authority_set_id if wl.just is not None else 0)
-        print(json.dumps({
+        emit({
             "metric": f"header_range_{N_HEADERS} proofs/sec, ONE proof sharded over the GPUs", "value": round(args.steps / elapsed, 4), "unit": "proofs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u64 (Goldilocks) / u8 (hashes)", "data": "synthetic",
@@ -305,10 +305,32 @@ def sharded_proof_bench(args, vx, ctx, wl, dist, rank, world, local_rank, barrie
                                    f"{S + 4} (segments, Merkle, commitment, Ed25519, SHA-512) proven by rank t mod {world}; one all-reduce of the trace caps per proof, "
                                    "partial blobs gathered and merged on rank 0", "map_segments": S, "blob_bytes": int(blob.size * 8),
                        "exchange": f"torch.distributed all_reduce ({dist.get_backend()})" if dist else "none (1 rank)"},
-            "verified": True}), flush=True)
+            "verified": True})
     ctx.close()
     if dist:
         dist.destroy_process_group()
+
+
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """stdout carries exactly ONE JSON line.  Libraries print there too (the RCCL build PyTorch ships writes a version banner to stdout
+    at its first communicator): from here on file descriptor 1 of this process points at stderr and emit() writes to the real stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    data = (json.dumps(line) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
 
 
 def launch_ranks(n_gpus, argv):
@@ -346,7 +368,7 @@ def dry_launch(args):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"dry_launch": True, "n_gpus": world, "gpus_arg": args.gpus, "ranks": got}), flush=True)
+        emit({"dry_launch": True, "n_gpus": world, "gpus_arg": args.gpus, "ranks": got})
 
 
 def main():
@@ -383,6 +405,7 @@ def main():
             sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     elif int(os.environ["WORLD_SIZE"]) != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
+    quiet_stdout()
     if args.dry_launch:
         return dry_launch(args)
     rank = int(os.environ.get("RANK", "0"))
@@ -573,10 +596,11 @@ def main():
             "proof_scope": "every statement of HeaderRangeCircuit is inside a STARK: all 96 public output bytes (Blake2b header-chain table + SHA-256 Merkle table "
                            "of the state / data roots), the authority-set commitment, and the justification -- floor(2n/3)+1 = 201 Ed25519 signatures over the precommit of "
                            "the target header (curve table + SHA-512 table), bound to the committed keys; five tables on one logUp bus under shared challenges. "
-                           "NOT done: the five STARKs are not aggregated into one succinct proof (no recursion / Groth16 wrap), and the reference's MapReduce "
-                           "sub-proof structure is replaced by flat tables",
+                           "NOT done: the five STARKs are not aggregated into one succinct proof (no recursion / Groth16 wrap). The reference's MapReduce structure exists as "
+                           "map segments of the hash-chain table linked by the verifier (vx_header_range_prove_ex, bench --shard-proof); this line uses ONE segment",
             "config": {
-                "workload": f"header_range_{N_HEADERS}: {N_HEADERS} x {'15,360-B' if PROFILE == 'P15k' else '35,840-B' if PROFILE == 'Pmax' else '512..35,840-B'} synthetic Avail headers ({PROFILE}), 300 authorities, one input per GPU; "
+                "workload": "" if args.circuit != "header_range" else
+                            f"header_range_{N_HEADERS}: {N_HEADERS} x {'15,360-B' if PROFILE == 'P15k' else '35,840-B' if PROFILE == 'Pmax' else '512..35,840-B'} synthetic Avail headers ({PROFILE}), 300 authorities, one input per GPU; "
                             f"{sum((int(z) + 127) // 128 for z in wl.chain.sizes):,} Blake2b compressions -> BlakeChainAir (byte-lookup AIR) trace 2^{LOG_ROWS} rows x (745 main + 276 logUp) columns + ShaTreeAir (SHA-256 Merkle table, 2^{16 if N_HEADERS == 256 else 17} x 428) "
                             "+ ShaChainAir (2^16 x 418) + EdAir (201 signatures, 2^16 x 1527) + Sha512Air (2^15 x 805) on the same logUp bus",
                 "complete_proof": False,
@@ -592,7 +616,7 @@ def main():
                            "EdAir witness + STARK: [S]B = R + [h]A for 201 signatures -- 253 double-and-add steps of 14 field multiplications each, 16-bit limbs, "
                            "672 logUp range checks per row; h = H mod l in-table",
                            "Sha512Air witness + STARK: H = SHA-512(R || A || precommit) for the same 201 signatures, exchanged with EdAir over the bus"],
-                "missing": ["recursive aggregation of the five STARKs into one succinct proof (f4)", "the reference's MapReduce sub-proof structure (a2 / f2)"],
+                "missing": ["recursive aggregation of the five STARKs into one succinct proof (f4)"],
             },
             "roofline": roof,
         }
@@ -624,7 +648,7 @@ def main():
             }
         elif not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline(vx, ctx)
-        print(json.dumps(line), flush=True)
+        emit(line)
     if comm:
         comm.close()
     for c in ctxs:
