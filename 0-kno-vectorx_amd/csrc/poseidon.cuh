@@ -90,6 +90,68 @@ __device__ __forceinline__ void poseidon_mds_part(const TIn* x, T* y) {
 // (Tried: a 55/9 split with the high part as packed 16-bit dot products, v_dot2_u32_u16, 84 instructions instead of
 // ~140: the permutation went from 66.3 k to 70.6 k cycles -- the dot instructions do not issue at full rate.)
 // RC: 0 = no constants, 1 = the next round's constant for element 0 only (a partial round follows), 12 = all twelve
+#ifndef VX_POSEIDON_FP64
+#define VX_POSEIDON_FP64 0
+#endif
+#if VX_POSEIDON_FP64
+// (Tried, off: tools/ab_poseidon_fp64.sh, profiles/r03_ab_poseidon_fp64.txt -- same outputs, v_add_f64 / v_fma_f64 issue at 4.2 cycles as
+// hoped, but the layer went from 1241 to 1298 cycles and the permutation from 61.7 k to 63.8 k: the 24 conversions and the longer
+// dependent chains cost more than the 48 saved instructions.)
+// The low part in EXACT double-precision arithmetic.  The layer's network grows its inputs by at most 2^8 (every intermediate is a
+// linear form whose absolute coefficients sum to <= 256; + 8 x[0] for the diagonal), so with a 43 / 21 split the low part's
+// intermediates stay below 2^52 -- integers a double holds exactly -- and the high part's below 2^30.  One v_add_f64 / v_fma_f64
+// does what the 64-bit integer form needs a v_lshl_add_u64 (sums) or a two-instruction borrow chain (differences) plus a shift for:
+// 78 instructions for the low part instead of 139.  In: (2^52 + lo43) is assembled as the bit pattern of a double (the mantissa IS the
+// integer) and 2^52 subtracted; out: 2^52 (+ the round constant's low part) is added, which leaves the integer in the mantissa again.
+struct PoseidonRcSplit {
+    uint64_t d[360];  // bit pattern of the double 2^52 + (c mod 2^43)
+    uint32_t h[360];  // c >> 43
+};
+constexpr PoseidonRcSplit poseidon_rc_split() {
+    constexpr uint64_t rc[360] = VX_POSEIDON_RC_FOLDED_INIT;
+    PoseidonRcSplit t{};
+    for (int i = 0; i < 360; ++i) {
+        t.d[i] = 0x4330000000000000ULL + (rc[i] & ((1ULL << 43) - 1));
+        t.h[i] = (uint32_t)(rc[i] >> 43);
+    }
+    return t;
+}
+static __constant__ PoseidonRcSplit POSEIDON_RCT = poseidon_rc_split();
+template <int RC>
+__device__ __forceinline__ void poseidon_mds(uint64_t* s, int rc_next) {
+    constexpr double TWO52 = 4503599627370496.0;
+    double xl[12];
+    uint32_t xh[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const uint32_t lo = (uint32_t)s[i], hi = (uint32_t)(s[i] >> 32);
+        xl[i] = __longlong_as_double((long long)(((uint64_t)(0x43300000u | (hi & 0x7FFu)) << 32) | lo)) - TWO52;
+        xh[i] = hi >> 11;
+    }
+    double yl[12];
+    int32_t yh[12];
+    poseidon_mds_part<double>(xl, yl);
+    poseidon_mds_part<int32_t>(xh, yh);
+    yl[0] += xl[0] * (double)VX_POSEIDON_MDS_DIAG0;
+    yh[0] += (int32_t)(xh[0] * VX_POSEIDON_MDS_DIAG0);
+#pragma unroll
+    for (int r = 0; r < 12; ++r) {
+        double magic = TWO52;
+        uint32_t ah = (uint32_t)yh[r];
+        if (RC == 12 || (RC == 1 && r == 0)) {
+            magic = __longlong_as_double((long long)POSEIDON_RCT.d[rc_next + r]);  // 2^52 + (c mod 2^43), a scalar operand
+            ah += POSEIDON_RCT.h[rc_next + r];                                      // c >> 43
+        }
+        // 0 <= yl + (c & M43) < 2^52: the sum lands in [2^52, 2^53) and its low 52 mantissa bits are the integer
+        const uint64_t al = (uint64_t)__double_as_longlong(yl[r] + magic) & ((1ULL << 52) - 1);
+        const uint64_t w = (uint64_t)(ah >> 21) * GL_EPS + al;  // (ah >> 21) 2^64 = (ah >> 21) eps; < 2^53
+        uint32_t yhi;
+        const bool carry = __builtin_add_overflow((uint32_t)(w >> 32), ah << 11, &yhi);  // + (ah mod 2^21) 2^43
+        const uint64_t y = ((uint64_t)yhi << 32) | (uint32_t)w;
+        s[r] = y + (carry ? (uint64_t)GL_EPS : 0);  // y wrapped to < 2^53: no second carry
+    }
+}
+#else
 template <int RC>
 __device__ __forceinline__ void poseidon_mds(uint64_t* s, int rc_next) {
     constexpr uint64_t M52 = (1ULL << 52) - 1;
@@ -122,6 +184,8 @@ __device__ __forceinline__ void poseidon_mds(uint64_t* s, int rc_next) {
         s[r] = y + (carry ? (uint64_t)GL_EPS : 0);  // y wrapped to < 2^62: no second carry
     }
 }
+
+#endif
 
 __device__ __forceinline__ void poseidon_permute(uint64_t* s) {
     int rc = 12;  // constants of round k+1 are added by the MDS layer of round k
