@@ -15,7 +15,11 @@
 // must match byte for byte (tests/test_gpu_stark.py).
 #include <string.h>
 
+#include <map>
+#include <mutex>
+
 #include "air.cuh"
+#include "air_program.h"
 #include "air_blake.cuh"
 #include "air_sha.cuh"
 #include "air_ed.cuh"
@@ -140,6 +144,54 @@ __global__ __launch_bounds__(QB) __attribute__((amdgpu_waves_per_eu(VX_Q_WAVES, 
         a.q_out[loc.i[j]] = gl_mul(c.result(0, j), zinv[j]);
         a.q_out[N + loc.i[j]] = gl_mul(c.result(1, j), zinv[j]);
     }
+}
+
+// The same evaluation for a registered constraint PROGRAM (include/vx.h vx_air_program; csrc/air_program.h): one LDE point per
+// lane, the register file in LDS (register r of lane t at regs[r * QB + t]: conflict-free), instructions fetched with scalar
+// loads (the program counter is wave-uniform).  Constraints go through the same consumer as the compiled AIRs, so a program
+// that restates a compiled AIR yields the same quotient values.
+struct ProgArgs {
+    const uint64_t* code;    // device: n_code instruction words, then the constants
+    const uint64_t* consts;
+    const uint64_t* per_tab; // device: per periodic column (offset into QuotArgs::periodic, length - 1)
+    int n_code;
+};
+__global__ __launch_bounds__(QB) void k_quotient_prog(QuotArgs a, ProgArgs p) {
+    extern __shared__ uint64_t prog_regs[];
+    using F = Fp;
+    const size_t N = (size_t)1 << a.log_N;
+    const size_t i = (blockIdx.x * (size_t)QB + threadIdx.x) & (N - 1);
+    const size_t step = (size_t)1 << a.rate_bits, inext = (i + step) & (N - 1);
+    Consumer<F> c;
+    c.init(a.apow);
+    const uint64_t x = gl_mul(a.shift, root_pow_f(a.tw, i, a.log_N));
+    const int kz = (int)(i & (step - 1));
+    c.z_last.v[0] = gl_sub(x, a.last);
+    const uint64_t zh_n = gl_mul(a.zh[kz], a.n_inv);
+    c.l_first.v[0] = gl_mul(zh_n, gl_inv(gl_sub(x, 1)));
+    c.l_last.v[0] = gl_mul(gl_mul(zh_n, a.last), gl_inv(gl_sub(x, a.last)));
+    uint64_t* R = prog_regs + threadIdx.x;
+#pragma unroll 1
+    for (int pc = 0; pc < p.n_code; ++pc) {
+        const uint64_t w = p.code[pc];
+        const int op = (int)(w & 0xFF), d = (int)((w >> 8) & 0xFF) * QB, ra = (int)((w >> 16) & 0xFFFF), rb = (int)((w >> 32) & 0xFFFF);
+        switch (op) {
+            case VX_AIRP_LOC: R[d] = a.lde[(size_t)ra * N + i]; break;
+            case VX_AIRP_NXT: R[d] = a.lde[(size_t)ra * N + inext]; break;
+            case VX_AIRP_PER: R[d] = a.periodic[p.per_tab[2 * ra] + (i & p.per_tab[2 * ra + 1])]; break;
+            case VX_AIRP_PUB: R[d] = a.pub[ra]; break;
+            case VX_AIRP_CONST: R[d] = p.consts[ra]; break;
+            case VX_AIRP_ADD: R[d] = gl_add(R[ra * QB], R[rb * QB]); break;
+            case VX_AIRP_SUB: R[d] = gl_sub(R[ra * QB], R[rb * QB]); break;
+            case VX_AIRP_MUL: R[d] = gl_mul(R[ra * QB], R[rb * QB]); break;
+            case VX_AIRP_ASSERT: c.constraint(F{{R[ra * QB]}}); break;
+            case VX_AIRP_ASSERT_TRANSITION: c.transition(F{{R[ra * QB]}}); break;
+            case VX_AIRP_ASSERT_FIRST: c.first_row(F{{R[ra * QB]}}); break;
+            default: c.last_row(F{{R[ra * QB]}}); break;  // VX_AIRP_ASSERT_LAST: registration admits nothing else
+        }
+    }
+    a.q_out[i] = gl_mul(c.result(0, 0), a.zh_inv[kz]);
+    a.q_out[N + i] = gl_mul(c.result(1, 0), a.zh_inv[kz]);
 }
 
 // Openings from the committed LDE: the n points x_i = g * w_n^i (LDE indices i << r) determine a polynomial
@@ -301,6 +353,7 @@ struct AirDesc {
     int aux, chal, auxpub;  // auxiliary round: columns, base-field challenges, published extension values
     int (*plog)(int);       // period (log2) of periodic column q
     gen_aux_fn gen_aux;     // trace + challenges -> auxiliary columns [aux][n] (+ 2*auxpub published words, host)
+    const AirProgram* prog = nullptr;  // a registered constraint program (include/vx.h vx_air_register): launch / count / plog come from it
 };
 template <class Air>
 static int count_q() {
@@ -347,11 +400,26 @@ static const AirDesc AIRS[] = {
     desc<Sha512Air16>(Sha512Air16::periodic_values, vx_sha512_air_gen_aux), desc<Sha512Air10>(Sha512Air10::periodic_values, vx_sha512_air_gen_aux), desc<Sha512Air15>(Sha512Air15::periodic_values, vx_sha512_air_gen_aux),
     desc<EpochEndAir>(EpochEndAir::periodic_values, vx_epoch_air_gen_aux),
 };
+static std::mutex g_prog_desc_mu;
+static std::map<int, AirDesc> g_prog_desc;  // descriptors of registered programs (node addresses are stable)
 static const AirDesc* find_air(int id) {
     for (const AirDesc& d : AIRS)
         if (d.id == id) return &d;
+    if (id >= VX_AIR_USER_BASE) {
+        const AirProgram* pg = vx_air_program_find(id);
+        if (!pg) return nullptr;
+        std::lock_guard<std::mutex> lk(g_prog_desc_mu);
+        auto it = g_prog_desc.find(id);
+        if (it == g_prog_desc.end()) {
+            AirDesc d{};
+            d.id = id, d.cols = (int)pg->cols, d.pub = (int)pg->pub, d.periodic = (int)pg->plog.size(), d.period_log = pg->period_log, d.prog = pg;
+            it = g_prog_desc.emplace(id, d).first;
+        }
+        return &it->second;
+    }
     return nullptr;
 }
+static int air_plog(const AirDesc* air, int q) { return air->prog ? air->prog->plog[q] : air->plog(q); }
 
 // values v[0..p) of a periodic column on the rows -> its values on the LDE coset:
 // P(Y) with P(w_p^k) = v[k]; coset point Y_i = shift^(n/p) * w_{p 2^r}^i, i < p 2^r.
@@ -504,16 +572,17 @@ static int32_t periodic_table_dev(vx_ctx* ctx, const AirDesc* air, int L, int r,
     }
     const size_t n = (size_t)1 << L;
     std::vector<uint64_t> pv;
-    air->periodic_values(pv);
+    if (air->prog) pv = air->prog->periodic;
+    else air->periodic_values(pv);
     size_t total = 0, in_total = 0;
-    for (int q = 0; q < air->periodic; ++q) total += (size_t)1 << (air->plog(q) + r), in_total += (size_t)1 << air->plog(q);
+    for (int q = 0; q < air->periodic; ++q) total += (size_t)1 << (air_plog(air, q) + r), in_total += (size_t)1 << air_plog(air, q);
     VX_CHECK(pv.size() == in_total, "periodic table of AIR %d has %zu values, expected %zu", air->id, pv.size(), in_total);
     uint64_t* d = nullptr;
     VX_HIP(hipMalloc((void**)&d, total * 8));
     std::vector<uint64_t> tab(total);
     size_t off = 0, in_off = 0;
     for (int q = 0; q < air->periodic; ++q) {
-        const int pl = air->plog(q);
+        const int pl = air_plog(air, q);
         const size_t p = (size_t)1 << pl, m = p << r;
         const uint64_t shift_pow = glh::pow(7, n >> pl);
         if (pl <= 6) {
@@ -574,7 +643,7 @@ static int32_t quotient_eval_dev(vx_ctx* ctx, const AirDesc* air, int L, int r, 
         for (int q = 0; q < 2 * air->auxpub && q < 8; ++q) qa.apub[q] = apub[q];
         qa.tw = ctx->tw_fwd.d;
         // powers of the two alphas for the K constraints (the Horner recurrence as a dot product, air.cuh)
-        const int K = air->count();
+        const int K = air->prog ? (int)air->prog->n_constraints : air->count();
         std::vector<uint64_t> apow(2 * (size_t)K);
         uint64_t pw[2] = {1, 1};
         for (int kk = K - 1; kk >= 0; --kk)
@@ -586,8 +655,35 @@ static int32_t quotient_eval_dev(vx_ctx* ctx, const AirDesc* air, int L, int r, 
         VX_CHECK(d_apow_q, "stark prove: out of device memory (alpha powers)");
         VX_HIP(hipMemcpyAsync(d_apow_q, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         qa.apow = d_apow_q;
-        air->launch(qa, ctx->stream);
-        VX_HIP(hipStreamSynchronize(ctx->stream));  // apow (host vector) must outlive the copy
+        std::vector<uint64_t> per_tab;
+        if (air->prog) {
+            // the program on the device (cached per context: programs are immutable), and where each periodic column sits in qa.periodic
+            const AirProgram& pg = *air->prog;
+            const uint64_t key = ((uint64_t)air->id << 16) | 0xFFFFULL;  // (periodic tables use L << 8 | r <= 0x1B03 in the low half)
+            uint64_t* d_code = nullptr;
+            auto it = ctx->periodic_cache.find(key);
+            if (it != ctx->periodic_cache.end()) d_code = it->second;
+            else {
+                std::vector<uint64_t> blob(pg.code);
+                blob.insert(blob.end(), pg.consts.begin(), pg.consts.end());
+                VX_HIP(hipMalloc((void**)&d_code, blob.size() * 8));
+                VX_HIP(hipMemcpy(d_code, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
+                ctx->periodic_cache[key] = d_code;
+            }
+            size_t off = 0;
+            for (size_t q = 0; q < pg.plog.size(); ++q) {
+                const size_t plen = (size_t)1 << (pg.plog[q] + r);
+                per_tab.push_back(off), per_tab.push_back(plen - 1);
+                off += plen;
+            }
+            uint64_t* d_per_tab = mem.alloc(per_tab.size() ? per_tab.size() : 1);
+            VX_CHECK(d_per_tab, "stark prove: out of device memory (program tables)");
+            if (!per_tab.empty()) VX_HIP(hipMemcpyAsync(d_per_tab, per_tab.data(), per_tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            ProgArgs pa{d_code, d_code + pg.code.size(), d_per_tab, (int)pg.code.size()};
+            const size_t N = (size_t)1 << LN;
+            hipLaunchKernelGGL(k_quotient_prog, dim3((unsigned)((N + QB - 1) / QB)), dim3(QB), pg.n_regs * QB * sizeof(uint64_t), ctx->stream, qa, pa);
+        } else air->launch(qa, ctx->stream);
+        VX_HIP(hipStreamSynchronize(ctx->stream));  // apow / per_tab (host vectors) must outlive the copies
         VX_HIP(hipGetLastError());
     }
     return VX_OK;

@@ -8,12 +8,17 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
+#include <memory>
+#include <mutex>
+
 #include "air.cuh"
 #include "air_blake.cuh"
 #include "air_sha.cuh"
 #include "air_ed.cuh"
 #include "air_epoch.cuh"
 #include "air_sha512.cuh"
+#include "air_program.h"
 #include "air_sha_tree.cuh"
 #include "glh_poseidon.h"
 #include "vx_bus.h"
@@ -80,6 +85,7 @@ struct AirV {
     void (*eval)(const HostRow&, const HostRow&, const Fx*, const Fx*, const Fx*, const Fx*, Consumer<Fx>&);
     int aux, chal, auxpub;
     int (*plog)(int);
+    const AirProgram* prog = nullptr;  // a registered constraint program instead of a compiled AIR
 };
 template <class Air>
 void eval_host(const HostRow& l, const HostRow& n, const Fx* per, const Fx* pub, const Fx* chal, const Fx* apub, Consumer<Fx>& c) {
@@ -155,6 +161,120 @@ int32_t v_fail(char* err, size_t errlen, const char* fmt, ...) {
     } while (0)
 }  // namespace
 
+
+// ---- run-time AIR descriptors: the registry (process-wide; programs are immutable and never freed, ids never reused)
+namespace {
+std::mutex g_airp_mu;
+std::map<int, std::shared_ptr<const AirProgram>> g_airp;       // live ids
+std::vector<std::shared_ptr<const AirProgram>> g_airp_retired;  // kept alive: a prover may still hold the pointer
+int g_airp_next = VX_AIR_USER_BASE;
+int32_t airp_fail(char* err, size_t errlen, const char* fmt, ...) {
+    if (err && errlen) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(err, errlen, fmt, ap);
+        va_end(ap);
+    }
+    return VX_ERR_ARG;
+}
+#define AIRP_NEED(cond, ...) \
+    do {                     \
+        if (!(cond)) return airp_fail(err, errlen, __VA_ARGS__); \
+    } while (0)
+}  // namespace
+const AirProgram* vx_air_program_find(int id) {
+    std::lock_guard<std::mutex> lk(g_airp_mu);
+    auto it = g_airp.find(id);
+    return it == g_airp.end() ? nullptr : it->second.get();
+}
+extern "C" {
+int32_t vx_air_register(const vx_air_program* in, int* air_id, char* err, size_t errlen) {
+    if (!in || !air_id) return VX_ERR_ARG;
+    AIRP_NEED(in->cols >= 1 && in->cols <= VX_AIRP_MAX_COLS, "air program: %u columns (1..%d)", in->cols, VX_AIRP_MAX_COLS);
+    AIRP_NEED(in->n_public <= 64, "air program: %u public inputs (at most 64)", in->n_public);
+    AIRP_NEED(in->n_periodic <= 256 && (in->n_periodic == 0 || (in->periodic_log && in->periodic_values)), "air program: bad periodic columns");
+    AIRP_NEED(in->n_regs >= 1 && in->n_regs <= VX_AIRP_MAX_REGS, "air program: %u registers (1..%d)", in->n_regs, VX_AIRP_MAX_REGS);
+    AIRP_NEED(in->n_consts <= 65536 && (in->n_consts == 0 || in->consts), "air program: bad constant table");
+    AIRP_NEED(in->code && in->n_code >= 1 && in->n_code <= VX_AIRP_MAX_CODE, "air program: %u instructions (1..%d)", in->n_code, VX_AIRP_MAX_CODE);
+    auto pg = std::make_shared<AirProgram>();
+    pg->cols = in->cols, pg->pub = in->n_public, pg->n_regs = in->n_regs;
+    size_t n_per_values = 0;
+    for (uint32_t q = 0; q < in->n_periodic; ++q) {
+        AIRP_NEED(in->periodic_log[q] <= VX_AIRP_MAX_PERIOD_LOG, "air program: periodic column %u has period 2^%u (at most 2^%d)", q, in->periodic_log[q], VX_AIRP_MAX_PERIOD_LOG);
+        pg->plog.push_back(in->periodic_log[q]);
+        if (in->periodic_log[q] > pg->period_log) pg->period_log = in->periodic_log[q];
+        n_per_values += (size_t)1 << in->periodic_log[q];
+    }
+    pg->periodic.assign(in->periodic_values, in->periodic_values + n_per_values);
+    for (uint64_t v : pg->periodic) AIRP_NEED(v < glh::P, "air program: non-canonical periodic value");
+    pg->consts.assign(in->consts, in->consts + in->n_consts);
+    for (uint64_t v : pg->consts) AIRP_NEED(v < glh::P, "air program: non-canonical constant");
+    pg->code.assign(in->code, in->code + in->n_code);
+    // operands, def-before-use and degrees by abstract interpretation (degree of a register: columns and periodic columns 1)
+    std::vector<int> deg(in->n_regs, -1);
+    for (uint32_t pc = 0; pc < in->n_code; ++pc) {
+        const uint64_t w = pg->code[pc];
+        const AirpInsn i = airp_decode(w);
+        AIRP_NEED((w >> 48) == 0, "air program: instruction %u has reserved bits set", pc);
+        auto reg_ok = [&](int r) { return r >= 0 && r < (int)in->n_regs; };
+        auto src = [&](int r) { return reg_ok(r) && deg[r] >= 0; };
+        switch (i.op) {
+            case VX_AIRP_LOC:
+            case VX_AIRP_NXT:
+                AIRP_NEED(reg_ok(i.d) && i.a < (int)in->cols && i.b == 0, "air program: instruction %u: bad column load", pc);
+                deg[i.d] = 1;
+                break;
+            case VX_AIRP_PER:
+                AIRP_NEED(reg_ok(i.d) && i.a < (int)in->n_periodic && i.b == 0, "air program: instruction %u: bad periodic load", pc);
+                deg[i.d] = 1;
+                break;
+            case VX_AIRP_PUB:
+                AIRP_NEED(reg_ok(i.d) && i.a < (int)in->n_public && i.b == 0, "air program: instruction %u: bad public-input load", pc);
+                deg[i.d] = 0;
+                break;
+            case VX_AIRP_CONST:
+                AIRP_NEED(reg_ok(i.d) && i.a < (int)in->n_consts && i.b == 0, "air program: instruction %u: bad constant load", pc);
+                deg[i.d] = 0;
+                break;
+            case VX_AIRP_ADD:
+            case VX_AIRP_SUB:
+            case VX_AIRP_MUL: {
+                AIRP_NEED(reg_ok(i.d) && src(i.a) && src(i.b), "air program: instruction %u reads a register that was never written (or out of range)", pc);
+                const int dg = i.op == VX_AIRP_MUL ? deg[i.a] + deg[i.b] : (deg[i.a] > deg[i.b] ? deg[i.a] : deg[i.b]);
+                deg[i.d] = dg > 1000 ? 1000 : dg;
+                break;
+            }
+            case VX_AIRP_ASSERT:
+            case VX_AIRP_ASSERT_TRANSITION:
+            case VX_AIRP_ASSERT_FIRST:
+            case VX_AIRP_ASSERT_LAST: {
+                AIRP_NEED(i.d == 0 && i.b == 0 && src(i.a), "air program: instruction %u asserts a register that was never written (or out of range)", pc);
+                const int lim = i.op == VX_AIRP_ASSERT ? 3 : 2;
+                AIRP_NEED(deg[i.a] <= lim, "air program: instruction %u asserts an expression of degree %d (limit %d at rate_bits 1)", pc, deg[i.a], lim);
+                ++pg->n_constraints;
+                break;
+            }
+            default: AIRP_NEED(false, "air program: instruction %u has unknown opcode %d", pc, i.op);
+        }
+    }
+    AIRP_NEED(pg->n_constraints >= 1, "air program: no constraint");
+    std::lock_guard<std::mutex> lk(g_airp_mu);
+    AIRP_NEED(g_airp_next < 0x7FFFFFF0, "air program: id space exhausted");
+    pg->id = g_airp_next++;
+    *air_id = pg->id;
+    g_airp[pg->id] = pg;
+    return VX_OK;
+}
+int32_t vx_air_unregister(int air_id) {
+    std::lock_guard<std::mutex> lk(g_airp_mu);
+    auto it = g_airp.find(air_id);
+    if (it == g_airp.end()) return VX_ERR_ARG;
+    g_airp_retired.push_back(it->second);
+    g_airp.erase(it);
+    return VX_OK;
+}
+}  // extern "C"
+
 extern "C" {
 
 int32_t vx_stark_verify(const vx_stark_config* cfg, const uint64_t* pr, size_t len, int expect_air,
@@ -208,6 +328,13 @@ int32_t vx_stark_verify_ext(const vx_stark_config* cfg, const uint64_t* pr, size
     const AirV* air = nullptr;
     for (const AirV& a : V_AIRS)
         if (a.id == air_id) air = &a;
+    AirV prog_air{};
+    if (!air && air_id >= VX_AIR_USER_BASE) {
+        if (const AirProgram* pg = vx_air_program_find(air_id)) {
+            prog_air = {air_id, (int)pg->cols, (int)pg->pub, (int)pg->plog.size(), pg->period_log, 0, nullptr, nullptr, 0, 0, 0, nullptr, pg};
+            air = &prog_air;
+        }
+    }
     NEED(air && (expect_air == 0 || expect_air == air_id), "unexpected AIR %d", air_id);
     const size_t cm = air->cols, ca = air->aux, c = cm + ca;  // main ++ auxiliary columns
     // FRI reduction plan (ConstantArityBits)
@@ -301,10 +428,11 @@ int32_t vx_stark_verify_ext(const vx_stark_config* cfg, const uint64_t* pr, size
         std::vector<Fx> per(air->periodic ? air->periodic : 1), pubx(n_pub ? n_pub : 1), chalx(8), apubx(8);
         if (air->periodic) {
             std::vector<uint64_t> pv;
-            air->periodic_values(pv);
+            if (air->prog) pv = air->prog->periodic;
+            else air->periodic_values(pv);
             size_t in_off = 0;
             for (int j = 0; j < air->periodic; ++j) {
-                const int pl = air->plog(j);
+                const int pl = air->prog ? air->prog->plog[j] : air->plog(j);
                 const size_t p = (size_t)1 << pl;
                 NEED(in_off + p <= pv.size(), "periodic table of AIR %d is short", air_id);
                 std::vector<uint64_t> coef(pv.begin() + in_off, pv.begin() + in_off + p);
@@ -320,7 +448,8 @@ int32_t vx_stark_verify_ext(const vx_stark_config* cfg, const uint64_t* pr, size
         for (int q = 0; q < air->chal; ++q) chalx[q] = {chal[q], 0};
         for (int q = 0; q < 2 * air->auxpub; ++q) apubx[q] = {apub[q], 0};
         HostRow loc{o_local.data()}, nxt{o_next.data()};
-        air->eval(loc, nxt, per.data(), pubx.data(), chalx.data(), apubx.data(), cons);
+        if (air->prog) air_program_eval<Fx>(*air->prog, loc, nxt, per.data(), pubx.data(), cons);
+        else air->eval(loc, nxt, per.data(), pubx.data(), chalx.data(), apubx.data(), cons);
         for (int k = 0; k < 2; ++k) {
             const Fx q = o_quot[2 * k] + o_quot[2 * k + 1] * zn;
             NEED(fx_eq(cons.acc[k], zh * q), "constraint identity fails at zeta (challenge %d)", k);

@@ -28,7 +28,7 @@ SYMBOLS = [
     "vx_ed25519_verify_batch", "vx_verify_simple_justification", "vx_sha_chain_trace",
     "vx_verify_epoch_end_header", "vx_rotate_proof_bound", "vx_rotate_prove", "vx_rotate_verify",
     "vx_gather_proofs", "vx_quotient_eval", "vx_decode_header_batch", "vx_decode_precommit_batch", "vx_stark_aux_trace",
-    "vx_ed_trace", "vx_sha512_trace", "vx_epoch_end_trace", "vx_partial_products",
+    "vx_ed_trace", "vx_sha512_trace", "vx_epoch_end_trace", "vx_partial_products", "vx_air_register", "vx_air_unregister",
 ]
 
 VX_AIR_FIBONACCI, VX_AIR_MIX, VX_AIR_BLAKE_CHAIN, VX_AIR_LOOKUP = 1, 2, 6, 5
@@ -68,6 +68,12 @@ class PackedJustification:
 class StarkConfig(C.Structure):
     _fields_ = [("rate_bits", C.c_int32), ("cap_height", C.c_int32), ("num_queries", C.c_int32), ("pow_bits", C.c_int32),
                 ("arity_bits", C.c_int32), ("final_poly_bits", C.c_int32)]
+
+
+class AirProgramStruct(C.Structure):  # include/vx.h vx_air_program
+    _fields_ = [("cols", C.c_uint32), ("n_public", C.c_uint32), ("n_periodic", C.c_uint32), ("n_regs", C.c_uint32),
+                ("periodic_log", C.c_void_p), ("periodic_values", C.c_void_p), ("consts", C.c_void_p), ("n_consts", C.c_uint32),
+                ("code", C.c_void_p), ("n_code", C.c_uint32)]
 
 
 class VxError(RuntimeError):
@@ -147,6 +153,7 @@ def load_library():
         "vx_decode_header_batch": [vp, vp, sz, vp, sz, vp, vp, vp, vp, vp, vp],
         "vx_decode_precommit_batch": [vp, vp, sz, vp, vp, vp, vp, vp],
         "vx_stark_aux_trace": [vp, C.c_int, vp, C.c_int, vp, sz, vp, sz, vp, vp],
+        "vx_air_register": [C.POINTER(AirProgramStruct), C.POINTER(C.c_int), C.c_char_p, sz], "vx_air_unregister": [C.c_int],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -181,6 +188,35 @@ def stark_verify(proof, cfg=None, expect_air=0, expect_public=None):
     rc = L.vx_stark_verify(C.byref(cfg), _ptr(pr), pr.size, expect_air, None if pub is None else _ptr(pub), 0 if pub is None else pub.size, err, 256)
     if rc != 0:
         raise VxError(rc, err.value.decode())
+
+
+def air_register(cols, n_public, code, consts=(), periodic=(), n_regs=None):
+    """Register a constraint program (include/vx.h vx_air_register; no GPU needed) and return its AIR id.
+    code: uint64 instruction words; consts: canonical field elements; periodic: a list of columns, each 2^k values;
+    n_regs: registers used (default: the highest register the code names + 1).  air_program.AirBuilder writes these."""
+    L = load_library()
+    code = np.ascontiguousarray(code, dtype=np.uint64)
+    consts = np.ascontiguousarray(consts, dtype=np.uint64)
+    plog = np.array([max(len(c), 1).bit_length() - 1 for c in periodic], dtype=np.uint8)
+    for c, k in zip(periodic, plog):
+        if len(c) != 1 << int(k):
+            raise ValueError("a periodic column must have a power-of-two number of values")
+    pvals = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.uint64) for c in periodic]) if len(periodic) else np.zeros(0, np.uint64))
+    if n_regs is None:
+        n_regs = 1 + max([int((w >> 8) & 0xFF) for w in code.tolist()] + [0])
+    st = AirProgramStruct(cols, n_public, len(periodic), n_regs, _ptr(plog) if len(periodic) else None, _ptr(pvals) if len(periodic) else None,
+                          _ptr(consts) if consts.size else None, consts.size, _ptr(code) if code.size else None, code.size)
+    air_id, err = C.c_int(0), C.create_string_buffer(256)
+    rc = L.vx_air_register(C.byref(st), C.byref(air_id), err, 256)
+    if rc != 0:
+        raise VxError(rc, err.value.decode())
+    return air_id.value
+
+
+def air_unregister(air_id):
+    rc = load_library().vx_air_unregister(air_id)
+    if rc != 0:
+        raise VxError(rc, "unknown AIR program id %d" % air_id)
 
 
 HR_FIXED = 22  # fixed words of a header_range blob's header; the lengths of its S hash-chain segments follow

@@ -158,15 +158,47 @@ typedef struct vx_stark_config {
     int32_t arity_bits;      /* ConstantArityBits(4, 5) */
     int32_t final_poly_bits;
 } vx_stark_config;
-/* AIRs are COMPILED INTO the library (there is no run-time AIR descriptor): 1 Fibonacci and 2 "cubic mixer" pin the
- * generic prover, 5 is the smallest AIR with an auxiliary (lookup / logUp) commitment round.  The tables of the
+/* The AIRs of the statements are COMPILED INTO the library: 1 Fibonacci and 2 "cubic mixer" pin the
+ * generic prover, 5 is the smallest AIR with an auxiliary (lookup / logUp) commitment round.  A host can add its own at run
+ * time as a constraint PROGRAM (vx_air_register below; no auxiliary round).  The tables of the
  * header_range / rotate statements, each declared with its trace generator below: 6 Blake2b header chain
  * (VX_AIR_BLAKE_CHAIN), 4 SHA-256 authority-set commitment (VX_AIR_SHA_CHAIN), 7 / 8 / 9 SHA-256 Merkle trees of 256 /
  * 512 / 16 leaves, 10 / 12 Ed25519 (2^17 / 2^16 rows), 11 / 14 / 13 SHA-512 (2^16 / 2^15 / 2^10 rows), 15 epoch-end log. */
 enum { VX_AIR_FIBONACCI = 1, VX_AIR_MIX = 2, VX_AIR_LOOKUP = 5 };
 int32_t vx_stark_default_config(vx_stark_config* cfg);
+/* Run-time AIR descriptor (SURVEY 8b `vx_air_desc`): the constraint system of a starky-style AIR as a straight-line program over a
+ * register file, the form a Rust host would lower `Stark::eval_packed_generic` / `eval_ext_circuit` to (starky v0.2.0 stark.rs; the
+ * reference reaches it through curta's AirParser).  The same program is run by the GPU quotient kernel (one LDE point per lane,
+ * registers in LDS), by the host verifier (at zeta, in the quadratic extension) and, restated, by oracle/air_program.py.
+ * One instruction = one uint64:  bits 0..7 opcode, 8..15 destination register d, 16..31 operand a, 32..47 operand b, 48..63 zero.
+ *   LOC d, a      r[d] = local row, column a            NXT d, a     r[d] = next row, column a
+ *   PER d, a      r[d] = periodic column a              PUB d, a     r[d] = public input a
+ *   CONST d, a    r[d] = consts[a]                      ADD / SUB / MUL d, a, b   r[d] = r[a] op r[b]
+ *   ASSERT a            r[a] = 0 on EVERY row (the wrap-around pair included)
+ *   ASSERT_TRANSITION a r[a] (x - w^-1): every row pair but the wrap-around      ASSERT_FIRST a / ASSERT_LAST a: on that row only
+ * Constraints are consumed in program order (the order is protocol, as for the compiled AIRs).  Registration checks every operand,
+ * that no register is read before it is written, that constants and periodic values are canonical, and the DEGREE of every
+ * asserted expression (columns and periodic columns count 1; ASSERT <= 3, the three others <= 2: rate_bits 1 carries degree 3).
+ * Periodic column q has 2^periodic_log[q] values (<= 2^16), given back to back.  A program is immutable once registered and its id
+ * (>= VX_AIR_USER_BASE, never reused) works wherever an AIR id does: vx_quotient_eval, vx_stark_proof_bound, vx_stark_prove,
+ * vx_stark_verify.  Registration is process-wide, thread-safe, needs no GPU; a verifier must register the SAME program (the proof does
+ * not carry it).  vx_air_unregister retires the id. */
+enum { VX_AIRP_LOC = 1, VX_AIRP_NXT = 2, VX_AIRP_PER = 3, VX_AIRP_PUB = 4, VX_AIRP_CONST = 5, VX_AIRP_ADD = 6, VX_AIRP_SUB = 7, VX_AIRP_MUL = 8,
+       VX_AIRP_ASSERT = 9, VX_AIRP_ASSERT_TRANSITION = 10, VX_AIRP_ASSERT_FIRST = 11, VX_AIRP_ASSERT_LAST = 12 };
+enum { VX_AIR_USER_BASE = 4096, VX_AIRP_MAX_REGS = 32, VX_AIRP_MAX_COLS = 65535, VX_AIRP_MAX_CODE = 1 << 20, VX_AIRP_MAX_PERIOD_LOG = 16 };
+typedef struct vx_air_program {
+    uint32_t cols, n_public, n_periodic, n_regs;
+    const uint8_t* periodic_log;      /* [n_periodic] */
+    const uint64_t* periodic_values;  /* sum of 2^periodic_log[q] values */
+    const uint64_t* consts;
+    uint32_t n_consts;
+    const uint64_t* code;
+    uint32_t n_code;
+} vx_air_program;
+int32_t vx_air_register(const vx_air_program* program, int* air_id, char* err, size_t errlen);
+int32_t vx_air_unregister(int air_id);
 /* K5: batched constraint / quotient-polynomial evaluation (starky prover.rs compute_quotient_polys) for an AIR compiled
- * into the library.  trace_lde: column-major [cols][N], N = 2^(log_n + rate_bits), natural order, values on the coset
+ * into the library or registered as a program.  trace_lde: column-major [cols][N], N = 2^(log_n + rate_bits), natural order, values on the coset
  * 7 * <w_N>.  out[k*N + i] = (sum_j alpha_k^(K-1-j) c_j(x_i)) / Z_H(x_i) for the two challenges k = 0, 1. */
 int32_t vx_quotient_eval(vx_ctx* ctx, int air_id, int rate_bits, const vx_buf* trace_lde, int log_n, const uint64_t alphas[2],
                          const uint64_t* public_inputs, size_t n_public, vx_buf* out);

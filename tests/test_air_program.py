@@ -1,0 +1,139 @@
+"""Run-time AIR descriptors (include/vx.h vx_air_register): the builder, the registration checks and the HOST interpreter of the
+product verifier, against the oracle's own reading of the format (oracle/air_program.py) -- no GPU involved.  A program that
+restates FibAir / MixAir must give, word for word, the proof of the compiled AIR (only the id word differs)."""
+import numpy as np
+import pytest
+
+import air_programs as AP
+from oracle import stark_ref as S
+from oracle.air_program import ProgramAir
+
+P = 2**64 - 2**32 + 1
+CFG = dict(S.DEFAULT_CFG, num_queries=12)
+
+
+def oracle_air(air_id, b):
+    code, consts, _ = b.assemble()
+    return ProgramAir(air_id, b.cols, b.n_public, code, consts, b.periodic)
+
+
+@pytest.mark.parametrize("name,log_n", [("fib", 6), ("mix", 7)])
+def test_restated_airs_give_the_compiled_airs_proofs(vx, oracle, name, log_n):
+    ap = vx.air_program
+    base, b = (S.FibAir, AP.fib_builder(ap)) if name == "fib" else (S.MixAir, AP.mix_builder(ap))
+    air_id = b.register()
+    assert air_id >= 4096
+    air = oracle_air(air_id, b)
+    trace, pub = base.trace(log_n)
+    assert S.check_trace(air, trace, pub) is None
+    S.register_air(air)
+    got, want = S.prove(air, trace, pub, CFG), S.prove(base, trace, pub, CFG)
+    assert got[1] == air_id and want[1] == base.ID
+    assert (np.delete(got, 1) == np.delete(want, 1)).all()
+    pcfg = vx.lib.default_stark_config(num_queries=CFG["num_queries"])
+    # the product's host interpreter (at zeta, in the extension field) accepts it under the program's id ...
+    vx.lib.stark_verify(got, pcfg, expect_air=air_id, expect_public=pub)
+    S.verify(got, CFG, expect_air=air_id, expect_public=pub)
+    for w in (12, len(got) // 2, len(got) - 4):
+        bad = got.copy()
+        bad[w] ^= np.uint64(1)
+        with pytest.raises(vx.VxError):
+            vx.lib.stark_verify(bad, pcfg)
+    # ... and the compiled AIR's verifier accepts the same bytes under ITS id: one statement, two descriptions
+    twin = got.copy()
+    twin[1] = base.ID
+    vx.lib.stark_verify(twin, pcfg, expect_air=base.ID, expect_public=pub)
+    vx.lib.air_unregister(air_id)
+    with pytest.raises(vx.VxError, match="unexpected AIR"):
+        vx.lib.stark_verify(got, pcfg)
+    with pytest.raises(vx.VxError):
+        vx.lib.air_unregister(air_id)
+
+
+def test_a_different_program_rejects_the_proof(vx, oracle):
+    """The verifier's registry defines the statement: a proof made for one program fails the constraint identity under another."""
+    ap = vx.air_program
+    good, other = AP.fib_builder(ap), AP.fib_builder(ap, bump=1)
+    id_good, id_other = good.register(), other.register()
+    assert id_other == id_good + 1
+    trace, pub = S.FibAir.trace(5)
+    air = oracle_air(id_good, good)
+    S.register_air(air)
+    proof = S.prove(air, trace, pub, CFG)
+    pcfg = vx.lib.default_stark_config(num_queries=CFG["num_queries"])
+    vx.lib.stark_verify(proof, pcfg, expect_air=id_good)
+    forged = proof.copy()
+    forged[1] = id_other
+    with pytest.raises(vx.VxError, match="constraint identity"):
+        vx.lib.stark_verify(forged, pcfg)
+    assert S.check_trace(oracle_air(id_other, other), trace, pub) == (4, 0)  # the bumped recurrence, violated from row 0 on
+
+
+def test_an_air_that_is_not_compiled_in(vx, oracle):
+    """CubeAir exists only as a program: periodic round keys, a degree-3 constraint on every row, all four assertion kinds."""
+    b = AP.cube_builder(vx.air_program)
+    air_id = b.register()
+    air = oracle_air(air_id, b)
+    S.register_air(air)
+    trace, pub = AP.cube_trace(7)
+    assert S.check_trace(air, trace, pub) is None
+    proof = S.prove(air, trace, pub, CFG)
+    S.verify(proof, CFG, expect_air=air_id, expect_public=pub)
+    pcfg = vx.lib.default_stark_config(num_queries=CFG["num_queries"])
+    vx.lib.stark_verify(proof, pcfg, expect_air=air_id, expect_public=pub)
+    bad_trace, bad_pub = AP.cube_trace(7, force_t=(9, 3))
+    assert S.check_trace(air, bad_trace, bad_pub) == (7, 9)  # only the degree-3 range constraint, only on row 9
+    bad = S.prove(air, bad_trace, bad_pub, CFG)
+    with pytest.raises(vx.VxError):
+        vx.lib.stark_verify(bad, pcfg)
+
+
+def test_builder_shares_subexpressions_and_recycles_registers(vx):
+    ap = vx.air_program
+    b = ap.AirBuilder(2)
+    x = b.loc(0)
+    sq = x * x
+    b.assert_zero(sq * sq - b.loc(1) * 1)
+    code, consts, n_regs = b.assemble()
+    ops = [int(w) & 0xFF for w in code]
+    assert ops.count(1) == 2 and ops.count(8) == 3 and n_regs <= 3  # x loaded once, x^2 computed once
+    assert list(consts) == [1]
+    deep = ap.AirBuilder(1)
+    e = deep.loc(0)
+    for _ in range(200):
+        e = e + deep.loc(0)
+    deep.assert_transition(e)
+    assert deep.assemble()[2] == 2  # a left-leaning chain needs two registers whatever its length
+
+
+def test_registration_checks(vx):
+    L, ap = vx.lib, vx.air_program
+    I = ap.insn
+    ok = [I(1, 0, 0), I(9, 0, 0)]  # LOC r0 <- col 0; ASSERT r0
+    assert L.air_register(1, 0, ok) >= 4096
+    cases = {
+        "never written": [I(6, 0, 1, 2), I(9, 0, 0)],
+        "asserts a register": [I(9, 0, 5)],
+        "bad column": [I(1, 0, 7), I(9, 0, 0)],
+        "unknown opcode": [I(13, 0, 0), I(9, 0, 0)],
+        "reserved": [I(1, 0, 0) | (1 << 50), I(9, 0, 0)],
+        "no constraint": [I(1, 0, 0)],
+        "degree 4": [I(1, 0, 0), I(8, 1, 0, 0), I(8, 1, 1, 1), I(9, 0, 1)],
+        "degree 3": [I(1, 0, 0), I(8, 1, 0, 0), I(8, 1, 1, 0), I(10, 0, 1)],  # a transition may carry degree 2 only
+        "bad public": [I(4, 0, 0), I(9, 0, 0)],
+        "bad constant": [I(5, 0, 0), I(9, 0, 0)],
+        "bad periodic": [I(3, 0, 0), I(9, 0, 0)],
+    }
+    for what, code in cases.items():
+        with pytest.raises(vx.VxError, match=what):
+            L.air_register(1, 0, code, n_regs=8)
+    with pytest.raises(vx.VxError, match="registers"):
+        L.air_register(1, 0, ok, n_regs=33)
+    with pytest.raises(vx.VxError, match="non-canonical constant"):
+        L.air_register(1, 0, [I(5, 0, 0), I(9, 0, 0)], consts=[P])
+    with pytest.raises(vx.VxError, match="non-canonical periodic"):
+        L.air_register(1, 0, [I(3, 0, 0), I(9, 0, 0)], periodic=[[1, P]])
+    with pytest.raises(vx.VxError, match="columns"):
+        L.air_register(0, 0, ok)
+    # degree 3 on every row is the limit and is accepted
+    assert L.air_register(1, 0, [I(1, 0, 0), I(8, 1, 0, 0), I(8, 1, 1, 0), I(9, 0, 1)]) >= 4096

@@ -1,0 +1,98 @@
+"""Run-time AIR descriptors on the GPU (k_quotient_prog, the interpreter of vx_air_program): proofs of a registered program
+are, word for word, the proofs of the compiled AIR it restates and of the coefficient-space reference prover running the
+oracle's own reading of the format; an AIR that exists ONLY as a program (CubeAir) is proven and checked the same way."""
+import numpy as np
+import pytest
+
+import air_programs as AP
+from oracle import stark_ref as S
+from oracle.air_program import ProgramAir
+
+P = 2**64 - 2**32 + 1
+pytestmark = pytest.mark.gpu
+
+
+def oracle_air(air_id, b):
+    code, consts, _ = b.assemble()
+    air = ProgramAir(air_id, b.cols, b.n_public, code, consts, b.periodic)
+    S.register_air(air)
+    return air
+
+
+@pytest.mark.parametrize("name,log_n", [("fib", 5), ("fib", 12), ("mix", 4), ("mix", 9), ("mix", 14)])
+def test_program_proofs_equal_compiled_and_reference_proofs(ctx, vx, oracle, name, log_n):
+    base, b = (S.FibAir, AP.fib_builder(vx.air_program)) if name == "fib" else (S.MixAir, AP.mix_builder(vx.air_program))
+    air_id = b.register()
+    trace, pub = base.trace(log_n)
+    got = ctx.stark_prove(air_id, ctx.from_host(trace), log_n, pub)
+    compiled = ctx.stark_prove(base.ID, ctx.from_host(trace), log_n, pub)
+    assert got[1] == air_id and got.size == compiled.size
+    assert (np.delete(got, 1) == np.delete(compiled, 1)).all()
+    want = S.prove(oracle_air(air_id, b), trace, pub)
+    assert (got == want).all()
+    vx.lib.stark_verify(got, expect_air=air_id, expect_public=pub)
+    S.verify(got, expect_air=air_id, expect_public=pub)
+
+
+@pytest.mark.parametrize("log_n", [3, 7, 12])
+def test_an_air_that_exists_only_as_a_program(ctx, vx, oracle, log_n):
+    b = AP.cube_builder(vx.air_program)
+    air_id = b.register()
+    air = oracle_air(air_id, b)
+    trace, pub = AP.cube_trace(log_n)
+    assert S.check_trace(air, trace, pub) is None
+    got = ctx.stark_prove(air_id, ctx.from_host(trace), log_n, pub)
+    want = S.prove(air, trace, pub)
+    assert got.size == want.size and (got == want).all()
+    vx.lib.stark_verify(got, expect_air=air_id, expect_public=pub)
+    # a trace that breaks only the degree-3 range constraint: the GPU still emits a proof, nobody accepts it
+    if log_n >= 7:
+        bad_trace, bad_pub = AP.cube_trace(log_n, force_t=(9, 3))
+        bad = ctx.stark_prove(air_id, ctx.from_host(bad_trace), log_n, bad_pub)
+        with pytest.raises(vx.VxError):
+            vx.lib.stark_verify(bad, expect_air=air_id)
+        with pytest.raises(S.VerifyError):
+            S.verify(bad, expect_air=air_id)
+
+
+def test_quotient_values_of_a_program(ctx, vx, oracle):
+    """K5 alone (vx_quotient_eval): the interpreter's quotient values equal the compiled kernel's and the reference's."""
+    log_n, r = 6, 1
+    b = AP.mix_builder(vx.air_program)
+    air_id = b.register()
+    trace, pub = S.MixAir.trace(log_n)
+    leaves, _ = oracle.lde_from_values(trace, r, 7)
+    lde_nat = np.ascontiguousarray(leaves[S.bitrev_perm(log_n + r)].T)
+    alphas = [0x123456789ABCDEF % P, 0xFEDCBA987654321 % P]
+    buf = ctx.from_host(lde_nat)
+    got = ctx.quotient_eval(air_id, r, buf, log_n, alphas, pub)
+    assert (got == ctx.quotient_eval(S.MixAir.ID, r, buf, log_n, alphas, pub)).all()
+    assert (got == S.quotient_values(S.MixAir, lde_nat, [int(x) % P for x in pub], alphas, log_n, r)).all()
+
+
+def test_large_program_trace_and_other_configs(ctx, vx, oracle):
+    b = AP.cube_builder(vx.air_program)
+    air_id = b.register()
+    air = oracle_air(air_id, b)
+    trace, pub = AP.cube_trace(17)
+    proof = ctx.stark_prove(air_id, ctx.from_host(trace), 17, pub)
+    vx.lib.stark_verify(proof, expect_air=air_id, expect_public=pub)
+    S.verify(proof, expect_air=air_id, expect_public=pub)
+    trace, pub = AP.cube_trace(9)
+    for over in (dict(num_queries=10, pow_bits=8), dict(cap_height=0, num_queries=5), dict(arity_bits=2, final_poly_bits=0, num_queries=3, pow_bits=0)):
+        got = ctx.stark_prove(air_id, ctx.from_host(trace), 9, pub, ctx.stark_config(**over))
+        assert (got == S.prove(air, trace, pub, dict(S.DEFAULT_CFG, **over))).all(), over
+
+
+def test_program_argument_errors(ctx, vx):
+    b = AP.fib_builder(vx.air_program)
+    air_id = b.register()
+    trace, pub = S.FibAir.trace(6)
+    buf = ctx.from_host(trace)
+    with pytest.raises(vx.VxError):
+        ctx.stark_prove(air_id, buf, 6, pub[:2])
+    with pytest.raises(vx.VxError):
+        ctx.stark_prove(air_id + 1000, buf, 6, pub)
+    vx.lib.air_unregister(air_id)
+    with pytest.raises(vx.VxError):
+        ctx.stark_prove(air_id, buf, 6, pub)

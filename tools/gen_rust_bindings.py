@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BEGIN, END = "<!-- BEGIN GENERATED: tools/gen_rust_bindings.py -->", "<!-- END GENERATED -->"
 BASE = {"int32_t": "i32", "int": "c_int", "size_t": "usize", "uint64_t": "u64", "uint32_t": "u32", "uint8_t": "u8", "char": "c_char",
         "float": "f32", "void": "c_void", "vx_ctx": "VxCtx", "vx_buf": "VxBuf", "vx_tree": "VxTree", "vx_stark_config": "VxStarkConfig",
-        "vx_justification": "VxJustification", "vx_hr_exchange": "VxHrExchange"}
+        "vx_justification": "VxJustification", "vx_hr_exchange": "VxHrExchange", "vx_air_program": "VxAirProgram"}
 
 
 def declarations():
@@ -57,6 +57,9 @@ def block():
              "#[repr(C)] pub struct VxJustification {", "    pub authority_set_id: u64, pub authority_set_hash: *const u8, pub precommit: *const u8,",
              "    pub pubkeys: *const u8, pub signatures: *const u8, pub validator_signed: *const u8,", "    pub num_authorities: u32, pub max_authorities: u32,", "}",
              "/// all-reduce (wrapping sum of u64 words) across the shards of one header_range proof (vx_header_range_prove_ex)",
+             "/// a constraint program (run-time AIR descriptor) for vx_air_register: what a host lowers `Stark::eval_packed_generic` to",
+             "#[repr(C)] pub struct VxAirProgram {", "    pub cols: u32, pub n_public: u32, pub n_periodic: u32, pub n_regs: u32,",
+             "    pub periodic_log: *const u8, pub periodic_values: *const u64, pub consts: *const u64, pub n_consts: u32, pub code: *const u64, pub n_code: u32,", "}",
              "#[repr(C)] pub struct VxHrExchange { pub func: Option<unsafe extern \"C\" fn(user: *mut c_void, words: *mut u64, n_words: usize) -> i32>, pub user: *mut c_void }",
              '#[link(name = "vxprove")]', 'extern "C" {']
     for ret, name, args in declarations():
