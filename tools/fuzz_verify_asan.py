@@ -178,7 +178,63 @@ def child(iters):
         assert rot_verify(p) != 0, f"mutation kind {kind} of the rotate blob was ACCEPTED"
         total += 1
         rejected += 1
-    print(f"fuzz: {total} inputs, {rejected} mutated proofs rejected, no sanitizer report")
+    # run-time AIR descriptors (vx_air_register + the host interpreter): random and mutated instruction streams must be refused or
+    # registered without a sanitizer report; whatever registers is then run by the verifier on a real proof of another program
+    # (it must reject: a different statement) and on that proof's mutations
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import air_programs as AP
+    from oracle.air_program import ProgramAir
+
+    AirProgramStruct = vx.lib.AirProgramStruct
+    L.vx_air_register.argtypes = [C.POINTER(AirProgramStruct), C.POINTER(C.c_int), C.c_char_p, sz]
+    L.vx_air_register.restype = C.c_int32
+
+    def register(cols, n_pub, code, consts, periodic, n_regs):
+        code, consts = np.ascontiguousarray(code, dtype=np.uint64), np.ascontiguousarray(consts, dtype=np.uint64)
+        plog = np.array([len(c).bit_length() - 1 for c in periodic], dtype=np.uint8)
+        pv = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.uint64) for c in periodic]) if periodic else np.zeros(1, np.uint64))
+        st = AirProgramStruct(cols, n_pub, len(periodic), n_regs, plog.ctypes.data_as(vp) if periodic else None, pv.ctypes.data_as(vp) if periodic else None,
+                              consts.ctypes.data_as(vp) if consts.size else None, consts.size, code.ctypes.data_as(vp) if code.size else None, code.size)
+        aid = C.c_int(0)
+        return L.vx_air_register(C.byref(st), C.byref(aid), err, 256), aid.value
+
+    b = AP.cube_builder(vx.air_program)
+    code, consts, n_regs = b.assemble()
+    rc, cube_id = register(b.cols, b.n_public, code, consts, b.periodic, n_regs)
+    assert rc == 0, err.value
+    air = ProgramAir(cube_id, b.cols, b.n_public, code, consts, b.periodic)
+    S.register_air(air)
+    tr, pub = AP.cube_trace(6)
+    seed = S.prove(air, tr, pub, ocfg)
+    assert verify(seed, cube_id) == 0, err.value
+    n, registered = seed.size, 0
+    for it in range(iters):
+        kind = it % 4
+        c2 = code.copy()
+        if kind == 0:  # one field of one instruction changed
+            k = int(rng.integers(c2.size))
+            c2[k] ^= np.uint64(1) << np.uint64(rng.integers(48))
+        elif kind == 1:  # random words with plausible opcodes
+            c2 = (rng.integers(1, 14, size=c2.size).astype(np.uint64) | (rng.integers(0, 40, size=c2.size).astype(np.uint64) << np.uint64(8))
+                  | (rng.integers(0, 40, size=c2.size).astype(np.uint64) << np.uint64(16)) | (rng.integers(0, 40, size=c2.size).astype(np.uint64) << np.uint64(32)))
+        elif kind == 2:
+            c2 = rng.integers(0, 2**63, size=int(rng.integers(0, 64)), dtype=np.uint64)
+        else:  # two instructions swapped: often still well-formed, a different statement
+            i, j = (int(x) for x in rng.integers(0, c2.size, size=2))
+            c2[i], c2[j] = c2[j], c2[i]
+        rc, aid = register(b.cols, b.n_public, c2, consts, b.periodic, int(rng.integers(1, 34)) if kind == 2 else n_regs)
+        total += 1
+        if rc != 0:
+            continue
+        registered += 1
+        p = seed.copy()
+        p[1] = np.uint64(aid)
+        same = c2.size == code.size and (c2 == code).all()
+        rcv = verify(p, aid)
+        assert (rcv == 0) == same or rcv == 0 and kind in (0, 3), f"cube proof under mutated program (kind {kind}): rc {rcv}"
+        p[rng.integers(10, n)] ^= np.uint64(1) << np.uint64(rng.integers(64))
+        assert verify(p, aid) != 0
+    print(f"fuzz: {total} inputs, {rejected} mutated proofs rejected, {registered} mutated programs registered and run, no sanitizer report")
 
 
 if __name__ == "__main__":
