@@ -44,7 +44,25 @@ EXPORT void vxo_batch_mul(const uint64_t* a, const uint64_t* b, uint64_t* o, siz
 /* plonky2 Field::batch_multiplicative_inverse semantics: inverse of every
  * element; zero is not allowed upstream (panics) -- here 0 maps to 0. */
 EXPORT void vxo_batch_inv(const uint64_t* a, uint64_t* o, size_t n) {
-    for (size_t i = 0; i < n; ++i) o[i] = a[i] ? gl_inv(a[i]) : 0;
+    /* Montgomery's trick in blocks of 256 (one exponentiation per block instead of per element; the same values) */
+    enum { B = 256 };
+    uint64_t pre[B];
+    for (size_t s = 0; s < n; s += B) {
+        const size_t m = n - s < B ? n - s : B;
+        uint64_t acc = 1;
+        for (size_t i = 0; i < m; ++i) {
+            pre[i] = acc;
+            if (a[s + i]) acc = gl_mul(acc, a[s + i]);
+        }
+        uint64_t inv = gl_inv(acc);
+        for (size_t i = m; i-- > 0;) {
+            const uint64_t x = a[s + i];  /* (o may alias a) */
+            if (x) {
+                o[s + i] = gl_mul(inv, pre[i]);
+                inv = gl_mul(inv, x);
+            } else o[s + i] = 0;
+        }
+    }
 }
 EXPORT uint64_t vxo_pow(uint64_t a, uint64_t e) { return gl_pow(a, e); }
 EXPORT uint64_t vxo_root(int log_n) { return gl_root(log_n); }
@@ -57,11 +75,26 @@ EXPORT void vxo_ext_mul(const uint64_t* a, const uint64_t* b, uint64_t* o, size_
     }
 }
 EXPORT void vxo_ext_inv(const uint64_t* a, uint64_t* o, size_t n) {
-    for (size_t i = 0; i < n; ++i) {
-        gl2_t x = {{a[2 * i], a[2 * i + 1]}};
-        gl2_t r = gl2_inv(x);
-        o[2 * i] = r.c[0];
-        o[2 * i + 1] = r.c[1];
+    /* the same trick in the quadratic extension; 0 maps to 0 as gl2_inv does */
+    enum { B = 256 };
+    gl2_t pre[B];
+    for (size_t s = 0; s < n; s += B) {
+        const size_t m = n - s < B ? n - s : B;
+        gl2_t acc = {{1, 0}};
+        for (size_t i = 0; i < m; ++i) {
+            pre[i] = acc;
+            gl2_t x = {{a[2 * (s + i)], a[2 * (s + i) + 1]}};
+            if (x.c[0] | x.c[1]) acc = gl2_mul(acc, x);
+        }
+        gl2_t inv = gl2_inv(acc);
+        for (size_t i = m; i-- > 0;) {
+            gl2_t x = {{a[2 * (s + i)], a[2 * (s + i) + 1]}};
+            if (x.c[0] | x.c[1]) {
+                gl2_t r = gl2_mul(inv, pre[i]);
+                inv = gl2_mul(inv, x);
+                o[2 * (s + i)] = r.c[0], o[2 * (s + i) + 1] = r.c[1];
+            } else o[2 * (s + i)] = 0, o[2 * (s + i) + 1] = 0;
+        }
     }
 }
 

@@ -416,6 +416,58 @@ def test_map_segments_small(ctx, vx, oracle):
         ctx.header_range_prove(*args, just=good, n_segments=17)
 
 
+def test_full_size_map_segments(ctx, vx):
+    """header_range_256 at the benchmarked size (P15k, 300 authorities) with the hash-chain table cut into 8 map segments of
+    2^16 rows -- the shape `bench.py --shard-proof 8` times: same 96 output bytes as the unsegmented proof, the product verifier
+    accepts, the segments' public inputs chain (hash and numbering links, the first and last ones are the request's), a
+    second run is byte-identical, and the links are what holds the range together: with two segments exchanged, or one segment
+    replaced by a valid proof of the same rows of ANOTHER chain, the blob is refused."""
+    n, n_seg = 256, 8
+    ch = vx.synth.Chain(n, profile="P15k")
+    hb = ctx.from_host(ch.headers)
+    cfg = ctx.stark_config()
+    sj = vx.synth.Justification(ch.target_block, ch.target_hash)
+    just = vx.lib.PackedJustification(sj)
+    args = (hb, ch.stride, ch.sizes, n, ch.trusted_block, ch.trusted_hash, ch.target_block, cfg)
+    ver = dict(authority_set_hash=sj.authority_set_hash, authority_set_id=sj.set_id)
+    out96, blob = ctx.header_range_prove(*args, just=just, n_segments=n_seg)
+    blob = blob.copy()
+    assert out96 == ch.expected_outputs(n) and vx.lib.blob_segments(blob) == n_seg
+    vx.lib.header_range_verify(blob, n, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg, **ver)
+    _, again = ctx.header_range_prove(*args, just=just, n_segments=n_seg)
+    assert (again == blob).all()
+    segs = vx.lib.split_blob_segments(blob)[0]
+    pubs = [[int(x) for x in S.proof_peek(p, 4)[0]] for p in segs]
+    assert all(int(p[2]) == 16 for p in segs)                       # every segment is a 2^16-row table
+    assert pubs[0][:8] == limbs(ch.trusted_hash) and pubs[-1][8:16] == limbs(out96[:32])
+    assert pubs[0][16] == ch.trusted_block + 1 and pubs[-1][17] == ch.target_block
+    for a, b in zip(pubs, pubs[1:]):
+        assert a[8:16] == b[:8] and b[16] == a[17] + 1
+    assert sum(p[17] - p[16] + 1 for p in pubs) == n
+
+    def rebuild(parts):
+        hdr = blob[: vx.lib.HR_FIXED + n_seg].copy()
+        hdr[vx.lib.HR_FIXED: vx.lib.HR_FIXED + n_seg] = [p.size for p in parts]
+        tail = blob[vx.lib.HR_FIXED + n_seg + sum(p.size for p in segs):]
+        return np.concatenate([hdr] + list(parts) + [tail])
+
+    assert (rebuild(segs) == blob).all()
+    swapped = list(segs)
+    swapped[2], swapped[5] = swapped[5], swapped[2]
+    with pytest.raises(vx.VxError):
+        vx.lib.header_range_verify(rebuild(swapped), n, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg, **ver)
+    other = vx.synth.Chain(n, profile="P15k", seed=vx.synth.CHAIN_SEED + 1)
+    ob = ctx.from_host(other.headers)
+    _, blob_o = ctx.header_range_prove(ob, other.stride, other.sizes, n, other.trusted_block, other.trusted_hash, other.target_block, cfg,
+                                       just=vx.lib.PackedJustification(vx.synth.Justification(other.target_block, other.target_hash)), n_segments=n_seg)
+    segs_o = vx.lib.split_blob_segments(blob_o.copy())[0]
+    foreign = list(segs)
+    foreign[3] = segs_o[3]
+    with pytest.raises(vx.VxError):
+        vx.lib.header_range_verify(rebuild(foreign), n, ch.trusted_block, ch.trusted_hash, ch.target_block, out96, cfg, **ver)
+    hb.free(), ob.free()
+
+
 def test_shards_of_one_proof_merge_to_the_segmented_blob(vx):
     """Intra-proof sharding: the tables of ONE proof proven by two shards -- here two host threads with a context
     each on the one GPU, exchanging their trace caps through the all-reduce the C ABI asks for -- and merged: byte for byte the
