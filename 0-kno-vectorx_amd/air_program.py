@@ -13,7 +13,7 @@ sub-expression (the same Python object used twice) is evaluated once; nothing is
 import numpy as np
 
 P = 2**64 - 2**32 + 1
-OP = dict(loc=1, nxt=2, per=3, pub=4, const=5, add=6, sub=7, mul=8, assert_zero=9, assert_transition=10, assert_first=11, assert_last=12)
+OP = dict(loc=1, nxt=2, per=3, pub=4, const=5, add=6, sub=7, mul=8, assert_zero=9, assert_transition=10, assert_first=11, assert_last=12, chal=13, apub=14)
 MAX_REGS = 32
 
 
@@ -50,11 +50,56 @@ class Expr:
         return Expr("mul", Expr.of(o), self)
 
 
+class X2:
+    """An element a + b X of the quadratic extension F[X]/(X^2 - 7) as a pair of expressions: lookup arguments (logUp) work there,
+    and the library's instruction set is base-field only, so the products are written out here (csrc/air.cuh X2<F> does the same
+    for the compiled AIRs, in the same order of operations)."""
+
+    def __init__(self, a, b=0):
+        self.a, self.b = Expr.of(a), Expr.of(b)
+
+    def __add__(self, o):
+        if isinstance(o, X2):
+            return X2(self.a + o.a, self.b + o.b)
+        return X2(self.a + o, self.b)
+
+    def __sub__(self, o):
+        if isinstance(o, X2):
+            return X2(self.a - o.a, self.b - o.b)
+        return X2(self.a - o, self.b)
+
+    def __mul__(self, o):
+        if isinstance(o, X2):
+            bb = self.b * o.b
+            b2 = bb + bb
+            b4 = b2 + b2
+            return X2(self.a * o.a + (b4 + b4 - bb), self.a * o.b + self.b * o.a)  # 7 x = 8 x - x
+        return X2(self.a * o, self.b * o)
+
+
 class AirBuilder:
-    def __init__(self, cols, n_public=0, periodic=()):
+    def __init__(self, cols, n_public=0, periodic=(), aux_cols=0, n_challenges=0, n_aux_public=0):
         self.cols, self.n_public = cols, n_public
+        self.aux_cols, self.n_challenges, self.n_aux_public = aux_cols, n_challenges, n_aux_public
         self.periodic = [[int(v) % P for v in col] for col in periodic]
         self.constraints = []
+
+    def chal(self, i):
+        return Expr("chal", i)
+
+    def apub(self, i):
+        return Expr("apub", i)
+
+    def aux(self, j):
+        """auxiliary column j of the local row (rows hold the main columns followed by the auxiliary ones)"""
+        return Expr("loc", self.cols + j)
+
+    def aux_nxt(self, j):
+        return Expr("nxt", self.cols + j)
+
+    def assert_zero_x2(self, e):
+        self.assert_zero(e.a)
+        self.assert_zero(e.b)
 
     def loc(self, col):
         return Expr("loc", col)
@@ -121,15 +166,15 @@ class AirBuilder:
                         const_ix[e.a] = len(consts)
                         consts.append(e.a)
                     code.append(insn(OP["const"], d, const_ix[e.a]))
-                elif e.op in ("loc", "nxt", "per", "pub"):
+                elif e.op in ("loc", "nxt", "per", "pub", "chal", "apub"):
                     code.append(insn(OP[e.op], d, e.a))
                 else:
                     code.append(insn(OP[e.op], d, ra, rb))
             code.append(insn(OP[kind], 0, reg[id(root)]))
         return np.array(code, dtype=np.uint64), np.array(consts, dtype=np.uint64), n_regs
 
-    def register(self):
+    def register(self, gen_aux=None):
         from . import lib
 
         code, consts, n_regs = self.assemble()
-        return lib.air_register(self.cols, self.n_public, code, consts, self.periodic, n_regs)
+        return lib.air_register(self.cols, self.n_public, code, consts, self.periodic, n_regs, self.aux_cols, self.n_challenges, self.n_aux_public, gen_aux)

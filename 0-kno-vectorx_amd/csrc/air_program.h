@@ -17,6 +17,9 @@ struct AirProgram {
     std::vector<uint8_t> plog;      // per periodic column
     std::vector<uint64_t> periodic; // one period of every periodic column, back to back
     std::vector<uint64_t> consts, code;
+    uint32_t aux = 0, chal = 0, auxpub = 0;  // auxiliary round: columns, base-field challenges, published extension values
+    vx_air_gen_aux_fn gen_aux = nullptr;     // the host's witness generator of that round (prover only)
+    void* gen_aux_user = nullptr;
 };
 // nullptr when the id is unknown or retired; a registered program is never freed
 const AirProgram* vx_air_program_find(int id);
@@ -28,7 +31,7 @@ static inline AirpInsn airp_decode(uint64_t w) { return {(int)(w & 0xFF), (int)(
 
 // host evaluation over any field type with + - * (the verifier's Fx); C = the constraint consumer of air.cuh
 template <class F, class Row, class C>
-static void air_program_eval(const AirProgram& p, const Row& loc, const Row& nxt, const F* per, const F* pub, C& c) {
+static void air_program_eval(const AirProgram& p, const Row& loc, const Row& nxt, const F* per, const F* pub, const F* chal, const F* apub, C& c) {
     std::vector<F> r(p.n_regs ? p.n_regs : 1);
     for (uint64_t w : p.code) {
         const AirpInsn i = airp_decode(w);
@@ -38,6 +41,8 @@ static void air_program_eval(const AirProgram& p, const Row& loc, const Row& nxt
             case VX_AIRP_PER: r[i.d] = per[i.a]; break;
             case VX_AIRP_PUB: r[i.d] = pub[i.a]; break;
             case VX_AIRP_CONST: r[i.d] = F::from(p.consts[i.a]); break;
+            case VX_AIRP_CHAL: r[i.d] = chal[i.a]; break;
+            case VX_AIRP_APUB: r[i.d] = apub[i.a]; break;
             case VX_AIRP_ADD: r[i.d] = r[i.a] + r[i.b]; break;
             case VX_AIRP_SUB: r[i.d] = r[i.a] - r[i.b]; break;
             case VX_AIRP_MUL: r[i.d] = r[i.a] * r[i.b]; break;

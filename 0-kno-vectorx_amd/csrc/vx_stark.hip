@@ -181,6 +181,8 @@ __global__ __launch_bounds__(QB) void k_quotient_prog(QuotArgs a, ProgArgs p) {
             case VX_AIRP_PER: R[d] = a.periodic[p.per_tab[2 * ra] + (i & p.per_tab[2 * ra + 1])]; break;
             case VX_AIRP_PUB: R[d] = a.pub[ra]; break;
             case VX_AIRP_CONST: R[d] = p.consts[ra]; break;
+            case VX_AIRP_CHAL: R[d] = a.chal[ra & 7]; break;
+            case VX_AIRP_APUB: R[d] = a.apub[ra & 7]; break;
             case VX_AIRP_ADD: R[d] = gl_add(R[ra * QB], R[rb * QB]); break;
             case VX_AIRP_SUB: R[d] = gl_sub(R[ra * QB], R[rb * QB]); break;
             case VX_AIRP_MUL: R[d] = gl_mul(R[ra * QB], R[rb * QB]); break;
@@ -413,6 +415,7 @@ static const AirDesc* find_air(int id) {
         if (it == g_prog_desc.end()) {
             AirDesc d{};
             d.id = id, d.cols = (int)pg->cols, d.pub = (int)pg->pub, d.periodic = (int)pg->plog.size(), d.period_log = pg->period_log, d.prog = pg;
+            d.aux = (int)pg->aux, d.chal = (int)pg->chal, d.auxpub = (int)pg->auxpub;
             it = g_prog_desc.emplace(id, d).first;
         }
         return &it->second;
@@ -420,6 +423,17 @@ static const AirDesc* find_air(int id) {
     return nullptr;
 }
 static int air_plog(const AirDesc* air, int q) { return air->prog ? air->prog->plog[q] : air->plog(q); }
+// the auxiliary columns of an AIR: the compiled generator, or the host's callback of a registered program (which sees the
+// device arrays as buffers of the context)
+static bool air_has_gen_aux(const AirDesc* air) { return air->prog ? air->prog->gen_aux != nullptr : air->gen_aux != nullptr; }
+static int32_t air_gen_aux(vx_ctx* ctx, const AirDesc* air, uint64_t* trace_d, int L, const uint64_t* chal, const uint64_t* pub, uint64_t* aux_d, uint64_t* apub) {
+    if (!air->prog) return air->gen_aux(ctx, trace_d, L, chal, pub, aux_d, apub);
+    const size_t n = (size_t)1 << L;
+    vx_buf tb{trace_d, n * (size_t)air->cols}, ab{aux_d, n * (size_t)air->aux};
+    const int32_t rc = air->prog->gen_aux(air->prog->gen_aux_user, ctx, &tb, L, chal, pub, &ab, apub);
+    if (rc != VX_OK) return vx_fail(ctx, rc, "air program %d: the auxiliary-round generator returned %d", air->id, rc);
+    return VX_OK;
+}
 
 // values v[0..p) of a periodic column on the rows -> its values on the LDE coset:
 // P(Y) with P(w_p^k) = v[k]; coset point Y_i = shift^(n/p) * w_{p 2^r}^i, i < p 2^r.
@@ -537,7 +551,7 @@ int32_t vx_stark_aux_trace(vx_ctx* ctx, int air_id, const vx_buf* trace, int log
                            const uint64_t* challenges, size_t n_challenges, vx_buf* aux_out, uint64_t* aux_public_out) {
     if (!ctx || !trace || !challenges || !aux_out) return VX_ERR_ARG;
     const AirDesc* air = find_air(air_id);
-    VX_CHECK(air && air->aux > 0 && air->gen_aux, "aux trace: AIR %d has no auxiliary round", air_id);
+    VX_CHECK(air && air->aux > 0 && air_has_gen_aux(air), "aux trace: AIR %d has no auxiliary round (or no generator for it)", air_id);
     VX_CHECK((int)n_challenges == air->chal, "aux trace: AIR %d takes %d challenges", air_id, air->chal);
     VX_CHECK(log_n >= air->period_log && log_n <= 26, "aux trace: log_n %d out of range", log_n);
     const size_t n = (size_t)1 << log_n;
@@ -545,7 +559,7 @@ int32_t vx_stark_aux_trace(vx_ctx* ctx, int air_id, const vx_buf* trace, int log
     for (size_t i = 0; i < n_challenges; ++i) VX_CHECK(challenges[i] < glh::P, "aux trace: non-canonical challenge");
     uint64_t apub[8] = {0};
     VX_CHECK((int)n_public == air->pub && (n_public == 0 || public_inputs), "aux trace: AIR %d takes %d public inputs", air_id, air->pub);
-    VX_TRY(air->gen_aux(ctx, trace->d, log_n, challenges, public_inputs, aux_out->d, apub));
+    VX_TRY(air_gen_aux(ctx, air, trace->d, log_n, challenges, public_inputs, aux_out->d, apub));
     if (aux_public_out)
         for (int q = 0; q < 2 * air->auxpub; ++q) aux_public_out[q] = apub[q];
     return VX_OK;
@@ -726,7 +740,7 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
     // after the lookup challenges are known
     const size_t n = (size_t)1 << L, N = (size_t)1 << LN, cm = air->cols, ca = air->aux, c = cm + ca;
     VX_CHECK(trace_len >= n * cm, "stark prove: trace holds %zu < %zu elements", trace_len, n * cm);
-    VX_CHECK(air->chal <= 8 && 2 * air->auxpub <= 8 && (ca == 0 || air->gen_aux), "stark prove: AIR %d auxiliary round is misconfigured", air_id);
+    VX_CHECK(air->chal <= 8 && 2 * air->auxpub <= 8 && (ca == 0 || air_has_gen_aux(air)), "stark prove: AIR %d auxiliary round is misconfigured (a program needs its gen_aux callback to be proven)", air_id);
     for (size_t i = 0; i < n_public; ++i) VX_CHECK(public_inputs[i] < glh::P, "stark prove: public input %zu not canonical", i);
     const int Q = 2, nq = 2 * Q;  // quotient_degree_factor 2 (constraint degree 3), 2 challenges
     const uint64_t g = 7;         // F::coset_shift()
@@ -785,7 +799,7 @@ int32_t vx_stark_prove_impl(vx_ctx* ctx, int air_id, const vx_stark_config* cfg_
             for (int q = 0; q < air->chal; ++q) chal[q] = ch.challenge();
         aux_d = mem.alloc(n * ca);
         VX_CHECK(aux_d, "stark prove: out of device memory (auxiliary trace)");
-        VX_TRY(air->gen_aux(ctx, trace_d, L, chal, public_inputs, aux_d, apub));
+        VX_TRY(air_gen_aux(ctx, air, trace_d, L, chal, public_inputs, aux_d, apub));
         VX_TRY(vx_lde_consume_dev(ctx, aux_d, L, ca, r, g, trace_lde + N * cm));
         VX_TRY(vx_merkle_build_dev(ctx, trace_lde + N * cm, N, ca, VX_LEAVES_COLS_BITREV, cfg.cap_height, &t_aux));
         mem.trees.push_back(t_aux);

@@ -196,8 +196,13 @@ int32_t vx_air_register(const vx_air_program* in, int* air_id, char* err, size_t
     AIRP_NEED(in->n_regs >= 1 && in->n_regs <= VX_AIRP_MAX_REGS, "air program: %u registers (1..%d)", in->n_regs, VX_AIRP_MAX_REGS);
     AIRP_NEED(in->n_consts <= 65536 && (in->n_consts == 0 || in->consts), "air program: bad constant table");
     AIRP_NEED(in->code && in->n_code >= 1 && in->n_code <= VX_AIRP_MAX_CODE, "air program: %u instructions (1..%d)", in->n_code, VX_AIRP_MAX_CODE);
+    AIRP_NEED(in->aux_cols <= VX_AIRP_MAX_COLS && in->cols + in->aux_cols <= VX_AIRP_MAX_COLS && in->n_challenges <= 8 && in->n_aux_public <= 4,
+              "air program: auxiliary round out of range (%u columns, %u challenges <= 8, %u published values <= 4)", in->aux_cols, in->n_challenges, in->n_aux_public);
+    AIRP_NEED(in->aux_cols > 0 || (in->n_challenges == 0 && in->n_aux_public == 0 && !in->gen_aux), "air program: challenges / published values / a generator without auxiliary columns");
+    AIRP_NEED(in->aux_cols == 0 || in->n_challenges > 0, "air program: an auxiliary round without a challenge is a second trace commitment, not a lookup round");
     auto pg = std::make_shared<AirProgram>();
     pg->cols = in->cols, pg->pub = in->n_public, pg->n_regs = in->n_regs;
+    pg->aux = in->aux_cols, pg->chal = in->n_challenges, pg->auxpub = in->n_aux_public, pg->gen_aux = in->gen_aux, pg->gen_aux_user = in->gen_aux_user;
     size_t n_per_values = 0;
     for (uint32_t q = 0; q < in->n_periodic; ++q) {
         AIRP_NEED(in->periodic_log[q] <= VX_AIRP_MAX_PERIOD_LOG, "air program: periodic column %u has period 2^%u (at most 2^%d)", q, in->periodic_log[q], VX_AIRP_MAX_PERIOD_LOG);
@@ -221,7 +226,7 @@ int32_t vx_air_register(const vx_air_program* in, int* air_id, char* err, size_t
         switch (i.op) {
             case VX_AIRP_LOC:
             case VX_AIRP_NXT:
-                AIRP_NEED(reg_ok(i.d) && i.a < (int)in->cols && i.b == 0, "air program: instruction %u: bad column load", pc);
+                AIRP_NEED(reg_ok(i.d) && i.a < (int)(in->cols + in->aux_cols) && i.b == 0, "air program: instruction %u: bad column load", pc);
                 deg[i.d] = 1;
                 break;
             case VX_AIRP_PER:
@@ -234,6 +239,14 @@ int32_t vx_air_register(const vx_air_program* in, int* air_id, char* err, size_t
                 break;
             case VX_AIRP_CONST:
                 AIRP_NEED(reg_ok(i.d) && i.a < (int)in->n_consts && i.b == 0, "air program: instruction %u: bad constant load", pc);
+                deg[i.d] = 0;
+                break;
+            case VX_AIRP_CHAL:
+                AIRP_NEED(reg_ok(i.d) && i.a < (int)in->n_challenges && i.b == 0, "air program: instruction %u: bad challenge load", pc);
+                deg[i.d] = 0;
+                break;
+            case VX_AIRP_APUB:
+                AIRP_NEED(reg_ok(i.d) && i.a < (int)(2 * in->n_aux_public) && i.b == 0, "air program: instruction %u: bad published-value load", pc);
                 deg[i.d] = 0;
                 break;
             case VX_AIRP_ADD:
@@ -331,7 +344,7 @@ int32_t vx_stark_verify_ext(const vx_stark_config* cfg, const uint64_t* pr, size
     AirV prog_air{};
     if (!air && air_id >= VX_AIR_USER_BASE) {
         if (const AirProgram* pg = vx_air_program_find(air_id)) {
-            prog_air = {air_id, (int)pg->cols, (int)pg->pub, (int)pg->plog.size(), pg->period_log, 0, nullptr, nullptr, 0, 0, 0, nullptr, pg};
+            prog_air = {air_id, (int)pg->cols, (int)pg->pub, (int)pg->plog.size(), pg->period_log, 0, nullptr, nullptr, (int)pg->aux, (int)pg->chal, (int)pg->auxpub, nullptr, pg};
             air = &prog_air;
         }
     }
@@ -448,7 +461,7 @@ int32_t vx_stark_verify_ext(const vx_stark_config* cfg, const uint64_t* pr, size
         for (int q = 0; q < air->chal; ++q) chalx[q] = {chal[q], 0};
         for (int q = 0; q < 2 * air->auxpub; ++q) apubx[q] = {apub[q], 0};
         HostRow loc{o_local.data()}, nxt{o_next.data()};
-        if (air->prog) air_program_eval<Fx>(*air->prog, loc, nxt, per.data(), pubx.data(), cons);
+        if (air->prog) air_program_eval<Fx>(*air->prog, loc, nxt, per.data(), pubx.data(), chalx.data(), apubx.data(), cons);
         else air->eval(loc, nxt, per.data(), pubx.data(), chalx.data(), apubx.data(), cons);
         for (int k = 0; k < 2; ++k) {
             const Fx q = o_quot[2 * k] + o_quot[2 * k + 1] * zn;

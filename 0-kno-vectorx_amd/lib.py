@@ -73,7 +73,13 @@ class StarkConfig(C.Structure):
 class AirProgramStruct(C.Structure):  # include/vx.h vx_air_program
     _fields_ = [("cols", C.c_uint32), ("n_public", C.c_uint32), ("n_periodic", C.c_uint32), ("n_regs", C.c_uint32),
                 ("periodic_log", C.c_void_p), ("periodic_values", C.c_void_p), ("consts", C.c_void_p), ("n_consts", C.c_uint32),
-                ("code", C.c_void_p), ("n_code", C.c_uint32)]
+                ("code", C.c_void_p), ("n_code", C.c_uint32), ("aux_cols", C.c_uint32), ("n_challenges", C.c_uint32), ("n_aux_public", C.c_uint32),
+                ("gen_aux", C.c_void_p), ("gen_aux_user", C.c_void_p)]
+
+
+# include/vx.h vx_air_gen_aux_fn: (user, ctx, trace vx_buf*, log_n, challenges, public inputs, aux_out vx_buf*, aux_public_out) -> int32
+AIR_GEN_AUX_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64))
+_air_callbacks = []  # registered programs live for the life of the process: so do their callbacks
 
 
 class VxError(RuntimeError):
@@ -190,10 +196,13 @@ def stark_verify(proof, cfg=None, expect_air=0, expect_public=None):
         raise VxError(rc, err.value.decode())
 
 
-def air_register(cols, n_public, code, consts=(), periodic=(), n_regs=None):
+def air_register(cols, n_public, code, consts=(), periodic=(), n_regs=None, aux_cols=0, n_challenges=0, n_aux_public=0, gen_aux=None):
     """Register a constraint program (include/vx.h vx_air_register; no GPU needed) and return its AIR id.
     code: uint64 instruction words; consts: canonical field elements; periodic: a list of columns, each 2^k values;
-    n_regs: registers used (default: the highest register the code names + 1).  air_program.AirBuilder writes these."""
+    n_regs: registers used (default: the highest register the code names + 1).  air_program.AirBuilder writes these.
+    Auxiliary round: aux_cols / n_challenges / n_aux_public and gen_aux(ctx_handle, trace_handle, log_n, challenges, public_inputs,
+    aux_handle) -> list of 2 * n_aux_public published words -- the host's generator of the auxiliary columns (the handles are
+    the C ABI's vx_ctx* / vx_buf*: Context.adopt / Buffer.adopt wrap them)."""
     L = load_library()
     code = np.ascontiguousarray(code, dtype=np.uint64)
     consts = np.ascontiguousarray(consts, dtype=np.uint64)
@@ -204,8 +213,28 @@ def air_register(cols, n_public, code, consts=(), periodic=(), n_regs=None):
     pvals = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.uint64) for c in periodic]) if len(periodic) else np.zeros(0, np.uint64))
     if n_regs is None:
         n_regs = 1 + max([int((w >> 8) & 0xFF) for w in code.tolist()] + [0])
+    cb = None
+    if gen_aux is not None:
+        def trampoline(_user, ctx_h, trace_h, log_n, chal_p, pub_p, aux_h, apub_p):
+            try:
+                chal = [int(chal_p[i]) for i in range(n_challenges)]
+                pub = [int(pub_p[i]) for i in range(n_public)]
+                out = gen_aux(ctx_h, trace_h, log_n, chal, pub, aux_h) or []
+                if len(out) != 2 * n_aux_public:
+                    return -1
+                for i, v in enumerate(out):
+                    apub_p[i] = int(v)
+                return 0
+            except Exception:  # noqa: BLE001 -- an exception must not cross the C boundary
+                import traceback
+
+                traceback.print_exc()
+                return -5
+        cb = AIR_GEN_AUX_FN(trampoline)
+        _air_callbacks.append(cb)
     st = AirProgramStruct(cols, n_public, len(periodic), n_regs, _ptr(plog) if len(periodic) else None, _ptr(pvals) if len(periodic) else None,
-                          _ptr(consts) if consts.size else None, consts.size, _ptr(code) if code.size else None, code.size)
+                          _ptr(consts) if consts.size else None, consts.size, _ptr(code) if code.size else None, code.size,
+                          aux_cols, n_challenges, n_aux_public, C.cast(cb, C.c_void_p) if cb is not None else None, None)
     air_id, err = C.c_int(0), C.create_string_buffer(256)
     rc = L.vx_air_register(C.byref(st), C.byref(air_id), err, 256)
     if rc != 0:
@@ -332,10 +361,18 @@ class Buffer:
     def devptr(self):
         return self.ctx.L.vx_buf_devptr(self.h)
 
+    @classmethod
+    def adopt(cls, ctx, handle):
+        """A vx_buf* the library handed to a callback (vx_air_gen_aux_fn): usable, not owned."""
+        b = cls.__new__(cls)
+        b.ctx, b.h, b.borrowed = ctx, C.c_void_p(handle), True
+        b.n = int(ctx.L.vx_buf_len(b.h))
+        return b
+
     def free(self):
-        if self.h:
+        if self.h and not getattr(self, "borrowed", False):
             self.ctx.L.vx_free(self.ctx.h, self.h)
-            self.h = None
+        self.h = None
 
 
 class Tree:
@@ -380,10 +417,17 @@ class Context:
         if rc != 0:
             raise VxError(rc, self.L.vx_last_error(self.h).decode())
 
+    @classmethod
+    def adopt(cls, handle):
+        """The vx_ctx* a callback was called with: usable, not owned."""
+        c = cls.__new__(cls)
+        c.L, c.h, c.borrowed = load_library(), C.c_void_p(handle), True
+        return c
+
     def close(self):
-        if self.h:
+        if self.h and not getattr(self, "borrowed", False):
             self.L.vx_ctx_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __enter__(self):
         return self

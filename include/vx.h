@@ -174,18 +174,30 @@ int32_t vx_stark_default_config(vx_stark_config* cfg);
  *   LOC d, a      r[d] = local row, column a            NXT d, a     r[d] = next row, column a
  *   PER d, a      r[d] = periodic column a              PUB d, a     r[d] = public input a
  *   CONST d, a    r[d] = consts[a]                      ADD / SUB / MUL d, a, b   r[d] = r[a] op r[b]
+ *   CHAL d, a     r[d] = lookup challenge a          APUB d, a    r[d] = word a of the values published with the auxiliary cap
  *   ASSERT a            r[a] = 0 on EVERY row (the wrap-around pair included)
  *   ASSERT_TRANSITION a r[a] (x - w^-1): every row pair but the wrap-around      ASSERT_FIRST a / ASSERT_LAST a: on that row only
  * Constraints are consumed in program order (the order is protocol, as for the compiled AIRs).  Registration checks every operand,
  * that no register is read before it is written, that constants and periodic values are canonical, and the DEGREE of every
  * asserted expression (columns and periodic columns count 1; ASSERT <= 3, the three others <= 2: rate_bits 1 carries degree 3).
- * Periodic column q has 2^periodic_log[q] values (<= 2^16), given back to back.  A program is immutable once registered and its id
- * (>= VX_AIR_USER_BASE, never reused) works wherever an AIR id does: vx_quotient_eval, vx_stark_proof_bound, vx_stark_prove,
- * vx_stark_verify.  Registration is process-wide, thread-safe, needs no GPU; a verifier must register the SAME program (the proof does
- * not carry it).  vx_air_unregister retires the id. */
+ * Periodic column q has 2^periodic_log[q] values (<= 2^16), given back to back.
+ * AUXILIARY ROUND (lookup / logUp arguments, starky's `lookups()`): a program may declare aux_cols further columns, n_challenges
+ * base-field challenges (<= 8; extension elements are pairs) and n_aux_public published extension values (<= 4).  After the trace
+ * cap the prover draws the challenges and calls gen_aux -- the HOST's witness generator for this round: trace = the main columns
+ * [cols][2^log_n] and aux_out = [aux_cols][2^log_n], both resident in HBM as buffers of `ctx` (use the library's primitives or
+ * the host's own kernels on vx_buf_devptr, on the ctx stream); aux_public_out receives 2 * n_aux_public words.  The rows the
+ * program sees hold the main columns followed by the auxiliary ones (LOC / NXT a >= cols).  Extension-field arithmetic
+ * (F[X]/(X^2 - 7)) is written out in base-field instructions by whoever writes the program (air_program.py does).  A program with
+ * aux_cols > 0 and gen_aux NULL can be verified, not proven.
+ * A program is immutable once registered and its id
+ * (>= VX_AIR_USER_BASE, never reused) works wherever an AIR id does: vx_quotient_eval, vx_stark_aux_trace, vx_stark_proof_bound,
+ * vx_stark_prove, vx_stark_verify.  Registration is process-wide, thread-safe, needs no GPU; a verifier must register the SAME
+ * program (the proof does not carry it).  vx_air_unregister retires the id. */
 enum { VX_AIRP_LOC = 1, VX_AIRP_NXT = 2, VX_AIRP_PER = 3, VX_AIRP_PUB = 4, VX_AIRP_CONST = 5, VX_AIRP_ADD = 6, VX_AIRP_SUB = 7, VX_AIRP_MUL = 8,
-       VX_AIRP_ASSERT = 9, VX_AIRP_ASSERT_TRANSITION = 10, VX_AIRP_ASSERT_FIRST = 11, VX_AIRP_ASSERT_LAST = 12 };
+       VX_AIRP_ASSERT = 9, VX_AIRP_ASSERT_TRANSITION = 10, VX_AIRP_ASSERT_FIRST = 11, VX_AIRP_ASSERT_LAST = 12, VX_AIRP_CHAL = 13, VX_AIRP_APUB = 14 };
 enum { VX_AIR_USER_BASE = 4096, VX_AIRP_MAX_REGS = 32, VX_AIRP_MAX_COLS = 65535, VX_AIRP_MAX_CODE = 1 << 20, VX_AIRP_MAX_PERIOD_LOG = 16 };
+typedef int32_t (*vx_air_gen_aux_fn)(void* user, vx_ctx* ctx, const vx_buf* trace, int log_n, const uint64_t* challenges,
+                                     const uint64_t* public_inputs, vx_buf* aux_out, uint64_t* aux_public_out);
 typedef struct vx_air_program {
     uint32_t cols, n_public, n_periodic, n_regs;
     const uint8_t* periodic_log;      /* [n_periodic] */
@@ -194,6 +206,9 @@ typedef struct vx_air_program {
     uint32_t n_consts;
     const uint64_t* code;
     uint32_t n_code;
+    uint32_t aux_cols, n_challenges, n_aux_public; /* auxiliary round: all zero = none */
+    vx_air_gen_aux_fn gen_aux;
+    void* gen_aux_user;
 } vx_air_program;
 int32_t vx_air_register(const vx_air_program* program, int* air_id, char* err, size_t errlen);
 int32_t vx_air_unregister(int air_id);

@@ -61,3 +61,24 @@ def cube_trace(log_n, seed=3, force_t=None):
         tr[0, i], tr[1, i], tr[2, i], tr[3, i], tr[4, i] = x, w, y, i, ts[i]
         x, y = (w * x + CUBE_KEYS[i % 8]) % P, (y + x * i + int(ts[i])) % P
     return tr, [x0, int(tr[2, n - 1])]
+
+
+def lookup_builder(ap):
+    """LookupAir (AIR id 5, csrc/air.cuh / oracle/stark_ref.py) restated: two XOR lookups per row into a periodic 256-row table by
+    logUp -- four base-field challenges (beta, gamma in the extension), six auxiliary columns (helper, table helper, running sum)."""
+    idx = range(256)
+    b = ap.AirBuilder(7, 0, periodic=[[i & 15 for i in idx], [i >> 4 for i in idx], [(i & 15) ^ (i >> 4) for i in idx]], aux_cols=6, n_challenges=4)
+    X2 = ap.X2
+    beta, gamma = X2(b.chal(0), b.chal(1)), X2(b.chal(2), b.chal(3))
+    g2 = gamma * gamma
+
+    def fp(x, y, z):
+        return beta + x + gamma * y + g2 * z
+
+    d0, d1 = fp(b.loc(0), b.loc(1), b.loc(2)), fp(b.loc(3), b.loc(4), b.loc(5))
+    dt = fp(b.per(0), b.per(1), b.per(2))
+    h, ht, z, zn = X2(b.aux(0), b.aux(1)), X2(b.aux(2), b.aux(3)), X2(b.aux(4), b.aux(5)), X2(b.aux_nxt(4), b.aux_nxt(5))
+    b.assert_zero_x2(h * d0 * d1 - d0 - d1)
+    b.assert_zero_x2(ht * dt - b.loc(6))
+    b.assert_zero_x2(zn - z - h + ht)
+    return b

@@ -88,6 +88,26 @@ def test_an_air_that_is_not_compiled_in(vx, oracle):
         vx.lib.stark_verify(bad, pcfg)
 
 
+def test_a_program_with_a_lookup_round(vx, oracle):
+    """LookupAir restated (auxiliary columns, challenges, extension arithmetic written out in base-field instructions): the
+    reference prover gives the compiled AIR's proof word for word, and the product's host interpreter accepts it."""
+    b = AP.lookup_builder(vx.air_program)
+    code, consts, _ = b.assemble()
+    air_id = b.register()  # no generator: enough to verify
+    air = ProgramAir(air_id, b.cols, b.n_public, code, consts, b.periodic, b.aux_cols, b.n_challenges, b.n_aux_public, gen_aux=S.LookupAir.gen_aux)
+    S.register_air(air)
+    trace, pub = S.LookupAir.trace(8)
+    got, want = S.prove(air, trace, pub, CFG), S.prove(S.LookupAir, trace, pub, CFG)
+    assert (np.delete(got, 1) == np.delete(want, 1)).all() and got[1] == air_id
+    pcfg = vx.lib.default_stark_config(num_queries=CFG["num_queries"])
+    vx.lib.stark_verify(got, pcfg, expect_air=air_id)
+    bad_trace = trace.copy()
+    bad_trace[2, 5] ^= 1  # z != x ^ y: the tuple is not in the table, the running sum cannot close
+    bad = S.prove(air, bad_trace, pub, CFG)
+    with pytest.raises(vx.VxError):
+        vx.lib.stark_verify(bad, pcfg, expect_air=air_id)
+
+
 def test_builder_shares_subexpressions_and_recycles_registers(vx):
     ap = vx.air_program
     b = ap.AirBuilder(2)
@@ -115,7 +135,7 @@ def test_registration_checks(vx):
         "never written": [I(6, 0, 1, 2), I(9, 0, 0)],
         "asserts a register": [I(9, 0, 5)],
         "bad column": [I(1, 0, 7), I(9, 0, 0)],
-        "unknown opcode": [I(13, 0, 0), I(9, 0, 0)],
+        "unknown opcode": [I(15, 0, 0), I(9, 0, 0)],
         "reserved": [I(1, 0, 0) | (1 << 50), I(9, 0, 0)],
         "no constraint": [I(1, 0, 0)],
         "degree 4": [I(1, 0, 0), I(8, 1, 0, 0), I(8, 1, 1, 1), I(9, 0, 1)],
@@ -135,5 +155,19 @@ def test_registration_checks(vx):
         L.air_register(1, 0, [I(3, 0, 0), I(9, 0, 0)], periodic=[[1, P]])
     with pytest.raises(vx.VxError, match="columns"):
         L.air_register(0, 0, ok)
+    with pytest.raises(vx.VxError, match="bad challenge"):
+        L.air_register(1, 0, [I(13, 0, 0), I(9, 0, 0)], n_regs=2)
+    with pytest.raises(vx.VxError, match="bad challenge"):
+        L.air_register(1, 0, [I(13, 0, 2), I(9, 0, 0)], n_regs=2, aux_cols=2, n_challenges=2)
+    with pytest.raises(vx.VxError, match="published-value"):
+        L.air_register(1, 0, [I(14, 0, 2), I(9, 0, 0)], n_regs=2, aux_cols=2, n_challenges=2, n_aux_public=1)
+    with pytest.raises(vx.VxError, match="auxiliary round out of range"):
+        L.air_register(1, 0, ok, aux_cols=2, n_challenges=9)
+    with pytest.raises(vx.VxError, match="without auxiliary columns"):
+        L.air_register(1, 0, ok, n_challenges=2)
+    with pytest.raises(vx.VxError, match="without a challenge"):
+        L.air_register(1, 0, ok, aux_cols=2)
+    # an auxiliary column is a column: LOC 1 exists once aux_cols = 2
+    assert L.air_register(1, 0, [I(1, 0, 2), I(13, 1, 1), I(8, 0, 0, 1), I(9, 0, 0)], aux_cols=2, n_challenges=2) >= 4096
     # degree 3 on every row is the limit and is accepted
     assert L.air_register(1, 0, [I(1, 0, 0), I(8, 1, 0, 0), I(8, 1, 1, 0), I(9, 0, 1)]) >= 4096

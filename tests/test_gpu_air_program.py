@@ -84,6 +84,53 @@ def test_large_program_trace_and_other_configs(ctx, vx, oracle):
         assert (got == S.prove(air, trace, pub, dict(S.DEFAULT_CFG, **over))).all(), over
 
 
+def test_a_program_with_a_lookup_round(ctx, vx, oracle):
+    """The auxiliary round of a registered program: the prover commits the trace, draws the program's challenges and calls the
+    HOST's generator for the auxiliary columns (here a Python callback that runs the reference generator on the downloaded trace
+    and uploads the result into the buffer it was handed).  LookupAir restated this way gives the compiled LookupAir's proof and
+    the reference prover's, word for word."""
+    b = AP.lookup_builder(vx.air_program)
+    calls = []
+
+    def gen_aux(ctx_h, trace_h, log_n, chal, pub, aux_h):
+        c = vx.Context.adopt(ctx_h)
+        tr = vx.lib.Buffer.adopt(c, trace_h).download().reshape(7, -1)
+        assert tr.shape[1] == 1 << log_n and len(chal) == 4 and pub == []
+        aux, apub = S.LookupAir.gen_aux(tr, chal)
+        vx.lib.Buffer.adopt(c, aux_h).upload(aux)
+        calls.append(log_n)
+        return apub
+
+    air_id = b.register(gen_aux)
+    code, consts, _ = b.assemble()
+    air = ProgramAir(air_id, b.cols, b.n_public, code, consts, b.periodic, b.aux_cols, b.n_challenges, b.n_aux_public, gen_aux=S.LookupAir.gen_aux)
+    S.register_air(air)
+    for log_n in (8, 10):
+        trace, pub = S.LookupAir.trace(log_n)
+        got = ctx.stark_prove(air_id, ctx.from_host(trace), log_n, pub)
+        compiled = ctx.stark_prove(S.LookupAir.ID, ctx.from_host(trace), log_n, pub)
+        assert got[1] == air_id and (np.delete(got, 1) == np.delete(compiled, 1)).all()
+        assert (got == S.prove(air, trace, pub)).all()
+        vx.lib.stark_verify(got, expect_air=air_id)
+        S.verify(got, expect_air=air_id)
+    assert calls == [8, 10]
+    # the stand-alone generator entry point goes through the same callback and agrees with the compiled generator
+    trace, pub = S.LookupAir.trace(9)
+    chal = [11, 22, 33, 44]
+    a_prog, _ = ctx.stark_aux_trace(air_id, ctx.from_host(trace), 9, chal, 6)
+    a_comp, _ = ctx.stark_aux_trace(S.LookupAir.ID, ctx.from_host(trace), 9, chal, 6)
+    assert (a_prog.download() == a_comp.download()).all() and calls == [8, 10, 9]
+    # registered without a generator (a verifier's registration): verifies, cannot prove
+    verifier_only = b.register()
+    vx.lib.stark_verify(np.concatenate([got[:1], [np.uint64(verifier_only)], got[2:]]), expect_air=verifier_only)
+    with pytest.raises(vx.VxError, match="gen_aux"):
+        ctx.stark_prove(verifier_only, ctx.from_host(trace), 9, pub)
+    # a generator that fails is an error of the call, not a crash
+    failing = b.register(lambda *a: (_ for _ in ()).throw(RuntimeError("boom")))
+    with pytest.raises(vx.VxError, match="generator returned"):
+        ctx.stark_prove(failing, ctx.from_host(trace), 9, pub)
+
+
 def test_program_argument_errors(ctx, vx):
     b = AP.fib_builder(vx.air_program)
     air_id = b.register()

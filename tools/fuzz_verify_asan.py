@@ -215,7 +215,7 @@ def child(iters):
             k = int(rng.integers(c2.size))
             c2[k] ^= np.uint64(1) << np.uint64(rng.integers(48))
         elif kind == 1:  # random words with plausible opcodes
-            c2 = (rng.integers(1, 14, size=c2.size).astype(np.uint64) | (rng.integers(0, 40, size=c2.size).astype(np.uint64) << np.uint64(8))
+            c2 = (rng.integers(1, 16, size=c2.size).astype(np.uint64) | (rng.integers(0, 40, size=c2.size).astype(np.uint64) << np.uint64(8))
                   | (rng.integers(0, 40, size=c2.size).astype(np.uint64) << np.uint64(16)) | (rng.integers(0, 40, size=c2.size).astype(np.uint64) << np.uint64(32)))
         elif kind == 2:
             c2 = rng.integers(0, 2**63, size=int(rng.integers(0, 64)), dtype=np.uint64)

@@ -59,7 +59,11 @@ def block():
              "/// all-reduce (wrapping sum of u64 words) across the shards of one header_range proof (vx_header_range_prove_ex)",
              "/// a constraint program (run-time AIR descriptor) for vx_air_register: what a host lowers `Stark::eval_packed_generic` to",
              "#[repr(C)] pub struct VxAirProgram {", "    pub cols: u32, pub n_public: u32, pub n_periodic: u32, pub n_regs: u32,",
-             "    pub periodic_log: *const u8, pub periodic_values: *const u64, pub consts: *const u64, pub n_consts: u32, pub code: *const u64, pub n_code: u32,", "}",
+             "    pub periodic_log: *const u8, pub periodic_values: *const u64, pub consts: *const u64, pub n_consts: u32, pub code: *const u64, pub n_code: u32,",
+             "    pub aux_cols: u32, pub n_challenges: u32, pub n_aux_public: u32,",
+             "    /// the host's generator of the auxiliary (lookup) columns, called between the trace cap and the constraint challenges",
+             "    pub gen_aux: Option<unsafe extern \"C\" fn(user: *mut c_void, ctx: *mut VxCtx, trace: *const VxBuf, log_n: c_int, challenges: *const u64, public_inputs: *const u64, aux_out: *mut VxBuf, aux_public_out: *mut u64) -> i32>,",
+             "    pub gen_aux_user: *mut c_void,", "}",
              "#[repr(C)] pub struct VxHrExchange { pub func: Option<unsafe extern \"C\" fn(user: *mut c_void, words: *mut u64, n_words: usize) -> i32>, pub user: *mut c_void }",
              '#[link(name = "vxprove")]', 'extern "C" {']
     for ret, name, args in declarations():
