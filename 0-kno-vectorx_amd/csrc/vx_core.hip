@@ -140,6 +140,10 @@ extern "C" {
 
 const char* vx_backend_name(void) { return "hip-gfx950"; }
 
+// Stream priorities (VX_STREAM_PRIO=1; off by default, see profiles/README.md): a context made by the host gets the device's
+// highest priority, the side contexts a proof chains behind it (one per further table) the lowest -- the hash-chain table,
+// which is the critical path of a proof, runs on the host's context.
+static thread_local int g_side_ctx = 0;
 int32_t vx_ctx_create(int device, vx_ctx** out) {
     if (!out) return VX_ERR_ARG;
     *out = nullptr;
@@ -161,7 +165,15 @@ int32_t vx_ctx_create(int device, vx_ctx** out) {
         (void)hipSetDeviceFlags(m == 's' ? hipDeviceScheduleSpin : m == 'y' ? hipDeviceScheduleYield : hipDeviceScheduleBlockingSync);
         (void)hipGetLastError();  // (a host that has fixed the flags already keeps them)
     }
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess ||
+    hipError_t se = hipSetDevice(device);
+    if (se == hipSuccess) {
+        const char* sp = getenv("VX_STREAM_PRIO");
+        int least = 0, greatest = 0;
+        if (sp && sp[0] == '1' && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+            se = hipStreamCreateWithPriority(&ctx->stream, hipStreamDefault, g_side_ctx ? least : greatest);
+        else se = hipStreamCreate(&ctx->stream);
+    }
+    if (se != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx;
         return VX_ERR_DEVICE;
@@ -379,6 +391,10 @@ int32_t vx_gather_proofs(vx_ctx* ctx, void* nccl_comm, int world, const uint64_t
 }
 
 vx_ctx* vx_side_ctx(vx_ctx* ctx) {
-    if (!ctx->side && vx_ctx_create(ctx->device, &ctx->side) != VX_OK) ctx->side = nullptr;
+    if (!ctx->side) {
+        g_side_ctx = 1;
+        if (vx_ctx_create(ctx->device, &ctx->side) != VX_OK) ctx->side = nullptr;
+        g_side_ctx = 0;
+    }
     return ctx->side;
 }
