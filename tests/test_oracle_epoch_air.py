@@ -101,3 +101,38 @@ def test_epoch_end_forgeries():
         EP.gen_trace(bytes(h), e.start_position, 6)
     with pytest.raises(AssertionError):
         EP.gen_trace(e.bytes, e.start_position + 1, 6)
+
+
+def test_paired_mutation_of_the_byte_bus_dropping_a_validator():
+    """A false statement told consistently on BOTH sides of the epoch-end byte bus (bus balance cannot see a pair of
+    matching omissions): the last validator record is left out by the receiver (its row flag cleared, the delay row moved up) and by
+    the sender (a window 40 bytes shorter, followed by the four delay bytes).  The receiver is forced: the number of validator rows
+    is the public count n (checked by the verifier against the request), and n is the SCALE compact integer of the prefix bytes,
+    which are bytes of the hashed header -- so either the row-count constraint or the prefix constraint fails, whichever n is claimed."""
+    import vx_import
+
+    vx = vx_import.load()
+    n = 6
+    e = vx.synth.EpochEndHeader(140000, n)
+    tr, pub, _, plen = EP.gen_trace(e.bytes, e.start_position, n)
+    assert S.check_trace(EP.EpochEndAir, tr, pub, CHAL, *EP.gen_aux(tr, CHAL, pub)) is None
+    forged = tr.copy()
+    forged[:, n] = 0                      # validator n gone ...
+    forged[:, n] = tr[:, n + 1]           # ... its row is the delay row now
+    forged[:, n + 1] = 0
+    assert forged[EP.DL, n] == 1 and forged[EP.V, n] == 0
+
+    def violated(p):
+        aux, apub = EP.gen_aux(forged, CHAL, p)
+        return S.check_trace(EP.EpochEndAir, forged, p, CHAL, aux, apub)
+
+    bad = violated(pub)                    # claiming the true count: the delay row sits at record n - 1, not n
+    assert bad is not None and bad[1] == n
+    bad = violated([n - 1] + pub[1:])      # claiming n - 1: the rows agree, the compact integer in the prefix still says n
+    assert bad is not None and bad[1] == 0
+    # the sender's half of the lie is a valid Blake2b table (its window is witness-sized): only the receiver's constraints stand in the way
+    length = plen + 40 * (n - 1)
+    btr, bpub, _ = B.gen_trace([e.bytes], 16, e.bytes[:32], first_number=140000, window=(e.start_position + 1, length))
+    baux, bapub = B.BlakeChainAir.gen_aux(btr, CHAL, bpub)
+    rows = 16 * ((len(e.bytes) + 127) // 128)
+    assert S.check_trace(B.BlakeChainAir, btr, bpub, CHAL, baux, bapub, rows=(0, min(rows + 32, 4096))) is None
