@@ -82,3 +82,82 @@ def lookup_builder(ap):
     b.assert_zero_x2(ht * dt - b.loc(6))
     b.assert_zero_x2(zn - z - h + ht)
     return b
+
+
+# ---- PoseidonAir: the Poseidon-Goldilocks permutation (plonky2 v0.2.0 hash/poseidon.rs: width 12, x^7, 4 + 22 + 4 rounds) as a
+# constraint program -- the hash every Merkle path and transcript of this prover uses, i.e. the first table a recursive verifier
+#  needs.  One round per row, 32 rows per permutation (30 rounds, the output row, one spare):
+#   columns s[12] (state entering the round), a = x^2, b = a^2, t = x a b = x^7 with x = s + round constant (periodic);
+#   y_i = t_i in full rounds and for i = 0, x_i otherwise;  next s = MDS y on the 30 round rows, next s = s on the output row.
+MDS_CIRC = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
+MDS_DIAG = [8] + [0] * 11
+
+
+def poseidon_round_constants():
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gen_poseidon_constants.py")
+    spec = importlib.util.spec_from_file_location("_vx_gen_rc_t", path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.round_constants()
+
+
+def poseidon_builder(ap):
+    rc = poseidon_round_constants()
+    per = [[rc[12 * r + i] if r < 30 else 0 for r in range(32)] for i in range(12)]
+    per.append([1 if (r < 4 or 26 <= r < 30) else 0 for r in range(32)])  # full
+    per.append([1 if r < 30 else 0 for r in range(32)])                   # a round row
+    per.append([1 if r == 30 else 0 for r in range(32)])                  # the output row: the state is carried to the spare row
+    b = ap.AirBuilder(48, 24, periodic=per)
+    full, act, out = b.per(12), b.per(13), b.per(14)
+    x = [b.loc(i) + b.per(i) for i in range(12)]
+    a, bb, t = [b.loc(12 + i) for i in range(12)], [b.loc(24 + i) for i in range(12)], [b.loc(36 + i) for i in range(12)]
+    for i in range(12):
+        b.assert_zero(a[i] - x[i] * x[i])
+    for i in range(12):
+        b.assert_zero(bb[i] - a[i] * a[i])
+    for i in range(12):
+        b.assert_zero(t[i] - x[i] * a[i] * bb[i])
+    y = [t[0]] + [full * t[i] + (1 - full) * x[i] for i in range(1, 12)]
+    for row in range(12):
+        acc = y[row] * (MDS_CIRC[0] + MDS_DIAG[row])
+        for i in range(1, 12):
+            acc = acc + y[(i + row) % 12] * MDS_CIRC[i]
+        b.assert_zero(act * (b.nxt(row) - acc))
+    for i in range(12):
+        b.assert_zero(out * (b.nxt(i) - b.loc(i)))
+    for i in range(12):
+        b.assert_first(b.loc(i) - b.pub(i))
+    for i in range(12):
+        b.assert_last(b.loc(i) - b.pub(12 + i))
+    return b
+
+
+def poseidon_trace(log_n, seed=9):
+    """2^(log_n - 5) permutations of seeded inputs -> (trace [48][2^log_n], public inputs = the first input ++ the last output,
+    the list of (input, output) pairs)."""
+    rc = poseidon_round_constants()
+    n = 1 << log_n
+    rng = np.random.default_rng(seed)
+    tr = np.zeros((48, n), dtype=np.uint64)
+    pairs = []
+    for blk in range(n // 32):
+        s = [int(v) for v in rng.integers(0, P, size=12, dtype=np.uint64)]
+        inp = list(s)
+        for r in range(32):
+            row = 32 * blk + r
+            x = [(s[i] + (rc[12 * r + i] if r < 30 else 0)) % P for i in range(12)]
+            a = [v * v % P for v in x]
+            b4 = [v * v % P for v in a]
+            t = [x[i] * a[i] % P * b4[i] % P for i in range(12)]
+            for i in range(12):
+                tr[i, row], tr[12 + i, row], tr[24 + i, row], tr[36 + i, row] = s[i], a[i], b4[i], t[i]
+            if r < 30:
+                full = r < 4 or r >= 26
+                y = [t[0]] + [t[i] if full else x[i] for i in range(1, 12)]
+                s = [(sum(y[(i + q) % 12] * MDS_CIRC[i] for i in range(12)) + y[q] * MDS_DIAG[q]) % P for q in range(12)]
+            # r = 30: the output is carried to row 31; r = 31: the next block starts from a fresh input
+        pairs.append((inp, list(s)))
+    return tr, pairs[0][0] + pairs[-1][1], pairs

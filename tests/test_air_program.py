@@ -108,6 +108,33 @@ def test_a_program_with_a_lookup_round(vx, oracle):
         vx.lib.stark_verify(bad, pcfg, expect_air=air_id)
 
 
+def test_poseidon_permutation_as_a_program(vx, oracle):
+    """PoseidonAir (tests/air_programs.py): the permutation behind every Merkle cap and transcript of this prover, one round per row,
+    as a 2,124-instruction program with 15 periodic columns -- the first table a recursive verifier would need.  Its trace
+    generator agrees with the reference permutation; the reference prover's proof is accepted by the product's host interpreter;
+    a wrong claimed output has no proof."""
+    from oracle import pyref
+
+    b = AP.poseidon_builder(vx.air_program)
+    air_id = b.register()
+    air = oracle_air(air_id, b)
+    S.register_air(air)
+    trace, pub, pairs = AP.poseidon_trace(7)
+    assert len(pairs) == 4 and all(pyref.poseidon(i) == o for i, o in pairs)
+    assert [int(v) for v in oracle.poseidon(np.array([pairs[0][0]], dtype=np.uint64))[0]] == pairs[0][1]
+    assert S.check_trace(air, trace, pub) is None
+    proof = S.prove(air, trace, pub, CFG)
+    pcfg = vx.lib.default_stark_config(num_queries=CFG["num_queries"])
+    vx.lib.stark_verify(proof, pcfg, expect_air=air_id, expect_public=pub)
+    wrong = pub[:12] + [(pub[12] + 1) % P] + pub[13:]
+    assert S.check_trace(air, trace, wrong) is not None
+    with pytest.raises(vx.VxError):
+        vx.lib.stark_verify(S.prove(air, trace, wrong, CFG), pcfg, expect_air=air_id)
+    bad = trace.copy()
+    bad[36, 40] ^= np.uint64(1)  # one x^7 cell of a partial round: row 40 = round 8 of the second permutation
+    assert S.check_trace(air, bad, pub) is not None
+
+
 def test_builder_shares_subexpressions_and_recycles_registers(vx):
     ap = vx.air_program
     b = ap.AirBuilder(2)

@@ -131,6 +131,39 @@ def test_a_program_with_a_lookup_round(ctx, vx, oracle):
         ctx.stark_prove(failing, ctx.from_host(trace), 9, pub)
 
 
+@pytest.mark.parametrize("log_n", [6, 9])
+def test_poseidon_permutation_as_a_program(ctx, vx, oracle, log_n):
+    """PoseidonAir (48 columns, 84 constraints of degree <= 3, 15 periodic columns, 2,124 instructions) on the GPU interpreter:
+    byte-identical to the reference prover; the public outputs are the reference permutation's."""
+    from oracle import pyref
+
+    b = AP.poseidon_builder(vx.air_program)
+    air_id = b.register()
+    air = oracle_air(air_id, b)
+    trace, pub, pairs = AP.poseidon_trace(log_n)
+    assert pyref.poseidon(pairs[-1][0]) == pub[12:]
+    got = ctx.stark_prove(air_id, ctx.from_host(trace), log_n, pub)
+    assert (got == S.prove(air, trace, pub)).all()
+    vx.lib.stark_verify(got, expect_air=air_id, expect_public=pub)
+    with pytest.raises(vx.VxError):
+        vx.lib.stark_verify(got, expect_air=air_id, expect_public=pub[:23] + [pub[23] ^ 1])
+
+
+def test_poseidon_program_at_scale(ctx, vx, oracle):
+    """2^15 rows = 1,024 permutations proven in one table; both verifiers accept, the GPU's own Poseidon kernel agrees with the
+    table's claimed outputs."""
+    b = AP.poseidon_builder(vx.air_program)
+    air_id = b.register()
+    oracle_air(air_id, b)
+    trace, pub, pairs = AP.poseidon_trace(15)
+    sb = ctx.from_host(np.array([p[0] for p in pairs], dtype=np.uint64))
+    ctx.poseidon(sb, len(pairs))
+    assert (sb.download().reshape(-1, 12) == np.array([p[1] for p in pairs], dtype=np.uint64)).all()
+    proof = ctx.stark_prove(air_id, ctx.from_host(trace), 15, pub)
+    vx.lib.stark_verify(proof, expect_air=air_id, expect_public=pub)
+    S.verify(proof, expect_air=air_id, expect_public=pub)
+
+
 def test_program_argument_errors(ctx, vx):
     b = AP.fib_builder(vx.air_program)
     air_id = b.register()

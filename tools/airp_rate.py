@@ -18,7 +18,8 @@ vx = vx_import.load()
 ctx = vx.Context(0)
 P = 2**64 - 2**32 + 1
 out = {}
-progs = {"fib": (1, AP.fib_builder(vx.air_program)), "mix": (2, AP.mix_builder(vx.air_program)), "cube": (None, AP.cube_builder(vx.air_program))}
+progs = {"fib": (1, AP.fib_builder(vx.air_program)), "mix": (2, AP.mix_builder(vx.air_program)), "cube": (None, AP.cube_builder(vx.air_program)),
+         "poseidon": (None, AP.poseidon_builder(vx.air_program))}
 for name, (compiled, b) in progs.items():
     pid = b.register()
     code = b.assemble()[0]
@@ -26,7 +27,7 @@ for name, (compiled, b) in progs.items():
         N = 2 << log_n
         buf = ctx.alloc(N * b.cols)
         ctx.fill_random(buf, N * b.cols, 5)
-        pub = [3, 5, 7][: b.n_public]
+        pub = list(range(3, 3 + b.n_public))
         qout = ctx.alloc(2 * N)
         al = np.array([11, 13], dtype=np.uint64)
         pb = np.array(pub, dtype=np.uint64)
