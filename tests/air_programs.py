@@ -161,3 +161,97 @@ def poseidon_trace(log_n, seed=9):
             # r = 30: the output is carried to row 31; r = 31: the next block starts from a fresh input
         pairs.append((inp, list(s)))
     return tr, pairs[0][0] + pairs[-1][1], pairs
+
+
+# ---- MerklePathAir: verify_merkle_proof_to_cap (plonky2 v0.2.0 hash/merkle_proofs.rs) for a cap of height 0 as a table -- the leaf
+# digest is hashed upwards with its siblings, one PoseidonAir block (32 rows) per level:  next input = (cur, sib) or (sib, cur)
+# by the level's index bit, zero capacity; public inputs: leaf digest (4), root (4), leaf index.  With PoseidonAir this is what a
+# recursive verifier's FRI queries are made of; it exists only as a constraint program.
+M_BIT, M_SIB, M_IDX, M_COLS = 48, 49, 53, 54
+
+
+def merkle_path_builder(ap, depth):
+    n = 32 * depth
+    assert n & (n - 1) == 0, "32 * depth rows must be a power of two"
+    rc = poseidon_round_constants()
+    per = [[rc[12 * r + i] if r < 30 else 0 for r in range(32)] for i in range(12)]
+    per.append([1 if (r < 4 or 26 <= r < 30) else 0 for r in range(32)])  # 12 full
+    per.append([1 if r < 30 else 0 for r in range(32)])                   # 13 a round row
+    per.append([1 if r == 30 else 0 for r in range(32)])                  # 14 the output row
+    per.append([1 if r == 31 else 0 for r in range(32)])                  # 15 the spare row (holds the level's output)
+    per.append([1 if (r % 32 == 31 and r != n - 1) else 0 for r in range(n)])        # 16 link: spare rows but the last (period = the trace)
+    per.append([(1 << (r // 32 + 1)) if (r % 32 == 31 and r != n - 1) else 0 for r in range(n)])  # 17 weight of the NEXT level's index bit
+    b = ap.AirBuilder(M_COLS, 9, periodic=per)
+    full, act, out, spare, link, pown = (b.per(q) for q in range(12, 18))
+    x = [b.loc(i) + b.per(i) for i in range(12)]
+    a, bb, t = [b.loc(12 + i) for i in range(12)], [b.loc(24 + i) for i in range(12)], [b.loc(36 + i) for i in range(12)]
+    for i in range(12):
+        b.assert_zero(a[i] - x[i] * x[i])
+    for i in range(12):
+        b.assert_zero(bb[i] - a[i] * a[i])
+    for i in range(12):
+        b.assert_zero(t[i] - x[i] * a[i] * bb[i])
+    y = [t[0]] + [full * t[i] + (1 - full) * x[i] for i in range(1, 12)]
+    for row in range(12):
+        acc = y[row] * (MDS_CIRC[0] + MDS_DIAG[row])
+        for i in range(1, 12):
+            acc = acc + y[(i + row) % 12] * MDS_CIRC[i]
+        b.assert_zero(act * (b.nxt(row) - acc))
+    for i in range(12):
+        b.assert_zero(out * (b.nxt(i) - b.loc(i)))
+    bit, bit_n = b.loc(M_BIT), b.nxt(M_BIT)
+    b.assert_zero(bit * (bit - 1))
+    # the next level's input from this level's output (on the spare row) and the next row's (bit, sibling)
+    for i in range(4):
+        cur, sib_n = b.loc(i), b.nxt(M_SIB + i)
+        d = bit_n * (sib_n - cur)
+        b.assert_zero(link * (b.nxt(i) - cur - d))              # left  = bit ? sib : cur
+        b.assert_zero(link * (b.nxt(4 + i) - sib_n + d))        # right = bit ? cur : sib
+    for i in range(8, 12):
+        b.assert_zero(link * b.nxt(i))
+    b.assert_zero(link * (b.nxt(M_IDX) - b.loc(M_IDX) - bit_n * pown))
+    b.assert_zero((1 - spare) * (b.nxt(M_IDX) - b.loc(M_IDX)))
+    # first row: the leaf digest enters level 0; last row: the root and the index
+    for i in range(4):
+        leaf, sib = b.pub(i), b.loc(M_SIB + i)
+        d = bit * (sib - leaf)
+        b.assert_first(b.loc(i) - leaf - d)
+        b.assert_first(b.loc(4 + i) - sib + d)
+    for i in range(8, 12):
+        b.assert_first(b.loc(i))
+    b.assert_first(b.loc(M_IDX) - bit)
+    for i in range(4):
+        b.assert_last(b.loc(i) - b.pub(4 + i))
+    b.assert_last(b.loc(M_IDX) - b.pub(8))
+    return b
+
+
+def merkle_path_trace(leaf_digest, index, siblings):
+    """-> (trace [54][32 * depth], public inputs [leaf(4), root(4), index])"""
+    rc = poseidon_round_constants()
+    depth = len(siblings)
+    n = 32 * depth
+    tr = np.zeros((M_COLS, n), dtype=np.uint64)
+    cur = [int(v) for v in leaf_digest]
+    idx_acc = 0
+    for lvl in range(depth):
+        bit = (index >> lvl) & 1
+        sib = [int(v) for v in siblings[lvl]]
+        s = (sib + cur if bit else cur + sib) + [0, 0, 0, 0]
+        idx_acc += bit << lvl
+        for r in range(32):
+            row = 32 * lvl + r
+            x = [(s[i] + (rc[12 * r + i] if r < 30 else 0)) % P for i in range(12)]
+            a = [v * v % P for v in x]
+            b4 = [v * v % P for v in a]
+            t = [x[i] * a[i] % P * b4[i] % P for i in range(12)]
+            for i in range(12):
+                tr[i, row], tr[12 + i, row], tr[24 + i, row], tr[36 + i, row] = s[i], a[i], b4[i], t[i]
+            tr[M_BIT, row], tr[M_IDX, row] = bit, idx_acc
+            tr[M_SIB:M_SIB + 4, row] = sib
+            if r < 30:
+                full = r < 4 or r >= 26
+                y = [t[0]] + [t[i] if full else x[i] for i in range(1, 12)]
+                s = [(sum(y[(i + q) % 12] * MDS_CIRC[i] for i in range(12)) + y[q] * MDS_DIAG[q]) % P for q in range(12)]
+        cur = s[:4]
+    return tr, [int(v) for v in leaf_digest] + cur + [index]

@@ -135,6 +135,39 @@ def test_poseidon_permutation_as_a_program(vx, oracle):
     assert S.check_trace(air, bad, pub) is not None
 
 
+def test_merkle_path_as_a_program(vx, oracle):
+    """MerklePathAir (tests/air_programs.py): verify_merkle_proof_to_cap as a table, one PoseidonAir block per level.  A path of the
+    reference Merkle tree (oracle.MerkleTree = plonky2's) gives a satisfying trace whose public root is the tree's cap; the product's
+    host interpreter accepts the reference prover's proof; another index, another sibling or another leaf cannot claim that root."""
+    depth = 8
+    b = AP.merkle_path_builder(vx.air_program, depth)
+    air_id = b.register()
+    air = oracle_air(air_id, b)
+    S.register_air(air)
+    rng = np.random.default_rng(3)
+    leaves = rng.integers(0, P, size=(1 << depth, 7), dtype=np.uint64)
+    tree = oracle.MerkleTree(leaves, 0)
+    root = [int(v) for v in tree.cap[0]]
+    pcfg = vx.lib.default_stark_config(num_queries=CFG["num_queries"])
+    for idx in (0, 0xB5, 255):
+        sib, dig = tree.prove(idx), tree.leaf_digests()[idx]
+        trace, pub = AP.merkle_path_trace(dig, idx, sib)
+        assert pub[4:8] == root and pub[8] == idx
+        assert S.check_trace(air, trace, pub) is None
+        if idx == 0xB5:
+            vx.lib.stark_verify(S.prove(air, trace, pub, CFG), pcfg, expect_air=air_id, expect_public=pub)
+            t2, p2 = AP.merkle_path_trace(dig, idx ^ 4, sib)                       # the same nodes, another position
+            assert p2[4:8] != root and S.check_trace(air, t2, p2[:4] + root + [idx ^ 4]) is not None
+            sib2 = sib.copy()
+            sib2[3, 1] ^= np.uint64(1)
+            t3, p3 = AP.merkle_path_trace(dig, idx, sib2)                          # a sibling that is not in the tree
+            assert S.check_trace(air, t3, p3[:4] + root + [idx]) is not None
+            assert S.check_trace(air, trace, pub[:8] + [idx ^ 1]) is not None      # the index is bound to the bits that steer the path
+            forged = S.prove(air, t3, p3[:4] + root + [idx], CFG)
+            with pytest.raises(vx.VxError):
+                vx.lib.stark_verify(forged, pcfg, expect_air=air_id)
+
+
 def test_builder_shares_subexpressions_and_recycles_registers(vx):
     ap = vx.air_program
     b = ap.AirBuilder(2)

@@ -164,6 +164,33 @@ def test_poseidon_program_at_scale(ctx, vx, oracle):
     S.verify(proof, expect_air=air_id, expect_public=pub)
 
 
+@pytest.mark.parametrize("depth", [8, 16])
+def test_merkle_path_of_a_gpu_tree_as_a_program(ctx, vx, oracle, depth):
+    """The prover proves a statement about its own commitments: a Merkle tree built by the GPU (vx_merkle_build, cap height 0), one of
+    its authentication paths (vx_merkle_open) turned into a MerklePathAir trace, proven on the GPU by the program interpreter --
+    byte-identical to the reference prover, and the public root is the cap the GPU tree reports."""
+    b = AP.merkle_path_builder(vx.air_program, depth)
+    air_id = b.register()
+    air = oracle_air(air_id, b)
+    rng = np.random.default_rng(depth)
+    leaves = rng.integers(0, P, size=(1 << depth, 9), dtype=np.uint64)
+    tree = ctx.merkle(ctx.from_host(leaves), 1 << depth, 9, vx.lib.VX_LEAVES_ROW_MAJOR, 0)
+    root = [int(v) for v in tree.cap()[0]]
+    assert root == [int(v) for v in oracle.MerkleTree(leaves, 0).cap[0]]
+    idx = int(rng.integers(0, 1 << depth))
+    sib, dig = tree.open([idx])[0], tree.leaf_digests()[idx]
+    assert oracle.merkle_verify(leaves[idx], idx, sib, tree.cap())
+    trace, pub = AP.merkle_path_trace(dig, idx, sib)
+    assert pub == [int(v) for v in dig] + root + [idx]
+    log_n = (32 * depth).bit_length() - 1
+    got = ctx.stark_prove(air_id, ctx.from_host(trace), log_n, pub)
+    assert (got == S.prove(air, trace, pub)).all()
+    vx.lib.stark_verify(got, expect_air=air_id, expect_public=pub)
+    with pytest.raises(vx.VxError):
+        vx.lib.stark_verify(got, expect_air=air_id, expect_public=pub[:8] + [idx ^ 1])
+    tree.free()
+
+
 def test_program_argument_errors(ctx, vx):
     b = AP.fib_builder(vx.air_program)
     air_id = b.register()
