@@ -7,7 +7,7 @@ the thin host side: ctypes binding, synthetic witness data, and the mirror of
 the reference's `Circuit::prove` interface.  There is NO CPU fallback: every
 entry point raises if the library or a GPU is missing.
 """
-from . import air_program, lib, shard, synth  # noqa: F401
+from . import air_library, air_program, lib, shard, synth  # noqa: F401
 from .lib import Context, VxError, load_library  # noqa: F401
 
-__all__ = ["air_program", "lib", "shard", "synth", "Context", "VxError", "load_library"]
+__all__ = ["air_library", "air_program", "lib", "shard", "synth", "Context", "VxError", "load_library"]
