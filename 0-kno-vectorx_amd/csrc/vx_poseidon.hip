@@ -121,6 +121,47 @@ __global__ void k_gather_siblings(const uint64_t* levels, size_t n_leaves, int d
     for (int e = 0; e < 4; ++e) out[4 * t + e] = levels[off + 4 * node + e];
 }
 
+
+// ---- witness of PoseidonAir (the permutation as a STARK table: air_library.py poseidon_builder; 48 columns, 32 rows per permutation).
+// Lane p walks the 30 rounds of permutation p in the PLAIN schedule (constant layer, s-box, MDS: the rows of the table are the
+// states entering each round, not the folded form the hashing kernels use) and writes the state, x^2, x^4 and x^7 of every row;
+// rows 30 and 31 of a block hold the output.  trace: column-major [48][32 n_perm].
+static __constant__ uint64_t POSEIDON_RC_PLAIN[360] = VX_POSEIDON_RC_INIT;
+__global__ __launch_bounds__(256) void k_poseidon_air_trace(const uint64_t* in, size_t n_perm, uint64_t* tr) {
+    const size_t p = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (p >= n_perm) return;
+    constexpr uint32_t C[12] = VX_POSEIDON_MDS_CIRC_INIT;
+    const size_t n = 32 * n_perm;
+    uint64_t s[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = gl_canon(in[12 * p + i]);
+#pragma unroll 1
+    for (int r = 0; r < 32; ++r) {
+        const size_t row = 32 * p + r;
+        const bool full = r < 4 || (r >= 26 && r < 30);
+        uint64_t y[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const uint64_t x = r < 30 ? gl_add(s[i], POSEIDON_RC_PLAIN[12 * r + i]) : s[i];
+            const uint64_t a = gl_mul(x, x), b = gl_mul(a, a), t = gl_mul(gl_mul(x, a), b);
+            tr[(size_t)i * n + row] = s[i];
+            tr[(size_t)(12 + i) * n + row] = a;
+            tr[(size_t)(24 + i) * n + row] = b;
+            tr[(size_t)(36 + i) * n + row] = t;
+            y[i] = (full || i == 0) ? t : x;
+        }
+        if (r < 30) {
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                unsigned __int128 acc = q == 0 ? (unsigned __int128)y[0] * VX_POSEIDON_MDS_DIAG0 : 0;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) acc += (unsigned __int128)y[(i + q) % 12] * C[i];
+                s[q] = gl_reduce128((uint64_t)(acc >> 64), (uint64_t)acc);
+            }
+        }
+    }
+}
+
 // levels above the leaf digests, down to `cap` nodes (levels = digests of level 0 followed by each parent level)
 void vx_merkle_levels_launch(vx_ctx* ctx, uint64_t* levels, size_t n_leaves, size_t cap) {
     size_t off = 0, cur = n_leaves;
@@ -186,6 +227,14 @@ int32_t vx_poseidon_permute_batch(vx_ctx* ctx, vx_buf* states, size_t n) {
     VX_CHECK(12 * n <= states->n, "poseidon batch: %zu states exceed the buffer", n);
     if (n == 0) return VX_OK;
     hipLaunchKernelGGL(k_poseidon_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, states->d, n);
+    VX_HIP(hipGetLastError());
+    return VX_OK;
+}
+int32_t vx_poseidon_air_trace(vx_ctx* ctx, const vx_buf* states, size_t n_perm, vx_buf* trace_out) {
+    if (!ctx || !states || !trace_out) return VX_ERR_ARG;
+    VX_CHECK(n_perm >= 1 && (n_perm & (n_perm - 1)) == 0 && n_perm <= ((size_t)1 << 22), "poseidon air trace: %zu permutations (a power of two, at most 2^22)", n_perm);
+    VX_CHECK(12 * n_perm <= states->n && 48 * 32 * n_perm <= trace_out->n, "poseidon air trace: buffers too small");
+    hipLaunchKernelGGL(k_poseidon_air_trace, dim3((unsigned)((n_perm + 255) / 256)), dim3(256), 0, ctx->stream, states->d, n_perm, trace_out->d);
     VX_HIP(hipGetLastError());
     return VX_OK;
 }

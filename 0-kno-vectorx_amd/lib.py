@@ -28,7 +28,7 @@ SYMBOLS = [
     "vx_ed25519_verify_batch", "vx_verify_simple_justification", "vx_sha_chain_trace",
     "vx_verify_epoch_end_header", "vx_rotate_proof_bound", "vx_rotate_prove", "vx_rotate_verify",
     "vx_gather_proofs", "vx_quotient_eval", "vx_decode_header_batch", "vx_decode_precommit_batch", "vx_stark_aux_trace",
-    "vx_ed_trace", "vx_sha512_trace", "vx_epoch_end_trace", "vx_partial_products", "vx_air_register", "vx_air_unregister",
+    "vx_ed_trace", "vx_sha512_trace", "vx_epoch_end_trace", "vx_partial_products", "vx_air_register", "vx_air_unregister", "vx_poseidon_air_trace",
 ]
 
 VX_AIR_FIBONACCI, VX_AIR_MIX, VX_AIR_BLAKE_CHAIN, VX_AIR_LOOKUP = 1, 2, 6, 5
@@ -160,6 +160,7 @@ def load_library():
         "vx_decode_precommit_batch": [vp, vp, sz, vp, vp, vp, vp, vp],
         "vx_stark_aux_trace": [vp, C.c_int, vp, C.c_int, vp, sz, vp, sz, vp, vp],
         "vx_air_register": [C.POINTER(AirProgramStruct), C.POINTER(C.c_int), C.c_char_p, sz], "vx_air_unregister": [C.c_int],
+        "vx_poseidon_air_trace": [vp, vp, sz, vp],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -489,6 +490,12 @@ class Context:
     # K4
     def poseidon(self, states_buf, n):
         self._ck(self.L.vx_poseidon_permute_batch(self.h, states_buf.h, n))
+
+    def poseidon_air_trace(self, states_buf, n_perm, out=None):
+        """The witness of PoseidonAir (air_library.poseidon_builder) for n_perm input states -> Buffer [48][32 * n_perm]."""
+        out = out or self.alloc(48 * 32 * n_perm)
+        self._ck(self.L.vx_poseidon_air_trace(self.h, states_buf.h, n_perm, out.h))
+        return out
 
     def merkle(self, data, n_leaves, leaf_len, layout, cap_height, off=0):
         t = C.c_void_p()

@@ -212,6 +212,12 @@ typedef struct vx_air_program {
 } vx_air_program;
 int32_t vx_air_register(const vx_air_program* program, int* air_id, char* err, size_t errlen);
 int32_t vx_air_unregister(int air_id);
+/* The witness of PoseidonAir -- the Poseidon permutation as a STARK table (0-kno-vectorx_amd/air_library.py poseidon_builder: 48
+ * columns, one round per row, 32 rows per permutation; the constraint program ships with the library and is registered by the
+ * host): states = n_perm x 12 input words, trace_out = [48][32 * n_perm] column-major with the state, x^2, x^4 and x^7 of every
+ * round row; rows 30 / 31 of a block hold the permutation's output.  n_perm a power of two.  What a recursive verifier's hashing
+ * table is filled with (plonky2 v0.2.0 hash/poseidon.rs; reached from Circuit::prove's recursion, circuits/header_range.rs:167). */
+int32_t vx_poseidon_air_trace(vx_ctx* ctx, const vx_buf* states, size_t n_perm, vx_buf* trace_out);
 /* K5: batched constraint / quotient-polynomial evaluation (starky prover.rs compute_quotient_polys) for an AIR compiled
  * into the library or registered as a program.  trace_lde: column-major [cols][N], N = 2^(log_n + rate_bits), natural order, values on the coset
  * 7 * <w_N>.  out[k*N + i] = (sum_j alpha_k^(K-1-j) c_j(x_i)) / Z_H(x_i) for the two challenges k = 0, 1. */

@@ -149,6 +149,32 @@ def test_poseidon_permutation_as_a_program(ctx, vx, oracle, log_n):
         vx.lib.stark_verify(got, expect_air=air_id, expect_public=pub[:23] + [pub[23] ^ 1])
 
 
+def test_poseidon_air_witness_on_the_gpu(ctx, vx, oracle):
+    """vx_poseidon_air_trace: the GPU's witness of PoseidonAir equals the reference generator's cell by cell; at 2^20 rows (32,768
+    permutations of random states, filled, proven and verified without the trace ever leaving HBM) the outputs in the table are the
+    ones the hashing kernel computes."""
+    trace, pub, pairs = AP.poseidon_trace(8)
+    sb = ctx.from_host(np.array([p[0] for p in pairs], dtype=np.uint64))
+    got = ctx.poseidon_air_trace(sb, len(pairs)).download().reshape(48, -1)
+    assert (got == trace).all()
+    b = AP.poseidon_builder()
+    air_id = b.register()
+    n_perm, log_n = 1 << 15, 20
+    states = ctx.alloc(12 * n_perm)
+    ctx.fill_random(states, 12 * n_perm, 99)
+    tb = ctx.poseidon_air_trace(states, n_perm)
+    n = 32 * n_perm
+    first_in = states.download(12)
+    last_out = np.array([tb.download(1, i * n + n - 1)[0] for i in range(12)], dtype=np.uint64)
+    ctx.poseidon(states, n_perm)
+    assert (states.download(12, 12 * (n_perm - 1)) == last_out).all()
+    pub = [int(v) for v in first_in] + [int(v) for v in last_out]
+    proof = ctx.stark_prove(air_id, tb, log_n, pub)
+    vx.lib.stark_verify(proof, expect_air=air_id, expect_public=pub)
+    with pytest.raises(vx.VxError):
+        ctx.poseidon_air_trace(states, 3)  # not a power of two
+
+
 def test_poseidon_program_at_scale(ctx, vx, oracle):
     """2^15 rows = 1,024 permutations proven in one table; both verifiers accept, the GPU's own Poseidon kernel agrees with the
     table's claimed outputs."""
