@@ -3,6 +3,7 @@ the two tables a recursive STARK verifier is mostly made of (plonky
 
   poseidon_builder()        PoseidonAir   -- the Poseidon-Goldilocks permutation (width 12, x^7, 4 + 22 + 4 rounds), one round per row
   merkle_path_builder(d)    MerklePathAir -- verify_merkle_proof_to_cap for a cap of height 0: d levels, one PoseidonAir block each
+  sponge_builder(k)         SpongeAir     -- hash_n_to_hash_no_pad of 8 k words (the leaf hash of a Merkle tree): k blocks, overwrite mode
 
 Each returns an AirBuilder (`.register()` gives the AIR id; `.assemble()` the code).  The witness (trace) of these tables is the
 host's to fill: tests/air_programs.py has reference generators; tests/test_gpu_air_program.py proves a path of a GPU-built tree."""
@@ -123,3 +124,51 @@ def merkle_path_builder(depth):
     return b
 
 
+
+
+def sponge_builder(blocks):
+    """SpongeAir: plonky2's hash_n_to_hash_no_pad (hash/hashing.rs: the sponge absorbs 8 words per permutation by OVERWRITING the
+    rate part of the state, capacity carried; the digest is the first 4 words of the last output) for a message of 8 * blocks words
+    -- what hashes an opened row into the leaf digest MerklePathAir starts from.  `blocks` PoseidonAir blocks (a power of two);
+    public inputs: the message (8 * blocks words) then the digest (4)."""
+    n = 32 * blocks
+    assert blocks >= 1 and n & (n - 1) == 0 and 8 * blocks + 4 <= 64
+    rc = poseidon_round_constants()
+    per = [[rc[12 * r + i] if r < 30 else 0 for r in range(32)] for i in range(12)]
+    per.append([1 if (r < 4 or 26 <= r < 30) else 0 for r in range(32)])  # 12 full
+    per.append([1 if r < 30 else 0 for r in range(32)])                   # 13 a round row
+    per.append([1 if r == 30 else 0 for r in range(32)])                  # 14 the output row
+    for blk in range(1, blocks):                                           # 15.. : the spare row before block blk (period = the trace)
+        per.append([1 if r == 32 * blk - 1 else 0 for r in range(n)])
+    b = ap.AirBuilder(48, 8 * blocks + 4, periodic=per)
+    full, act, out = b.per(12), b.per(13), b.per(14)
+    x = [b.loc(i) + b.per(i) for i in range(12)]
+    a, bb, t = [b.loc(12 + i) for i in range(12)], [b.loc(24 + i) for i in range(12)], [b.loc(36 + i) for i in range(12)]
+    for i in range(12):
+        b.assert_zero(a[i] - x[i] * x[i])
+    for i in range(12):
+        b.assert_zero(bb[i] - a[i] * a[i])
+    for i in range(12):
+        b.assert_zero(t[i] - x[i] * a[i] * bb[i])
+    y = [t[0]] + [full * t[i] + (1 - full) * x[i] for i in range(1, 12)]
+    for row in range(12):
+        acc = y[row] * (MDS_CIRC[0] + MDS_DIAG[row])
+        for i in range(1, 12):
+            acc = acc + y[(i + row) % 12] * MDS_CIRC[i]
+        b.assert_zero(act * (b.nxt(row) - acc))
+    for i in range(12):
+        b.assert_zero(out * (b.nxt(i) - b.loc(i)))
+    # absorbing block blk: the rate part is overwritten with the next 8 message words, the capacity is carried
+    for blk in range(1, blocks):
+        sel = b.per(14 + blk)
+        for i in range(8):
+            b.assert_zero(sel * (b.nxt(i) - b.pub(8 * blk + i)))
+        for i in range(8, 12):
+            b.assert_zero(sel * (b.nxt(i) - b.loc(i)))
+    for i in range(8):
+        b.assert_first(b.loc(i) - b.pub(i))
+    for i in range(8, 12):
+        b.assert_first(b.loc(i))
+    for i in range(4):
+        b.assert_last(b.loc(i) - b.pub(8 * blocks + i))
+    return b

@@ -159,3 +159,33 @@ def merkle_path_trace(leaf_digest, index, siblings):
                 s = [(sum(y[(i + q) % 12] * MDS_CIRC[i] for i in range(12)) + y[q] * MDS_DIAG[q]) % P for q in range(12)]
         cur = s[:4]
     return tr, [int(v) for v in leaf_digest] + cur + [index]
+
+
+def sponge_builder(blocks):
+    return _lib.sponge_builder(blocks)
+
+
+def sponge_trace(message):
+    """-> (trace [48][32 * blocks], public inputs = message ++ digest) for a message of 8 * blocks words"""
+    rc = poseidon_round_constants()
+    msg = [int(v) % P for v in message]
+    blocks = len(msg) // 8
+    assert len(msg) == 8 * blocks
+    n = 32 * blocks
+    tr = np.zeros((48, n), dtype=np.uint64)
+    s = [0] * 12
+    for blk in range(blocks):
+        s = msg[8 * blk: 8 * blk + 8] + s[8:]
+        for r in range(32):
+            row = 32 * blk + r
+            x = [(s[i] + (rc[12 * r + i] if r < 30 else 0)) % P for i in range(12)]
+            a = [v * v % P for v in x]
+            b4 = [v * v % P for v in a]
+            t = [x[i] * a[i] % P * b4[i] % P for i in range(12)]
+            for i in range(12):
+                tr[i, row], tr[12 + i, row], tr[24 + i, row], tr[36 + i, row] = s[i], a[i], b4[i], t[i]
+            if r < 30:
+                full = r < 4 or r >= 26
+                y = [t[0]] + [t[i] if full else x[i] for i in range(1, 12)]
+                s = [(sum(y[(i + q) % 12] * MDS_CIRC[i] for i in range(12)) + y[q] * MDS_DIAG[q]) % P for q in range(12)]
+    return tr, msg + s[:4]

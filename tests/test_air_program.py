@@ -168,6 +168,28 @@ def test_merkle_path_as_a_program(vx, oracle):
                 vx.lib.stark_verify(forged, pcfg, expect_air=air_id)
 
 
+@pytest.mark.parametrize("blocks", [1, 4])
+def test_sponge_as_a_program(vx, oracle, blocks):
+    """SpongeAir: hash_n_to_hash_no_pad of 8 * blocks words as a table.  Its digest is the leaf digest the reference Merkle tree
+    (oracle.MerkleTree = plonky2's hash_or_noop on a row longer than 4 words) computes for the same row; another digest or another
+    message word has no proof."""
+    b = AP.sponge_builder(blocks)
+    air_id = b.register()
+    air = oracle_air(air_id, b)
+    S.register_air(air)
+    rng = np.random.default_rng(blocks)
+    leaves = rng.integers(0, P, size=(4, 8 * blocks), dtype=np.uint64)
+    want = [int(v) for v in oracle.MerkleTree(leaves, 0).leaf_digests()[2]]
+    trace, pub = AP.sponge_trace(leaves[2])
+    assert pub[-4:] == want
+    assert S.check_trace(air, trace, pub) is None
+    pcfg = vx.lib.default_stark_config(num_queries=CFG["num_queries"])
+    vx.lib.stark_verify(S.prove(air, trace, pub, CFG), pcfg, expect_air=air_id, expect_public=pub)
+    assert S.check_trace(air, trace, pub[:-1] + [pub[-1] ^ 1]) is not None
+    if blocks > 1:
+        assert S.check_trace(air, trace, pub[:9] + [pub[9] ^ 1] + pub[10:]) is not None  # a word of the second block
+
+
 def test_builder_shares_subexpressions_and_recycles_registers(vx):
     ap = vx.air_program
     b = ap.AirBuilder(2)

@@ -217,6 +217,23 @@ def test_merkle_path_of_a_gpu_tree_as_a_program(ctx, vx, oracle, depth):
     tree.free()
 
 
+def test_sponge_of_a_gpu_leaf_as_a_program(ctx, vx, oracle):
+    """SpongeAir on the GPU: the digest in the table's public inputs is the leaf digest the GPU's own Merkle kernel computes for the
+    same 32-word row; the proof is byte-identical to the reference prover's."""
+    b = AP.sponge_builder(4)
+    air_id = b.register()
+    air = oracle_air(air_id, b)
+    rng = np.random.default_rng(5)
+    leaves = rng.integers(0, P, size=(16, 32), dtype=np.uint64)
+    tree = ctx.merkle(ctx.from_host(leaves), 16, 32, vx.lib.VX_LEAVES_ROW_MAJOR, 0)
+    trace, pub = AP.sponge_trace(leaves[11])
+    assert pub[-4:] == [int(v) for v in tree.leaf_digests()[11]]
+    got = ctx.stark_prove(air_id, ctx.from_host(trace), 7, pub)
+    assert (got == S.prove(air, trace, pub)).all()
+    vx.lib.stark_verify(got, expect_air=air_id, expect_public=pub)
+    tree.free()
+
+
 def test_program_argument_errors(ctx, vx):
     b = AP.fib_builder(vx.air_program)
     air_id = b.register()
