@@ -80,7 +80,7 @@ int main() {
     hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
     uint64_t cx = 0, cy = 0;
     for (size_t i = 0; i < 64 * 256; ++i) cx ^= h[2 * i] + i, cy += h[2 * i + 1] % 0xFFFFFFFF00000001ULL;
-    printf("{\"fp64\": %d, \"checksum\": \"%016llx%016llx\"", VX_POSEIDON_FP64, (unsigned long long)cx, (unsigned long long)cy);
+    printf("{\"fp64\": %d, \"split_partial\": %d, \"checksum\": \"%016llx%016llx\"", VX_POSEIDON_FP64, VX_POSEIDON_SPLIT_PARTIAL, (unsigned long long)cx, (unsigned long long)cy);
     struct { const char* n; kern k; double scale; } ks[] = {
         {"perm_cycles_per_wave", k_perm, (double)ITER * 64 / PITER}, {"mds12_cycles_per_layer", k_mds, (double)ITER * 64 / (PITER * 30)},
         {"mds1_cycles_per_layer", k_mds1, (double)ITER * 64 / (PITER * 30)}, {"v_add_f64", k_add_f64, 1}, {"v_fma_f64", k_fma_f64, 1}, {"v_mul_f64", k_mul_f64, 1}};
